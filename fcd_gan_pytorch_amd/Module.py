@@ -1,0 +1,222 @@
+"""Drop-in for the reference's ``Module.py`` (same class names, constructor
+signatures, ``forward`` signatures and ``state_dict`` keys), running on the
+hand-written HIP kernels of ``libfcdgan_hip.so``.
+
+How it differs from a layer-by-layer module tree:
+ * parameter holders are stock ``nn.Conv2d`` / ``nn.BatchNorm2d`` / ``nn.PReLU``
+   objects (=> identical default initialisation, RNG consumption and checkpoint
+   layout) whose arithmetic is never used -- every ``forward`` here calls the
+   fused HIP ops directly with the holders' tensors;
+ * BatchNorm + ReLU/LeakyReLU/PReLU is one fused op;
+ * the Siamese encoder (reference Module.py:114-131) and the Discriminator's
+   shared ``net`` (Module.py:220-221) run both branches as ONE batch of 2N
+   samples; BN keeps per-branch statistics and ordered running-stat updates via
+   ``groups=2`` (see include/fcdgan_hip.h: fcd_bn_act_fwd).
+CUDA/ROCm tensors only: there is no CPU fallback in the product.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _ops as ops
+
+__all__ = ['DoubleConv', 'Down', 'Up', 'OutConv', 'Segmentor', 'Generator', 'ResidualBlock',
+           'Discriminator_SRGAN_simple']
+
+
+def _conv(holder, x):
+    """Apply an nn.Conv2d parameter holder through the MFMA implicit-GEMM kernel."""
+    return ops.conv2d(x, holder.weight, holder.bias, holder.stride[0], holder.padding[0])
+
+
+class DoubleConv(nn.Module):
+    """(conv3x3 p1 -> BN -> ReLU) x 2 -- reference Module.py:18-35.
+    ``double_conv`` keeps the reference's Sequential indices 0,1,(2),3,4,(5)."""
+
+    def __init__(self, in_channels, out_channels, mid_channels=None):
+        super().__init__()
+        mid = mid_channels if mid_channels else out_channels
+        self.double_conv = nn.Sequential(
+            nn.Conv2d(in_channels, mid, kernel_size=3, padding=1), nn.BatchNorm2d(mid), nn.ReLU(inplace=True),
+            nn.Conv2d(mid, out_channels, kernel_size=3, padding=1), nn.BatchNorm2d(out_channels),
+            nn.ReLU(inplace=True))
+
+    def forward(self, x, groups=1):
+        s = self.double_conv
+        x = ops.bn_act(_conv(s[0], x), s[1], ops.ACT_RELU, groups=groups)
+        return ops.bn_act(_conv(s[3], x), s[4], ops.ACT_RELU, groups=groups)
+
+
+class Down(nn.Module):
+    """MaxPool2d(2) then DoubleConv -- reference Module.py:38-49."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.maxpool_conv = nn.Sequential(nn.MaxPool2d(2), DoubleConv(in_channels, out_channels))
+
+    def forward(self, x, groups=1):
+        return self.maxpool_conv[1](ops.maxpool2(x), groups=groups)
+
+
+class Up(nn.Module):
+    """x2 upsample (bilinear align_corners=True | ConvTranspose2d k2 s2), zero-pad to
+    the skip's size, cat([skip, up]), DoubleConv -- reference Module.py:52-79."""
+
+    def __init__(self, in_channels, out_channels, bilinear=False):
+        super().__init__()
+        if bilinear:
+            self.up = nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True)
+            self.conv = DoubleConv(in_channels, out_channels, in_channels // 2)
+        else:
+            self.up = nn.ConvTranspose2d(in_channels, in_channels // 2, kernel_size=2, stride=2)
+            self.conv = DoubleConv(in_channels, out_channels)
+        self.bilinear = bool(bilinear)
+
+    def forward(self, x1, x2):
+        if self.bilinear:
+            x1 = ops.upsample2x(x1)
+        else:
+            x1 = ops.conv_transpose2x2(x1, self.up.weight, self.up.bias)
+        dy, dx = x2.shape[2] - x1.shape[2], x2.shape[3] - x1.shape[3]
+        if dy or dx:
+            x1 = F.pad(x1, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])
+        return self.conv(torch.cat([x2, x1], dim=1))
+
+
+class OutConv(nn.Module):
+    """1x1 conv + sigmoid -> change-density map -- reference Module.py:82-90."""
+
+    def __init__(self, in_channels, out_channels):
+        super(OutConv, self).__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=1)
+        self.Sigmoid = nn.Sigmoid()
+
+    def forward(self, x):
+        return torch.sigmoid(_conv(self.conv, x))
+
+
+class Segmentor(nn.Module):
+    """Siamese U-Net -- reference Module.py:93-140."""
+
+    def __init__(self, n_channels, n_outchannels=1, bilinear=False):
+        super(Segmentor, self).__init__()
+        self.n_channels = n_channels
+        self.n_outchannels = n_outchannels
+        self.bilinear = bilinear
+        factor = 2 if bilinear else 1
+        self.inc = DoubleConv(n_channels, 64)
+        self.down1 = Down(64, 128)
+        self.down2 = Down(128, 256)
+        self.down3 = Down(256, 512)
+        self.down4 = Down(512, 1024 // factor)
+        self.up1 = Up(2048, 1024 // factor, bilinear)
+        self.up2 = Up(1024, 512 // factor, bilinear)
+        self.up3 = Up(512, 256 // factor, bilinear)
+        self.up4 = Up(256, 128, bilinear)
+        self.outc = OutConv(128, n_outchannels)
+
+    @staticmethod
+    def _pair(f, n):
+        # (2N,C,h,w) two-branch features -> (N,2C,h,w) = cat([branch1, branch2], dim=1)
+        return torch.cat([f[:n], f[n:]], dim=1)
+
+    def forward(self, x1, x2):
+        n = x1.shape[0]
+        f = self.inc(torch.cat([x1, x2], dim=0), groups=2)      # both temporal branches in one batch
+        skips = [self._pair(f, n)]
+        for stage in (self.down1, self.down2, self.down3, self.down4):
+            f = stage(f, groups=2)
+            skips.append(self._pair(f, n))
+        x = self.up1(skips[4], skips[3])
+        x = self.up2(x, skips[2])
+        x = self.up3(x, skips[1])
+        x = self.up4(x, skips[0])
+        return self.outc(x)
+
+
+class ResidualBlock(nn.Module):
+    """conv-BN-PReLU-conv-BN + identity -- reference Module.py:174-190."""
+
+    def __init__(self, channels):
+        super(ResidualBlock, self).__init__()
+        self.conv1 = nn.Conv2d(channels, channels, kernel_size=3, padding=1)
+        self.bn1 = nn.BatchNorm2d(channels)
+        self.prelu = nn.PReLU()
+        self.conv2 = nn.Conv2d(channels, channels, kernel_size=3, padding=1)
+        self.bn2 = nn.BatchNorm2d(channels)
+
+    def forward(self, x):
+        r = ops.bn_act(_conv(self.conv1, x), self.bn1, ops.ACT_PRELU, slope=self.prelu.weight)
+        r = ops.bn_act(_conv(self.conv2, r), self.bn2, ops.ACT_NONE)
+        return x + r
+
+
+class Generator(nn.Module):
+    """SRGAN-style generator, raw (no tanh) output -- reference Module.py:142-172."""
+
+    def __init__(self, n_channels):
+        super(Generator, self).__init__()
+        self.block1 = nn.Sequential(nn.Conv2d(n_channels, 64, kernel_size=9, padding=4), nn.PReLU())
+        self.block2 = ResidualBlock(64)
+        self.block3 = ResidualBlock(64)
+        self.block4 = ResidualBlock(64)
+        self.block5 = ResidualBlock(64)
+        self.block6 = ResidualBlock(64)
+        self.block7 = nn.Sequential(nn.Conv2d(64, 64, kernel_size=3, padding=1), nn.BatchNorm2d(64))
+        self.block8 = nn.Conv2d(64, n_channels, kernel_size=9, padding=4)
+
+    def forward(self, x):
+        b1 = ops.bn_act(_conv(self.block1[0], x), None, ops.ACT_PRELU, slope=self.block1[1].weight)
+        h = b1
+        for blk in (self.block2, self.block3, self.block4, self.block5, self.block6):
+            h = blk(h)
+        h = ops.bn_act(_conv(self.block7[0], h), self.block7[1], ops.ACT_NONE)
+        return _conv(self.block8, b1 + h)
+
+
+class Discriminator_SRGAN_simple(nn.Module):
+    """4x stride-2 conv3x3 (+BN) + LeakyReLU(0.2) shared by both inputs, classifier on
+    the feature DIFFERENCE -- reference Module.py:192-223."""
+
+    def __init__(self, n_channels=3):
+        super(Discriminator_SRGAN_simple, self).__init__()
+        self.net = nn.Sequential(
+            nn.Conv2d(n_channels, 64, kernel_size=3, stride=2, padding=1), nn.LeakyReLU(0.2, inplace=True),
+            nn.Conv2d(64, 128, kernel_size=3, stride=2, padding=1), nn.BatchNorm2d(128),
+            nn.LeakyReLU(0.2, inplace=True),
+            nn.Conv2d(128, 256, kernel_size=3, stride=2, padding=1), nn.BatchNorm2d(256),
+            nn.LeakyReLU(0.2, inplace=True),
+            nn.Conv2d(256, 512, kernel_size=3, stride=2, padding=1), nn.BatchNorm2d(512),
+            nn.LeakyReLU(0.2, inplace=True))
+        self.classifier = nn.Sequential(
+            nn.AdaptiveAvgPool2d(1), nn.Conv2d(512, 1024, kernel_size=1), nn.LeakyReLU(0.2, inplace=True),
+            nn.Conv2d(1024, 1, kernel_size=1))
+
+    def features(self, z, groups):
+        """Shared ``net`` on a batch made of ``groups`` independent calls (BN statistics
+        per call, running stats updated call by call)."""
+        s = self.net
+        z = ops.bn_act(_conv(s[0], z), None, ops.ACT_LEAKY, slope_imm=0.2, groups=groups)
+        for ci, bi in ((2, 3), (5, 6), (8, 9)):
+            z = ops.bn_act(_conv(s[ci], z), s[bi], ops.ACT_LEAKY, slope_imm=0.2, groups=groups)
+        return z
+
+    def classify(self, diff):
+        c = self.classifier
+        d = diff.mean(dim=(2, 3), keepdim=True)
+        d = ops.bn_act(_conv(c[1], d), None, ops.ACT_LEAKY, slope_imm=0.2)
+        return torch.sigmoid(_conv(c[3], d).view(diff.shape[0]))
+
+    def forward(self, x, y):
+        n = x.shape[0]
+        f = self.features(torch.cat([x, y], dim=0), groups=2)
+        return self.classify(f[:n] - f[n:])
+
+    def forward_pairs(self, pairs):
+        """Evaluate several (x, y) pairs in one batched pass; equivalent to calling
+        ``forward`` on each pair in order (BN running stats see x1,y1,x2,y2,...)."""
+        n = pairs[0][0].shape[0]
+        z = torch.cat([t for p in pairs for t in p], dim=0)
+        f = self.features(z, groups=2 * len(pairs))
+        return [self.classify(f[(2 * i) * n:(2 * i + 1) * n] - f[(2 * i + 1) * n:(2 * i + 2) * n])
+                for i in range(len(pairs))]

@@ -1,0 +1,111 @@
+"""ctypes binding of ``libfcdgan_hip.so`` (C ABI declared in include/fcdgan_hip.h).
+
+There is NO fallback: if the shared library is missing or a symbol cannot be
+resolved, importing this module raises -- the product never silently routes
+around the HIP kernels.
+"""
+import ctypes
+import os
+import subprocess
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libfcdgan_hip.so')
+CSRC = os.path.join(_HERE, 'csrc')
+
+
+class FcdError(RuntimeError):
+    pass
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP sources in-tree with hipcc for gfx950 (works without a GPU)."""
+    if force and os.path.exists(LIB_PATH):
+        os.remove(LIB_PATH)
+    cmd = ['make', '-C', CSRC, '-j', str(max(2, os.cpu_count() or 2))]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout)
+    if r.returncode != 0 or not os.path.exists(LIB_PATH):
+        raise FcdError('building libfcdgan_hip.so failed (make -C %s)' % CSRC)
+    return LIB_PATH
+
+
+class ConvDesc(Structure):
+    _fields_ = [(n, c_int32) for n in ('N', 'C', 'H', 'W', 'K', 'R', 'S', 'stride', 'pad', 'P', 'Q')]
+
+
+P = c_void_p  # device pointers travel as plain addresses
+
+_SIGS = {
+    'fcd_version': (c_int, []),
+    'fcd_last_error_string': (c_char_p, []),
+    'fcd_conv_packed_elems': (c_int64, [c_int, c_int, c_int, c_int, c_int]),
+    'fcd_conv_pack_weights': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    'fcd_conv2d_fwd': (c_int, [POINTER(ConvDesc), P, P, P, P, P]),
+    'fcd_conv2d_bwd_data': (c_int, [POINTER(ConvDesc), P, P, P, P]),
+    'fcd_conv2d_bwd_weight_ws_bytes': (c_size_t, [POINTER(ConvDesc)]),
+    'fcd_conv2d_bwd_weight': (c_int, [POINTER(ConvDesc), P, P, P, P, c_size_t, P]),
+    'fcd_channel_sum': (c_int, [P, P, c_int, c_int, c_int, P]),
+    'fcd_bn_act_ws_bytes': (c_size_t, [c_int, c_int]),
+    'fcd_bn_act_fwd': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_float, c_float, c_int,
+                               P, P, c_int, P, c_float, P, c_size_t, P]),
+    'fcd_bn_act_bwd': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_float, c_int, P, P,
+                               c_int, P, c_float, P, P, P, P, c_size_t, P]),
+    'fcd_maxpool2_fwd': (c_int, [P, P, c_int, c_int, c_int, P]),
+    'fcd_maxpool2_bwd': (c_int, [P, P, P, c_int, c_int, c_int, P]),
+    'fcd_upsample2x_fwd': (c_int, [P, P, c_int, c_int, c_int, P]),
+    'fcd_upsample2x_bwd': (c_int, [P, P, c_int, c_int, c_int, P]),
+    'fcd_avgpool2_pad_fwd': (c_int, [P, P, c_int, c_int, c_int, P]),
+    'fcd_avgpool2_pad_bwd': (c_int, [P, P, c_int, c_int, c_int, P]),
+    'fcd_masked_recon_ws_bytes': (c_size_t, [c_int]),
+    'fcd_masked_recon_fwd': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
+    'fcd_masked_recon_bwd': (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    'fcd_ssim_ws_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'fcd_ssim_level_fwd': (c_int, [P, P, P, c_int, P, c_int, c_int, c_int, c_float, c_float, P, c_size_t, P]),
+    'fcd_ssim_level_bwd': (c_int, [P, P, P, c_int, P, P, P, P, c_int, c_int, c_int, c_float, c_float, P, c_size_t, P]),
+    'fcd_adam_step': (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int, c_float, P]),
+    'fcd_rmsprop_step': (c_int, [P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, P]),
+    'fcd_prof_enable': (None, [c_int]),
+    'fcd_prof_families': (c_int, []),
+    'fcd_prof_read': (c_int, [POINTER(c_double), c_int]),
+    'fcd_prof_family_name': (c_char_p, [c_int]),
+}
+
+EXPORTS = sorted(_SIGS)
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise FcdError('libfcdgan_hip.so not found at %s -- run `python -c "import __graft_entry__ as g; '
+                       'g.build()"` (needs hipcc); there is no CPU fallback.' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise FcdError('libfcdgan_hip.so does not export %s (stale build?)' % name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = lib.fcd_last_error_string()
+        raise FcdError('%s failed (%d): %s' % (what or 'fcd call', rc, msg.decode() if msg else ''))
+
+
+def prof_read(reset=True):
+    """{family: dict(ms, launches, flops, bytes)} accumulated since the last reset."""
+    nf = lib.fcd_prof_families()
+    buf = (c_double * (nf * 4))()
+    check(lib.fcd_prof_read(buf, 1 if reset else 0), 'fcd_prof_read')
+    out = {}
+    for f in range(nf):
+        out[lib.fcd_prof_family_name(f).decode()] = dict(ms=buf[f * 4], launches=int(buf[f * 4 + 1]),
+                                                         flops=buf[f * 4 + 2], bytes=buf[f * 4 + 3])
+    return out

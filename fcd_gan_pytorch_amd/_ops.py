@@ -1,0 +1,379 @@
+"""torch.autograd.Function wrappers around the C ABI (include/fcdgan_hip.h).
+
+PyTorch is plumbing here: it owns device memory (caching allocator), the HIP
+stream and the autograd tape (so ``loss.backward(retain_graph=True)`` followed
+by a second backward over the same graph, Demo_USSS.py:327,338 /
+Demo_RSSS.py:305,331, works unchanged).  All arithmetic of the ops below runs
+in the hand-written HIP kernels; CPU tensors are rejected (no fallback).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, check, lib
+
+ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_PRELU = 0, 1, 2, 3
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _dev(t, name='tensor'):
+    if not t.is_cuda:
+        raise _lib.FcdError('fcd_gan_pytorch_amd: %s is on %s; the HIP path needs a CUDA/ROCm tensor '
+                            '(no CPU fallback)' % (name, t.device))
+    if t.dtype != torch.float32:
+        raise _lib.FcdError('fcd_gan_pytorch_amd: %s must be float32, got %s' % (name, t.dtype))
+    return t.contiguous()
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+# --------------------------------------------------------------------------- conv
+def _desc(xs, ws, stride, pad):
+    N, C, H, W = xs
+    K, C2, R, S = ws
+    if C != C2:
+        raise _lib.FcdError('conv2d: input has %d channels, weight expects %d' % (C, C2))
+    P = (H + 2 * pad - R) // stride + 1
+    Q = (W + 2 * pad - S) // stride + 1
+    return ConvDesc(N, C, H, W, K, R, S, stride, pad, P, Q)
+
+
+def packed_weight(weight, mode):
+    """Packed GEMM-A layout of ``weight`` (mode 0 forward / 1 data-grad), cached on
+    the tensor object and keyed by its version counter.  fcd optimizers update
+    parameters outside autograd's view and call :func:`invalidate_packs`."""
+    cache = weight.__dict__.setdefault('_fcd_pack', {})
+    ver = weight._version
+    hit = cache.get(mode)
+    if hit is not None and hit[0] == ver and hit[1].device == weight.device:
+        return hit[1]
+    K, C, R, S = weight.shape
+    n = lib.fcd_conv_packed_elems(K, C, R, S, mode)
+    wp = torch.empty(n, dtype=torch.float32, device=weight.device)
+    w = weight.detach().contiguous()
+    check(lib.fcd_conv_pack_weights(_p(w), _p(wp), K, C, R, S, mode, _stream()), 'fcd_conv_pack_weights')
+    cache[mode] = (ver, wp)
+    return wp
+
+
+def invalidate_packs(params):
+    for p in params:
+        p.__dict__.pop('_fcd_pack', None)
+
+
+class _Conv2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad):
+        x = _dev(x, 'conv input')
+        weight_c = _dev(weight, 'conv weight')
+        d = _desc(x.shape, weight.shape, stride, pad)
+        y = torch.empty((d.N, d.K, d.P, d.Q), dtype=torch.float32, device=x.device)
+        wp = packed_weight(weight, 0)
+        b = _dev(bias, 'conv bias') if bias is not None else None
+        check(lib.fcd_conv2d_fwd(ctypes.byref(d), _p(x), _p(wp), _p(b), _p(y), _stream()), 'fcd_conv2d_fwd')
+        ctx.save_for_backward(x, weight)
+        ctx.geom = (stride, pad, bias is not None)
+        del weight_c
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        stride, pad, has_bias = ctx.geom
+        dy = _dev(dy, 'conv grad')
+        d = _desc(x.shape, weight.shape, stride, pad)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            wpb = packed_weight(weight, 1)
+            check(lib.fcd_conv2d_bwd_data(ctypes.byref(d), _p(dy), _p(wpb), _p(dx), _stream()), 'fcd_conv2d_bwd_data')
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
+            nb = lib.fcd_conv2d_bwd_weight_ws_bytes(ctypes.byref(d))
+            ws = _ws(nb, x.device)
+            check(lib.fcd_conv2d_bwd_weight(ctypes.byref(d), _p(x), _p(dy), _p(dw), _p(ws), ws.numel(), _stream()),
+                  'fcd_conv2d_bwd_weight')
+        if has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty(d.K, dtype=torch.float32, device=x.device)
+            check(lib.fcd_channel_sum(_p(dy), _p(db), d.N, d.K, d.P * d.Q, _stream()), 'fcd_channel_sum')
+        return dx, dw, db, None, None
+
+
+def conv2d(x, weight, bias=None, stride=1, padding=0):
+    return _Conv2d.apply(x, weight, bias, int(stride), int(padding))
+
+
+class _ConvT2x2(torch.autograd.Function):
+    """ConvTranspose2d(k=2, s=2) (Module.py:63) == data-gradient of the 2x2/stride-2
+    convolution whose filter tensor is the transposed-conv weight (Cin, Cout, 2, 2)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = _dev(x, 'convT input')
+        Cin, Cout = weight.shape[0], weight.shape[1]
+        N, _, h, w = x.shape
+        # the "forward conv" maps (N,Cout,2h,2w) -> (N,Cin,h,w)
+        d = ConvDesc(N, Cout, 2 * h, 2 * w, Cin, 2, 2, 2, 0, h, w)
+        y = torch.empty((N, Cout, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
+        wpb = packed_weight(weight, 1)
+        check(lib.fcd_conv2d_bwd_data(ctypes.byref(d), _p(x), _p(wpb), _p(y), _stream()), 'convT fwd')
+        if bias is not None:
+            y += bias.view(1, -1, 1, 1)
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = _dev(dy, 'convT grad')
+        Cin, Cout = weight.shape[0], weight.shape[1]
+        N, _, h, w = x.shape
+        d = ConvDesc(N, Cout, 2 * h, 2 * w, Cin, 2, 2, 2, 0, h, w)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            wp = packed_weight(weight, 0)
+            check(lib.fcd_conv2d_fwd(ctypes.byref(d), _p(dy), _p(wp), None, _p(dx), _stream()), 'convT bwd data')
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
+            ws = _ws(lib.fcd_conv2d_bwd_weight_ws_bytes(ctypes.byref(d)), x.device)
+            check(lib.fcd_conv2d_bwd_weight(ctypes.byref(d), _p(dy), _p(x), _p(dw), _p(ws), ws.numel(), _stream()),
+                  'convT bwd weight')
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty(Cout, dtype=torch.float32, device=x.device)
+            check(lib.fcd_channel_sum(_p(dy), _p(db), N, Cout, 4 * h * w, _stream()), 'fcd_channel_sum')
+        return dx, dw, db
+
+
+def conv_transpose2x2(x, weight, bias=None):
+    return _ConvT2x2.apply(x, weight, bias)
+
+
+# ----------------------------------------------------------------- BN + activation
+class _BnAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, slope, running_mean, running_var, training, momentum, eps, groups, act,
+                slope_imm):
+        x = _dev(x, 'bn input')
+        N, C, H, W = x.shape
+        has_bn = gamma is not None
+        y = torch.empty_like(x)
+        save_mean = save_invstd = None
+        if has_bn and training:
+            save_mean = torch.empty(groups * C, dtype=torch.float32, device=x.device)
+            save_invstd = torch.empty(groups * C, dtype=torch.float32, device=x.device)
+        ws = _ws(lib.fcd_bn_act_ws_bytes(C, groups), x.device)
+        check(lib.fcd_bn_act_fwd(_p(x), _p(y), N, C, H * W, groups, int(has_bn), _p(gamma), _p(beta),
+                                 _p(running_mean), _p(running_var), float(momentum), float(eps), int(training),
+                                 _p(save_mean), _p(save_invstd), act, _p(slope), float(slope_imm), _p(ws),
+                                 ws.numel(), _stream()), 'fcd_bn_act_fwd')
+        ctx.save_for_backward(x, gamma, beta, slope, save_mean, save_invstd, running_mean, running_var)
+        ctx.cfg = (bool(training), float(eps), groups, act, float(slope_imm), has_bn)
+        return y
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, gamma, beta, slope, save_mean, save_invstd, running_mean, running_var = ctx.saved_tensors
+        training, eps, groups, act, slope_imm, has_bn = ctx.cfg
+        dz = _dev(dz, 'bn grad')
+        N, C, H, W = x.shape
+        dx = torch.empty_like(x)
+        dgamma = dbeta = dslope = None
+        if has_bn and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
+            dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+            dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+        if slope is not None and ctx.needs_input_grad[3]:
+            dslope = torch.empty(1, dtype=torch.float32, device=x.device)
+        ws = _ws(lib.fcd_bn_act_ws_bytes(C, groups), x.device)
+        check(lib.fcd_bn_act_bwd(_p(dz), _p(x), _p(dx), N, C, H * W, groups, int(has_bn), _p(gamma), _p(beta),
+                                 _p(running_mean), _p(running_var), eps, int(training), _p(save_mean),
+                                 _p(save_invstd), act, _p(slope), slope_imm, _p(dgamma), _p(dbeta), _p(dslope),
+                                 _p(ws), ws.numel(), _stream()), 'fcd_bn_act_bwd')
+        if dslope is not None:
+            dslope = dslope.view(slope.shape)
+        return dx, dgamma, dbeta, dslope, None, None, None, None, None, None, None, None
+
+
+def bn_act(x, bn=None, act=ACT_NONE, slope=None, slope_imm=0.0, groups=1):
+    """y = act(BatchNorm(x)).  ``bn``: an nn.BatchNorm2d-like holder (weight, bias,
+    running_mean, running_var, momentum, eps, training, num_batches_tracked) or
+    None for a bare activation.  ``slope``: PReLU weight tensor (1 element)."""
+    if bn is None:
+        return _BnAct.apply(x, None, None, slope, None, None, False, 0.0, 0.0, groups, act, slope_imm)
+    training = bn.training or bn.running_mean is None
+    if training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += groups
+    return _BnAct.apply(x, bn.weight, bn.bias, slope, bn.running_mean, bn.running_var, training,
+                        bn.momentum if bn.momentum is not None else 0.1, bn.eps, groups, act, slope_imm)
+
+
+# -------------------------------------------------------------- pooling / resize
+class _MaxPool2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _dev(x, 'maxpool input')
+        N, C, H, W = x.shape
+        y = torch.empty((N, C, H // 2, W // 2), dtype=torch.float32, device=x.device)
+        check(lib.fcd_maxpool2_fwd(_p(x), _p(y), N * C, H, W, _stream()), 'fcd_maxpool2_fwd')
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = _dev(dy, 'maxpool grad')
+        N, C, H, W = x.shape
+        dx = torch.empty_like(x)
+        check(lib.fcd_maxpool2_bwd(_p(x), _p(dy), _p(dx), N * C, H, W, _stream()), 'fcd_maxpool2_bwd')
+        return dx
+
+
+def maxpool2(x):
+    return _MaxPool2.apply(x)
+
+
+class _Upsample2x(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _dev(x, 'upsample input')
+        N, C, H, W = x.shape
+        y = torch.empty((N, C, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
+        check(lib.fcd_upsample2x_fwd(_p(x), _p(y), N * C, H, W, _stream()), 'fcd_upsample2x_fwd')
+        ctx.shape = (N, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, C, H, W = ctx.shape
+        dy = _dev(dy, 'upsample grad')
+        dx = torch.empty((N, C, H, W), dtype=torch.float32, device=dy.device)
+        check(lib.fcd_upsample2x_bwd(_p(dy), _p(dx), N * C, H, W, _stream()), 'fcd_upsample2x_bwd')
+        return dx
+
+
+def upsample2x(x):
+    return _Upsample2x.apply(x)
+
+
+class _AvgPool2Pad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _dev(x, 'avgpool input')
+        N, C, H, W = x.shape
+        P = (H + 2 * (H % 2) - 2) // 2 + 1
+        Q = (W + 2 * (W % 2) - 2) // 2 + 1
+        y = torch.empty((N, C, P, Q), dtype=torch.float32, device=x.device)
+        check(lib.fcd_avgpool2_pad_fwd(_p(x), _p(y), N * C, H, W, _stream()), 'fcd_avgpool2_pad_fwd')
+        ctx.shape = (N, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, C, H, W = ctx.shape
+        dy = _dev(dy, 'avgpool grad')
+        dx = torch.empty((N, C, H, W), dtype=torch.float32, device=dy.device)
+        check(lib.fcd_avgpool2_pad_bwd(_p(dy), _p(dx), N * C, H, W, _stream()), 'fcd_avgpool2_pad_bwd')
+        return dx
+
+
+def avgpool2_pad(x):
+    return _AvgPool2Pad.apply(x)
+
+
+# ------------------------------------------------------------------------ losses
+class _MaskedSums(torch.autograd.Function):
+    """out[2N] = {num[n], wsum[n]} of include/fcdgan_hip.h:fcd_masked_recon_fwd."""
+
+    @staticmethod
+    def forward(ctx, a, b, m, kind, complement):
+        a = _dev(a, 'masked-sum a')
+        b = _dev(b, 'masked-sum b') if b is not None else None
+        m = _dev(m, 'masked-sum mask')
+        N, C, H, W = a.shape
+        out = torch.empty(2 * N, dtype=torch.float32, device=a.device)
+        ws = _ws(lib.fcd_masked_recon_ws_bytes(N), a.device)
+        check(lib.fcd_masked_recon_fwd(_p(a), _p(b), _p(m), _p(out), N, C, H * W, kind, int(complement), _p(ws),
+                                       ws.numel(), _stream()), 'fcd_masked_recon_fwd')
+        ctx.save_for_backward(a, b, m)
+        ctx.cfg = (kind, int(complement))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b, m = ctx.saved_tensors
+        kind, complement = ctx.cfg
+        N, C, H, W = a.shape
+        g = _dev(g, 'masked-sum grad')
+        coef, cw = g[:N].contiguous(), g[N:].contiguous()
+        da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        db = torch.empty_like(a) if (b is not None and ctx.needs_input_grad[1]) else None
+        dm = torch.empty_like(m) if ctx.needs_input_grad[2] else None
+        check(lib.fcd_masked_recon_bwd(_p(a), _p(b), _p(m), _p(coef), _p(cw), _p(da), _p(db), _p(dm), N, C, H * W,
+                                       kind, complement, _stream()), 'fcd_masked_recon_bwd')
+        return da, db, dm, None, None
+
+
+def masked_sums(a, b, m, kind, complement):
+    """(num[N], wsum[N]) with d=(a-b)*w, w = (1-m) if complement else m."""
+    out = _MaskedSums.apply(a, b, m, kind, complement)
+    N = a.shape[0]
+    return out[:N], out[N:]
+
+
+class _SsimLevel(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, X, Y, win, C1, C2):
+        X = _dev(X, 'ssim X')
+        Y = _dev(Y, 'ssim Y')
+        win = _dev(win, 'ssim window')
+        N, C, H, W = X.shape
+        out = torch.empty(2 * N * C, dtype=torch.float32, device=X.device)
+        ws = _ws(16 * N * C * ((H + 15) // 16) * ((W + 31) // 32), X.device)   # fp64 {ssim, cs} per tile
+        check(lib.fcd_ssim_level_fwd(_p(X), _p(Y), _p(win), win.numel(), _p(out), N * C, H, W, C1, C2, _p(ws),
+                                     ws.numel(), _stream()), 'fcd_ssim_level_fwd')
+        ctx.save_for_backward(X, Y, win)
+        ctx.consts = (C1, C2)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        X, Y, win = ctx.saved_tensors
+        C1, C2 = ctx.consts
+        N, C, H, W = X.shape
+        NC = N * C
+        g = _dev(g, 'ssim grad')
+        gs, gc = g[:NC].contiguous(), g[NC:].contiguous()
+        dX, dY = torch.empty_like(X), torch.empty_like(Y)
+        ws = _ws(lib.fcd_ssim_ws_bytes(NC, H, W), X.device)
+        check(lib.fcd_ssim_level_bwd(_p(X), _p(Y), _p(win), win.numel(), _p(gs), _p(gc), _p(dX), _p(dY), NC, H, W,
+                                     C1, C2, _p(ws), ws.numel(), _stream()), 'fcd_ssim_level_bwd')
+        return dX, dY, None, None, None
+
+
+def ssim_level(X, Y, win, C1, C2):
+    """(ssim_mean[N,C], cs_mean[N,C]) -- ssim.py:55-92."""
+    N, C = X.shape[0], X.shape[1]
+    out = _SsimLevel.apply(X, Y, win, float(C1), float(C2))
+    return out[:N * C].view(N, C), out[N * C:].view(N, C)
+
+
+# -------------------------------------------------------------------- optimizers
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    check(lib.fcd_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
+                            grad_scale, _stream()), 'fcd_adam_step')
+
+
+def rmsprop_step(p, g, sq, lr, alpha, eps, weight_decay, grad_scale=1.0):
+    check(lib.fcd_rmsprop_step(_p(p), _p(g), _p(sq), p.numel(), lr, alpha, eps, weight_decay, grad_scale, _stream()),
+          'fcd_rmsprop_step')

@@ -1,0 +1,100 @@
+// Shared host/device helpers for libfcdgan_hip.so (gfx950 / MI355X only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+
+#include "../../include/fcdgan_hip.h"
+
+#define FCD_WAVE 64
+
+// ---- error plumbing: never throw across the C ABI --------------------------
+void fcd_set_error(const char* fmt, ...);
+
+#define FCD_CHECK_ARG(cond, ...)                 \
+  do {                                           \
+    if (!(cond)) {                               \
+      fcd_set_error(__VA_ARGS__);                \
+      return FCD_ERR_INVALID;                    \
+    }                                            \
+  } while (0)
+
+#define FCD_LAUNCH_CHECK(name)                                              \
+  do {                                                                      \
+    hipError_t e__ = hipGetLastError();                                     \
+    if (e__ != hipSuccess) {                                                \
+      fcd_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+      return FCD_ERR_LAUNCH;                                                \
+    }                                                                       \
+  } while (0)
+
+// ---- per-kernel-family timing (HIP events on the launch stream) ------------
+// Family ids index the table returned by fcd_prof_read().
+enum {
+  FCD_K_CONV_FWD = 0,   // implicit-GEMM MFMA conv used as forward
+  FCD_K_CONV_DGRAD = 1, // same kernel used as data-gradient
+  FCD_K_CONV_WGRAD = 2, // MFMA weight-gradient kernel (+ split reduce)
+  FCD_K_PACK = 3,       // weight repacking
+  FCD_K_NORM = 4,       // BN statistics / apply / backward, activations
+  FCD_K_POOL = 5,       // maxpool / bilinear / avgpool
+  FCD_K_LOSS = 6,       // masked recon, SSIM, reductions
+  FCD_K_OPTIM = 7,      // Adam / RMSprop
+  FCD_K_MISC = 8,
+  FCD_K_COUNT = 9
+};
+
+struct FcdProfScope {
+  int fam;
+  hipStream_t st;
+  hipEvent_t e0, e1;
+  bool on;
+  FcdProfScope(int family, hipStream_t stream, double flops, double bytes);
+  ~FcdProfScope();
+};
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int round_up(int a, int b) { return cdiv(a, b) * b; }
+
+// ---- device helpers ---------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Block-wide sum (blockDim.x multiple of 64, <= 1024).  Result valid in thread 0.
+__device__ __forceinline__ double block_sum_d(double v, double* smem /* >= 16 doubles */) {
+  v = wave_sum_d(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) smem[w] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0) {
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int i = 0; i < nw; ++i) r += smem[i];
+  }
+  return r;
+}
+
+// activation codes shared by host + device
+// act: 0 none, 1 ReLU, 2 LeakyReLU(slope scalar), 3 PReLU(slope from device pointer)
+__device__ __forceinline__ float act_apply(float v, int act, float slope) {
+  if (act == FCD_ACT_NONE) return v;
+  if (act == FCD_ACT_RELU) return v > 0.f ? v : 0.f;
+  return v > 0.f ? v : v * slope;
+}
+// derivative factor d act(v) / d v  (PyTorch convention: slope branch at v <= 0)
+__device__ __forceinline__ float act_grad(float v, int act, float slope) {
+  if (act == FCD_ACT_NONE) return 1.f;
+  if (act == FCD_ACT_RELU) return v > 0.f ? 1.f : 0.f;
+  return v > 0.f ? 1.f : slope;
+}

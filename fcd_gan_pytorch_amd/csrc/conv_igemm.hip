@@ -1,0 +1,360 @@
+// Implicit-GEMM fp32 convolution on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// GEMM view:  Y[k][pixel] = sum_{(c,r,s)} Wp[(c,r,s)][k] * Xpatch[c][pixel + (r,s)]
+//   M = output channels (MFMA rows), N = output pixels of one image tile (MFMA
+//   cols, contiguous in NCHW => coalesced stores), Kdim = C*R*S.
+// Per workgroup (256 threads = 4 waves): BM x BN output tile; the K loop walks
+// channel chunks of CB channels; each step stages the CB x (TH+R-1) x (TW+S-1)
+// input patch and the matching CB*RCH*S x BM slab of pre-packed filter taps in
+// LDS (global -> registers -> LDS, issued one step ahead so HBM/L2 latency hides
+// under the MFMAs of the current step), then every wave reads its A/B operands
+// with conflict-free ds_read_b32 (lanes 0-31 walk consecutive k / pixels, the
+// two wave halves take the two k-slices of the 32x32x2 MFMA = two channels).
+//
+// The same kernel serves: forward (mode-0 packed weights), stride-1 data
+// gradient (mode-1 packed = flipped/transposed taps, pad' = R-1-pad) and, with
+// DIL=2, the data gradient of stride-2 convolutions (reads a zero-dilated dY).
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvArgs {
+  const float* x;
+  const float* wp;
+  const float* bias;
+  float* y;
+  int N, C, H, W;   // stored input tensor
+  int K, Kpad;      // real / packed output channels
+  int P, Q;         // output extent
+  int pad;
+  int nchunks;      // ceil(C / CB)
+  int tiles_p, tiles_q;
+};
+
+template <int R, int S, int RCH, int STRIDE, int DIL, int CB, int MI, int NI, int WM, int WN, int TH,
+          int TW>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+  constexpr int BM = 32 * MI * WM;
+  constexpr int BN = 32 * NI * WN;
+  static_assert(WM * WN == 4, "4 waves");
+  static_assert(TH * TW == BN, "pixel tile");
+  static_assert(R % RCH == 0, "row chunks");
+  constexpr int PH = (TH - 1) * STRIDE + R;
+  constexpr int PW = (TW - 1) * STRIDE + S;
+  constexpr int PWP = PW | 1;
+  constexpr int PLANE = PH * PWP;
+  constexpr int KC = CB * RCH * S;  // packed-weight rows per step
+  constexpr int NR = R / RCH;       // steps per channel chunk
+  constexpr int W_F4 = KC * BM / 4;
+  constexpr int W_PER_T = (W_F4 + 255) / 256;
+  constexpr int X_ELEMS = CB * PH * PW;
+  constexpr int X_PER_T = (X_ELEMS + 255) / 256;
+
+  __shared__ __attribute__((aligned(16))) float smem[KC * BM + CB * PLANE];
+  float* Ws = smem;
+  float* Xs = smem + KC * BM;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wm = wave / WN, wn = wave % WN;
+
+  int bx = blockIdx.x;
+  const int tq = bx % a.tiles_q;
+  bx /= a.tiles_q;
+  const int tp = bx % a.tiles_p;
+  const int n = bx / a.tiles_p;
+  const int ko0 = blockIdx.y * BM;
+  const int p0 = tp * TH, q0 = tq * TW;
+
+  int xoff[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int pidx = wn * (32 * NI) + ni * 32 + l31;
+    xoff[ni] = half * PLANE + (pidx / TW) * STRIDE * PWP + (pidx % TW) * STRIDE;
+  }
+  const int woff = half * (RCH * S) * BM + wm * (32 * MI) + l31;
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  float4 wr[W_PER_T];
+  float xr[X_PER_T];
+
+  const float* xin = a.x + (size_t)n * a.C * a.H * a.W;
+  const int ih0 = p0 * STRIDE - a.pad, iw0 = q0 * STRIDE - a.pad;
+
+  auto load_w = [&](int cchunk, int rr) {
+#pragma unroll
+    for (int i = 0; i < W_PER_T; ++i) {
+      const int idx = tid + i * 256;
+      if (W_F4 % 256 == 0 || idx < W_F4) {
+        const int row = idx / (BM / 4), col4 = idx % (BM / 4);
+        const int cc = row / (RCH * S), rem = row % (RCH * S);
+        const int grow = (cchunk * CB + cc) * (R * S) + rr * (RCH * S) + rem;
+        wr[i] = *reinterpret_cast<const float4*>(a.wp + (size_t)grow * a.Kpad + ko0 + col4 * 4);
+      }
+    }
+  };
+  auto store_w = [&]() {
+#pragma unroll
+    for (int i = 0; i < W_PER_T; ++i) {
+      const int idx = tid + i * 256;
+      if (W_F4 % 256 == 0 || idx < W_F4) *reinterpret_cast<float4*>(Ws + idx * 4) = wr[i];
+    }
+  };
+  auto load_x = [&](int cchunk) {
+#pragma unroll
+    for (int i = 0; i < X_PER_T; ++i) {
+      const int idx = tid + i * 256;
+      float v = 0.f;
+      if (idx < X_ELEMS) {
+        const int cc = idx / (PH * PW), rem = idx % (PH * PW);
+        const int ph = rem / PW, pw = rem % PW;
+        const int c = cchunk * CB + cc;
+        int ih = ih0 + ph, iw = iw0 + pw;
+        bool ok = (c < a.C) && ih >= 0 && iw >= 0;
+        if (DIL == 2) {
+          ok = ok && !((ih | iw) & 1);
+          ih >>= 1;
+          iw >>= 1;
+        }
+        ok = ok && ih < a.H && iw < a.W;
+        if (ok) v = xin[((size_t)c * a.H + ih) * a.W + iw];
+      }
+      xr[i] = v;
+    }
+  };
+  auto store_x = [&]() {
+#pragma unroll
+    for (int i = 0; i < X_PER_T; ++i) {
+      const int idx = tid + i * 256;
+      if (idx < X_ELEMS) {
+        const int cc = idx / (PH * PW), rem = idx % (PH * PW);
+        Xs[cc * PLANE + (rem / PW) * PWP + (rem % PW)] = xr[i];
+      }
+    }
+  };
+
+  const int nsteps = a.nchunks * NR;
+  load_x(0);
+  load_w(0, 0);
+  store_x();
+  store_w();
+  __syncthreads();
+
+  for (int step = 0; step < nsteps; ++step) {
+    const int nxt = step + 1;
+    const int rr = (NR == 1) ? 0 : step % NR;
+    const bool have_next = nxt < nsteps;
+    const bool next_patch = have_next && (NR == 1 || nxt % NR == 0);
+    if (have_next) {
+      if (next_patch) load_x(nxt / NR);
+      load_w(nxt / NR, (NR == 1) ? 0 : nxt % NR);
+    }
+
+    const float* wl = Ws + woff;
+    const float* xl = Xs + rr * RCH * PWP;
+#pragma unroll
+    for (int cc2 = 0; cc2 < CB / 2; ++cc2) {
+#pragma unroll
+      for (int rl = 0; rl < RCH; ++rl) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+          float av[MI], bv[NI];
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) av[mi] = wl[((cc2 * 2) * (RCH * S) + rl * S + s) * BM + mi * 32];
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) bv[ni] = xl[xoff[ni] + (cc2 * 2) * PLANE + rl * PWP + s];
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+    if (have_next) {
+      if (next_patch) store_x();
+      store_w();
+    }
+    __syncthreads();
+  }
+
+  // epilogue: D layout col = lane&31 (pixel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (channel)
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int pidx = wn * (32 * NI) + ni * 32 + l31;
+    const int p = p0 + pidx / TW, q = q0 + pidx % TW;
+    if (p >= a.P || q >= a.Q) continue;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ko = ko0 + wm * (32 * MI) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (ko < a.K) {
+          float v = acc[mi][ni][r];
+          if (a.bias) v += a.bias[ko];
+          a.y[(((size_t)n * a.K + ko) * a.P + p) * a.Q + q] = v;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// weight packing
+__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int K, int C,
+                                    int R, int S, int rows, int cols, int mode) {
+  const int64_t total = (int64_t)rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int col = (int)(i % cols);
+    const int row = (int)(i / cols);
+    const int tap = row % (R * S), ch = row / (R * S);
+    const int r = tap / S, s = tap % S;
+    float v = 0.f;
+    if (mode == 0) {  // row = (c, r, s), col = k
+      if (ch < C && col < K) v = w[(((int64_t)col * C + ch) * R + r) * S + s];
+    } else {  // row = (k, r', s'), col = c ; flipped taps
+      if (ch < K && col < C) v = w[(((int64_t)ch * C + col) * R + (R - 1 - r)) * S + (S - 1 - s)];
+    }
+    wp[i] = v;
+  }
+}
+
+static inline int cb_for(int R, int S) { return (R * S == 1) ? 32 : 8; }
+
+static void packed_dims(int K, int C, int R, int S, int mode, int* rows, int* cols) {
+  const int cb = cb_for(R, S);
+  if (mode == 0) {
+    *rows = round_up(C, cb) * R * S;
+    *cols = round_up(K, 128);
+  } else {
+    *rows = round_up(K, cb) * R * S;
+    *cols = round_up(C, 128);
+  }
+}
+
+extern "C" int64_t fcd_conv_packed_elems(int K, int C, int R, int S, int mode) {
+  int rows, cols;
+  packed_dims(K, C, R, S, mode, &rows, &cols);
+  return (int64_t)rows * cols;
+}
+
+extern "C" int fcd_conv_pack_weights(const float* w, float* wp, int K, int C, int R, int S, int mode,
+                                     void* stream) {
+  FCD_CHECK_ARG(w && wp && K > 0 && C > 0 && R > 0 && S > 0 && (mode == 0 || mode == 1),
+                "fcd_conv_pack_weights: bad arguments");
+  int rows, cols;
+  packed_dims(K, C, R, S, mode, &rows, &cols);
+  const int64_t total = (int64_t)rows * cols;
+  const int grid = (int)std::min<int64_t>(cdiv64(total, 256), 4096);
+  FcdProfScope prof(FCD_K_PACK, (hipStream_t)stream, 0.0, 8.0 * total);
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, wp, K, C, R,
+                     S, rows, cols, mode);
+  FCD_LAUNCH_CHECK("pack_weights");
+  return FCD_OK;
+}
+
+// ---------------------------------------------------------------------------
+// dispatch
+template <int R, int S, int RCH, int STRIDE, int DIL, int CB, int MI, int NI, int WM, int WN, int TH,
+          int TW>
+static int launch_cfg(const ConvArgs& a0, hipStream_t st) {
+  ConvArgs a = a0;
+  constexpr int BM = 32 * MI * WM;
+  a.tiles_p = cdiv(a.P, TH);
+  a.tiles_q = cdiv(a.Q, TW);
+  a.nchunks = cdiv(a.C, CB);
+  dim3 grid((unsigned)(a.N * a.tiles_p * a.tiles_q), (unsigned)cdiv(a.K, BM));
+  hipLaunchKernelGGL((conv_igemm_kernel<R, S, RCH, STRIDE, DIL, CB, MI, NI, WM, WN, TH, TW>), grid,
+                     dim3(256), 0, st, a);
+  return 0;
+}
+
+template <int R, int S, int RCH, int STRIDE, int DIL, int CB>
+static int launch_family(const ConvArgs& a, hipStream_t st) {
+  const bool wide = a.Q > 16;  // 4x32 pixel tiles for wide maps, 8x16 otherwise
+  if (a.K > 64) {
+    return wide ? launch_cfg<R, S, RCH, STRIDE, DIL, CB, 2, 2, 2, 2, 4, 32>(a, st)
+                : launch_cfg<R, S, RCH, STRIDE, DIL, CB, 2, 2, 2, 2, 8, 16>(a, st);
+  } else if (a.K > 32) {
+    return wide ? launch_cfg<R, S, RCH, STRIDE, DIL, CB, 2, 1, 1, 4, 4, 32>(a, st)
+                : launch_cfg<R, S, RCH, STRIDE, DIL, CB, 2, 1, 1, 4, 8, 16>(a, st);
+  }
+  return wide ? launch_cfg<R, S, RCH, STRIDE, DIL, CB, 1, 1, 1, 4, 4, 32>(a, st)
+              : launch_cfg<R, S, RCH, STRIDE, DIL, CB, 1, 1, 1, 4, 8, 16>(a, st);
+}
+
+// generic entry: input tensor (N,C,H,W) -> output (N,K,P,Q) with filter RxS.
+static int conv_dispatch(const ConvArgs& a, int R, int S, int stride, int dil, hipStream_t st) {
+  if (R == 3 && S == 3 && stride == 1 && dil == 1) return launch_family<3, 3, 3, 1, 1, 8>(a, st);
+  if (R == 3 && S == 3 && stride == 2 && dil == 1) return launch_family<3, 3, 3, 2, 1, 8>(a, st);
+  if (R == 3 && S == 3 && stride == 1 && dil == 2) return launch_family<3, 3, 3, 1, 2, 8>(a, st);
+  if (R == 9 && S == 9 && stride == 1 && dil == 1) return launch_family<9, 9, 1, 1, 1, 8>(a, st);
+  if (R == 1 && S == 1 && stride == 1 && dil == 1) return launch_family<1, 1, 1, 1, 1, 32>(a, st);
+  if (R == 2 && S == 2 && stride == 2 && dil == 1) return launch_family<2, 2, 2, 2, 1, 8>(a, st);
+  if (R == 2 && S == 2 && stride == 1 && dil == 2) return launch_family<2, 2, 2, 1, 2, 8>(a, st);
+  return -1;
+}
+
+static int check_desc(const fcd_conv_desc* d, const char* who) {
+  FCD_CHECK_ARG(d, "%s: null desc", who);
+  FCD_CHECK_ARG(d->N > 0 && d->C > 0 && d->H > 0 && d->W > 0 && d->K > 0, "%s: non-positive dims", who);
+  FCD_CHECK_ARG(d->stride == 1 || d->stride == 2, "%s: stride %d unsupported", who, d->stride);
+  const int P = (d->H + 2 * d->pad - d->R) / d->stride + 1;
+  const int Q = (d->W + 2 * d->pad - d->S) / d->stride + 1;
+  FCD_CHECK_ARG(P == d->P && Q == d->Q && P > 0 && Q > 0, "%s: output size (%d,%d) != expected (%d,%d)",
+                who, d->P, d->Q, P, Q);
+  return FCD_OK;
+}
+
+extern "C" int fcd_conv2d_fwd(const fcd_conv_desc* d, const float* x, const float* wp, const float* bias,
+                              float* y, void* stream) {
+  int rc = check_desc(d, "fcd_conv2d_fwd");
+  if (rc) return rc;
+  FCD_CHECK_ARG(x && wp && y, "fcd_conv2d_fwd: null pointer");
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.wp = wp; a.bias = bias; a.y = y;
+  a.N = d->N; a.C = d->C; a.H = d->H; a.W = d->W;
+  a.K = d->K; a.Kpad = round_up(d->K, 128);
+  a.P = d->P; a.Q = d->Q; a.pad = d->pad;
+  const double flops = 2.0 * d->N * d->K * (double)d->P * d->Q * d->C * d->R * d->S;
+  const double bytes = 4.0 * ((double)d->N * d->C * d->H * d->W + (double)d->N * d->K * d->P * d->Q +
+                              (double)d->K * d->C * d->R * d->S);
+  FcdProfScope prof(FCD_K_CONV_FWD, (hipStream_t)stream, flops, bytes);
+  rc = conv_dispatch(a, d->R, d->S, d->stride, 1, (hipStream_t)stream);
+  FCD_CHECK_ARG(rc == 0, "fcd_conv2d_fwd: unsupported filter %dx%d stride %d", d->R, d->S, d->stride);
+  FCD_LAUNCH_CHECK("conv2d_fwd");
+  return FCD_OK;
+}
+
+extern "C" int fcd_conv2d_bwd_data(const fcd_conv_desc* d, const float* dy, const float* wp_bwd, float* dx,
+                                   void* stream) {
+  int rc = check_desc(d, "fcd_conv2d_bwd_data");
+  if (rc) return rc;
+  FCD_CHECK_ARG(dy && wp_bwd && dx, "fcd_conv2d_bwd_data: null pointer");
+  FCD_CHECK_ARG(d->R - 1 - d->pad >= 0, "fcd_conv2d_bwd_data: pad > R-1 unsupported");
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = dy; a.wp = wp_bwd; a.bias = nullptr; a.y = dx;
+  a.N = d->N; a.C = d->K; a.H = d->P; a.W = d->Q;     // "input" of the transposed conv = dy
+  a.K = d->C; a.Kpad = round_up(d->C, 128);
+  a.P = d->H; a.Q = d->W; a.pad = d->R - 1 - d->pad;
+  const double flops = 2.0 * d->N * d->K * (double)d->P * d->Q * d->C * d->R * d->S;
+  const double bytes = 4.0 * ((double)d->N * d->C * d->H * d->W + (double)d->N * d->K * d->P * d->Q +
+                              (double)d->K * d->C * d->R * d->S);
+  FcdProfScope prof(FCD_K_CONV_DGRAD, (hipStream_t)stream, flops, bytes);
+  rc = conv_dispatch(a, d->R, d->S, 1, d->stride, (hipStream_t)stream);
+  FCD_CHECK_ARG(rc == 0, "fcd_conv2d_bwd_data: unsupported filter %dx%d stride %d", d->R, d->S, d->stride);
+  FCD_LAUNCH_CHECK("conv2d_bwd_data");
+  return FCD_OK;
+}

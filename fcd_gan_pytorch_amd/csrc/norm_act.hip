@@ -1,0 +1,382 @@
+// BatchNorm2d (train / eval) fused with ReLU / LeakyReLU / PReLU, forward and
+// backward, with "sample groups" so that the Siamese / shared-net double
+// invocation of one BN layer (Module.py:114-131, :220-221) runs as ONE batched
+// launch while keeping per-call batch statistics and the ordered running-stat
+// updates of the reference.  HBM-bound: statistics are wavefront-reduced in
+// fp64, the normalise+activate pass is one read + one write with float4 access.
+#include "common.h"
+
+#define BN_MAX_SPLIT 64
+
+struct BnWs {
+  double* part;   // [G*C*BN_MAX_SPLIT*3]
+  double* fin;    // [G*C*3]
+  float* scale;   // [G*C]
+  float* shift;   // [G*C]
+  float* mean_e;  // [G*C] eval-mode mean / invstd (from running stats)
+  float* invstd_e;
+};
+
+static BnWs carve(void* ws, int C, int G) {
+  BnWs w;
+  char* p = (char*)ws;
+  w.part = (double*)p; p += sizeof(double) * (size_t)G * C * BN_MAX_SPLIT * 3;
+  w.fin = (double*)p;  p += sizeof(double) * (size_t)G * C * 3;
+  w.scale = (float*)p; p += sizeof(float) * (size_t)G * C;
+  w.shift = (float*)p; p += sizeof(float) * (size_t)G * C;
+  w.mean_e = (float*)p; p += sizeof(float) * (size_t)G * C;
+  w.invstd_e = (float*)p; p += sizeof(float) * (size_t)G * C;
+  return w;
+}
+
+extern "C" size_t fcd_bn_act_ws_bytes(int C, int groups) {
+  return (size_t)groups * C * (sizeof(double) * (BN_MAX_SPLIT * 3 + 3) + 4 * sizeof(float)) + 256;
+}
+
+static int pick_split(int C, int G, long long per_group_elems) {
+  int split = cdiv(2048, C * G);
+  const long long maxs = std::max<long long>(1, per_group_elems / 2048);
+  if (split > maxs) split = (int)maxs;
+  if (split > BN_MAX_SPLIT) split = BN_MAX_SPLIT;
+  if (split < 1) split = 1;
+  return split;
+}
+
+// ---- forward statistics ------------------------------------------------------
+// grid (C, G, split); part[((g*C+c)*split+sp)*3 + {0,1}] = {sum x, sum x^2}
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, double* __restrict__ part,
+                                                       int C, int HW, int Ng, int split) {
+  __shared__ double red[16];
+  const int c = blockIdx.x, g = blockIdx.y, sp = blockIdx.z;
+  double s1 = 0.0, s2 = 0.0;
+  if ((HW & 3) == 0) {
+    const int hw4 = HW >> 2;
+    const long long total = (long long)Ng * hw4;
+    const long long chunk = (total + split - 1) / split;
+    const long long beg = sp * chunk, end = min(beg + chunk, total);
+    for (long long e = beg + threadIdx.x; e < end; e += 256) {
+      const int n = (int)(e / hw4), i = (int)(e % hw4);
+      const float4 v = reinterpret_cast<const float4*>(x + ((size_t)(g * Ng + n) * C + c) * HW)[i];
+      s1 += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+      s2 += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    }
+  } else {
+    const long long total = (long long)Ng * HW;
+    const long long chunk = (total + split - 1) / split;
+    const long long beg = sp * chunk, end = min(beg + chunk, total);
+    for (long long e = beg + threadIdx.x; e < end; e += 256) {
+      const int n = (int)(e / HW), i = (int)(e % HW);
+      const float v = x[((size_t)(g * Ng + n) * C + c) * HW + i];
+      s1 += (double)v;
+      s2 += (double)v * v;
+    }
+  }
+  s1 = block_sum_d(s1, red);
+  s2 = block_sum_d(s2, red);
+  if (threadIdx.x == 0) {
+    double* o = part + ((size_t)(g * C + c) * split + sp) * 3;
+    o[0] = s1;
+    o[1] = s2;
+  }
+}
+
+// one thread per channel: finish stats for every group in order, update running stats
+__global__ void bn_finalize_kernel(const double* __restrict__ part, int C, int G, int split, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   float momentum, float eps, float* __restrict__ save_mean,
+                                   float* __restrict__ save_invstd, float* __restrict__ scale,
+                                   float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 1.f;
+  for (int g = 0; g < G; ++g) {
+    double s1 = 0.0, s2 = 0.0;
+    const double* p = part + (size_t)(g * C + c) * split * 3;
+    for (int s = 0; s < split; ++s) {
+      s1 += p[s * 3 + 0];
+      s2 += p[s * 3 + 1];
+    }
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float meanf = (float)mean;
+    save_mean[g * C + c] = meanf;
+    save_invstd[g * C + c] = invstd;
+    const float sc = gamma[c] * invstd;
+    scale[g * C + c] = sc;
+    shift[g * C + c] = beta[c] - meanf * sc;
+    const float unbiased = (float)(count > 1.0 ? var * count / (count - 1.0) : var);
+    rm = (1.f - momentum) * rm + momentum * meanf;
+    rv = (1.f - momentum) * rv + momentum * unbiased;
+  }
+  if (running_mean) running_mean[c] = rm;
+  if (running_var) running_var[c] = rv;
+}
+
+__global__ void bn_eval_prep_kernel(int C, int G, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                    float eps, float* __restrict__ scale, float* __restrict__ shift,
+                                    float* __restrict__ mean_e, float* __restrict__ invstd_e) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float invstd = 1.f / sqrtf(running_var[c] + eps);
+  const float sc = gamma[c] * invstd;
+  const float sh = beta[c] - running_mean[c] * sc;
+  for (int g = 0; g < G; ++g) {
+    scale[g * C + c] = sc;
+    shift[g * C + c] = sh;
+    mean_e[g * C + c] = running_mean[c];
+    invstd_e[g * C + c] = invstd;
+  }
+}
+
+// ---- forward apply: y = act(x*scale + shift) ------------------------------------
+__global__ __launch_bounds__(256) void bn_act_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                           int C, int HW, int Ng, int affine,
+                                                           const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, int act,
+                                                           const float* __restrict__ slope_ptr, float slope_imm) {
+  const int plane = blockIdx.x;
+  const int n = plane / C, c = plane % C;
+  const int sidx = (n / Ng) * C + c;
+  const float sc = affine ? scale[sidx] : 1.f;
+  const float sh = affine ? shift[sidx] : 0.f;
+  const float slope = slope_ptr ? slope_ptr[0] : slope_imm;
+  const float* xp = x + (size_t)plane * HW;
+  float* yp = y + (size_t)plane * HW;
+  if ((HW & 3) == 0) {
+    const int hw4 = HW >> 2;
+    for (int i = blockIdx.y * 256 + threadIdx.x; i < hw4; i += gridDim.y * 256) {
+      float4 v = reinterpret_cast<const float4*>(xp)[i];
+      v.x = act_apply(fmaf(v.x, sc, sh), act, slope);
+      v.y = act_apply(fmaf(v.y, sc, sh), act, slope);
+      v.z = act_apply(fmaf(v.z, sc, sh), act, slope);
+      v.w = act_apply(fmaf(v.w, sc, sh), act, slope);
+      reinterpret_cast<float4*>(yp)[i] = v;
+    }
+  } else {
+    for (int i = blockIdx.y * 256 + threadIdx.x; i < HW; i += gridDim.y * 256)
+      yp[i] = act_apply(fmaf(xp[i], sc, sh), act, slope);
+  }
+}
+
+static dim3 plane_grid(int planes, int HW) {
+  int chunks = cdiv(HW, 256 * 4 * 4);
+  if (chunks > 64) chunks = 64;
+  if (chunks < 1) chunks = 1;
+  return dim3((unsigned)planes, (unsigned)chunks);
+}
+
+extern "C" int fcd_bn_act_fwd(const float* x, float* y, int N, int C, int HW, int groups, int has_bn,
+                              const float* gamma, const float* beta, float* running_mean, float* running_var,
+                              float momentum, float eps, int training, float* save_mean, float* save_invstd,
+                              int act, const float* slope, float slope_imm, void* ws, size_t ws_bytes,
+                              void* stream) {
+  FCD_CHECK_ARG(x && y && N > 0 && C > 0 && HW > 0 && groups > 0 && N % groups == 0,
+                "fcd_bn_act_fwd: bad geometry N=%d C=%d HW=%d groups=%d", N, C, HW, groups);
+  hipStream_t st = (hipStream_t)stream;
+  const int Ng = N / groups;
+  BnWs w{};
+  FcdProfScope prof(FCD_K_NORM, st, 0.0, 4.0 * N * C * (double)HW * (has_bn && training ? 3.0 : 2.0));
+  if (has_bn) {
+    FCD_CHECK_ARG(gamma && beta, "fcd_bn_act_fwd: BN needs gamma/beta");
+    if (ws == nullptr || ws_bytes < fcd_bn_act_ws_bytes(C, groups)) {
+      fcd_set_error("fcd_bn_act_fwd: workspace too small");
+      return FCD_ERR_WORKSPACE;
+    }
+    w = carve(ws, C, groups);
+    if (training) {
+      FCD_CHECK_ARG(save_mean && save_invstd, "fcd_bn_act_fwd: training needs save buffers");
+      const int split = pick_split(C, groups, (long long)Ng * HW);
+      hipLaunchKernelGGL(bn_stats_kernel, dim3(C, groups, split), dim3(256), 0, st, x, w.part, C, HW, Ng, split);
+      hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, (const double*)w.part, C, groups,
+                         split, (double)Ng * HW, gamma, beta, running_mean, running_var, momentum, eps, save_mean,
+                         save_invstd, w.scale, w.shift);
+    } else {
+      FCD_CHECK_ARG(running_mean && running_var, "fcd_bn_act_fwd: eval needs running stats");
+      hipLaunchKernelGGL(bn_eval_prep_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, C, groups, gamma, beta,
+                         (const float*)running_mean, (const float*)running_var, eps, w.scale, w.shift, w.mean_e,
+                         w.invstd_e);
+    }
+  }
+  hipLaunchKernelGGL(bn_act_apply_kernel, plane_grid(N * C, HW), dim3(256), 0, st, x, y, C, HW, Ng, has_bn,
+                     (const float*)w.scale, (const float*)w.shift, act, slope, slope_imm);
+  FCD_LAUNCH_CHECK("bn_act_fwd");
+  return FCD_OK;
+}
+
+__global__ void bn_train_prep_kernel(int C, int G, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                     const float* __restrict__ mean, const float* __restrict__ invstd,
+                                     float* __restrict__ scale, float* __restrict__ shift) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C * G) return;
+  const int c = i % C;
+  const float sc = gamma[c] * invstd[i];
+  scale[i] = sc;
+  shift[i] = beta[c] - mean[i] * sc;
+}
+
+// ---- backward ----------------------------------------------------------------
+// reduce: per (g,c): s1 = sum dy', s2 = sum dy'*xhat, s3 = sum dz*y*[y<=0] (PReLU slope grad)
+// where y = x*scale+shift (pre-activation), dy' = dz*act'(y), xhat = (x-mean)*invstd
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
+    const float* __restrict__ dz, const float* __restrict__ x, double* __restrict__ part, int C, int HW, int Ng,
+    int split, int affine, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ mean, const float* __restrict__ invstd, int act,
+    const float* __restrict__ slope_ptr, float slope_imm) {
+  __shared__ double red[16];
+  const int c = blockIdx.x, g = blockIdx.y, sp = blockIdx.z;
+  const int sidx = g * C + c;
+  const float sc = affine ? scale[sidx] : 1.f, sh = affine ? shift[sidx] : 0.f;
+  const float mu = affine ? mean[sidx] : 0.f, is = affine ? invstd[sidx] : 1.f;
+  const float slope = slope_ptr ? slope_ptr[0] : slope_imm;
+  double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  const long long total = (long long)Ng * HW;
+  const long long chunk = (total + split - 1) / split;
+  const long long beg = sp * chunk, end = min(beg + chunk, total);
+  for (long long e = beg + threadIdx.x; e < end; e += 256) {
+    const int n = (int)(e / HW), i = (int)(e % HW);
+    const size_t off = ((size_t)(g * Ng + n) * C + c) * HW + i;
+    const float xv = x[off], dzv = dz[off];
+    const float yv = fmaf(xv, sc, sh);
+    const float dyv = dzv * act_grad(yv, act, slope);
+    s1 += (double)dyv;
+    s2 += (double)dyv * (double)((xv - mu) * is);
+    if (act == FCD_ACT_PRELU && yv <= 0.f) s3 += (double)dzv * (double)yv;
+  }
+  s1 = block_sum_d(s1, red);
+  s2 = block_sum_d(s2, red);
+  s3 = block_sum_d(s3, red);
+  if (threadIdx.x == 0) {
+    double* o = part + ((size_t)sidx * split + sp) * 3;
+    o[0] = s1;
+    o[1] = s2;
+    o[2] = s3;
+  }
+}
+
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, double* __restrict__ fin, int C, int G,
+                                       int split, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double tg = 0.0, tb = 0.0;
+  for (int g = 0; g < G; ++g) {
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    const double* p = part + (size_t)(g * C + c) * split * 3;
+    for (int s = 0; s < split; ++s) {
+      s1 += p[s * 3];
+      s2 += p[s * 3 + 1];
+      s3 += p[s * 3 + 2];
+    }
+    double* f = fin + (size_t)(g * C + c) * 3;
+    f[0] = s1;
+    f[1] = s2;
+    f[2] = s3;
+    tb += s1;
+    tg += s2;
+  }
+  if (dgamma) dgamma[c] = (float)tg;
+  if (dbeta) dbeta[c] = (float)tb;
+}
+
+__global__ void slope_grad_kernel(const double* __restrict__ fin, int GC, float* __restrict__ dslope) {
+  __shared__ double red[16];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < GC; i += blockDim.x) s += fin[(size_t)i * 3 + 2];
+  s = block_sum_d(s, red);
+  if (threadIdx.x == 0) dslope[0] = (float)s;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
+    const float* __restrict__ dz, const float* __restrict__ x, float* __restrict__ dx, int C, int HW, int Ng,
+    int affine, int training, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ mean, const float* __restrict__ invstd, const double* __restrict__ fin,
+    double inv_count, int act, const float* __restrict__ slope_ptr, float slope_imm) {
+  const int plane = blockIdx.x;
+  const int n = plane / C, c = plane % C;
+  const int sidx = (n / Ng) * C + c;
+  const float sc = affine ? scale[sidx] : 1.f, sh = affine ? shift[sidx] : 0.f;
+  const float slope = slope_ptr ? slope_ptr[0] : slope_imm;
+  float mu = 0.f, is = 1.f, k1 = 0.f, k2 = 0.f;
+  if (affine && training) {
+    mu = mean[sidx];
+    is = invstd[sidx];
+    k1 = (float)(fin[(size_t)sidx * 3 + 0] * inv_count);
+    k2 = (float)(fin[(size_t)sidx * 3 + 1] * inv_count);
+  }
+  const float* xp = x + (size_t)plane * HW;
+  const float* dp = dz + (size_t)plane * HW;
+  float* op = dx + (size_t)plane * HW;
+  for (int i = blockIdx.y * 256 + threadIdx.x; i < HW; i += gridDim.y * 256) {
+    const float xv = xp[i];
+    const float yv = fmaf(xv, sc, sh);
+    const float dyv = dp[i] * act_grad(yv, act, slope);
+    float r;
+    if (!affine) r = dyv;
+    else if (training) r = sc * (dyv - k1 - (xv - mu) * is * k2);
+    else r = dyv * sc;
+    op[i] = r;
+  }
+}
+
+extern "C" int fcd_bn_act_bwd(const float* dz, const float* x, float* dx, int N, int C, int HW, int groups,
+                              int has_bn, const float* gamma, const float* beta, const float* running_mean,
+                              const float* running_var, float eps, int training, const float* save_mean,
+                              const float* save_invstd, int act, const float* slope, float slope_imm,
+                              float* dgamma, float* dbeta, float* dslope, void* ws, size_t ws_bytes,
+                              void* stream) {
+  FCD_CHECK_ARG(dz && x && dx && N > 0 && C > 0 && HW > 0 && groups > 0 && N % groups == 0,
+                "fcd_bn_act_bwd: bad geometry");
+  if (ws == nullptr || ws_bytes < fcd_bn_act_ws_bytes(C, groups)) {
+    fcd_set_error("fcd_bn_act_bwd: workspace too small");
+    return FCD_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int Ng = N / groups;
+  BnWs w = carve(ws, C, groups);
+  FcdProfScope prof(FCD_K_NORM, st, 0.0, 4.0 * N * C * (double)HW * 5.0);
+  const float* mean = save_mean;
+  const float* invstd = save_invstd;
+  if (has_bn) {
+    FCD_CHECK_ARG(gamma && beta, "fcd_bn_act_bwd: BN needs gamma/beta");
+    if (training) {
+      FCD_CHECK_ARG(save_mean && save_invstd, "fcd_bn_act_bwd: training needs saved stats");
+      // rebuild scale/shift from the saved statistics
+      // (scale = gamma*invstd, shift = beta - mean*scale)
+    } else {
+      FCD_CHECK_ARG(running_mean && running_var, "fcd_bn_act_bwd: eval needs running stats");
+    }
+  }
+  // scale/shift
+  if (has_bn) {
+    if (training) {
+      // reuse eval-prep style kernel through a lambda-free path: small kernel below
+      hipLaunchKernelGGL(bn_train_prep_kernel, dim3(cdiv(C * groups, 128)), dim3(128), 0, st, C, groups, gamma, beta,
+                         save_mean, save_invstd, w.scale, w.shift);
+    } else {
+      hipLaunchKernelGGL(bn_eval_prep_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, C, groups, gamma, beta,
+                         running_mean, running_var, eps, w.scale, w.shift, w.mean_e, w.invstd_e);
+      mean = w.mean_e;
+      invstd = w.invstd_e;
+    }
+  }
+  const bool need_reduce = (has_bn && (training || dgamma || dbeta)) || (act == FCD_ACT_PRELU && dslope);
+  if (need_reduce) {
+    const int split = pick_split(C, groups, (long long)Ng * HW);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, groups, split), dim3(256), 0, st, dz, x, w.part, C, HW, Ng,
+                       split, has_bn, (const float*)w.scale, (const float*)w.shift, mean, invstd, act, slope,
+                       slope_imm);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, (const double*)w.part, w.fin, C,
+                       groups, split, has_bn ? dgamma : nullptr, has_bn ? dbeta : nullptr);
+    if (act == FCD_ACT_PRELU && dslope)
+      hipLaunchKernelGGL(slope_grad_kernel, dim3(1), dim3(256), 0, st, (const double*)w.fin, C * groups, dslope);
+  }
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, plane_grid(N * C, HW), dim3(256), 0, st, dz, x, dx, C, HW, Ng, has_bn,
+                     training, (const float*)w.scale, (const float*)w.shift, mean, invstd, (const double*)w.fin,
+                     1.0 / ((double)Ng * HW), act, slope, slope_imm);
+  FCD_LAUNCH_CHECK("bn_act_bwd");
+  return FCD_OK;
+}
+

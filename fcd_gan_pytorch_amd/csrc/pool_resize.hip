@@ -1,0 +1,269 @@
+// MaxPool2d(2), bilinear x2 (align_corners=True) and the padded 2x2 average pool
+// of MS-SSIM, forward + backward.  All HBM-bound gather kernels: one thread per
+// OUTPUT element of the pass (so no atomics and fully written outputs),
+// consecutive lanes on consecutive addresses of the wider tensor.
+#include "common.h"
+
+// ---- MaxPool2d(kernel 2, stride 2, floor) -------------------------------------
+__global__ void maxpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int NC, int H, int W,
+                                    int P, int Q) {
+  const long long total = (long long)NC * P * Q;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % Q);
+    const long long t = i / Q;
+    const int p = (int)(t % P);
+    const long long pl = t / P;
+    const float* s = x + (pl * H + 2 * p) * W + 2 * q;
+    const float2 a = *reinterpret_cast<const float2*>(s);   // W may be odd: 2q+1 <= W-1 always holds
+    const float2 b = *reinterpret_cast<const float2*>(s + W);
+    float m = a.x;
+    // NaN-propagating max in window order (PyTorch: val > max || isnan(val))
+    if (a.y > m || a.y != a.y) m = a.y;
+    if (b.x > m || b.x != b.x) m = b.x;
+    if (b.y > m || b.y != b.y) m = b.y;
+    y[i] = m;
+  }
+}
+
+__global__ void maxpool2_fwd_scalar_kernel(const float* __restrict__ x, float* __restrict__ y, int NC, int H, int W,
+                                           int P, int Q) {
+  const long long total = (long long)NC * P * Q;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % Q);
+    const long long t = i / Q;
+    const int p = (int)(t % P);
+    const long long pl = t / P;
+    const float* s = x + (pl * H + 2 * p) * W + 2 * q;
+    float m = s[0];
+    const float v1 = s[1], v2 = s[W], v3 = s[W + 1];
+    if (v1 > m || v1 != v1) m = v1;
+    if (v2 > m || v2 != v2) m = v2;
+    if (v3 > m || v3 != v3) m = v3;
+    y[i] = m;
+  }
+}
+
+// one thread per 2x2 input window (plus edge cells): recompute the argmax, route dy
+__global__ void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                    float* __restrict__ dx, int NC, int H, int W, int P, int Q) {
+  const int PH = (H + 1) / 2, PW = (W + 1) / 2;  // cover trailing odd row/col with zero windows
+  const long long total = (long long)NC * PH * PW;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % PW);
+    const long long t = i / PW;
+    const int p = (int)(t % PH);
+    const long long pl = t / PH;
+    const long long base = (pl * H + 2 * p) * W + 2 * q;
+    if (p < P && q < Q) {
+      const float v00 = x[base], v01 = x[base + 1], v10 = x[base + W], v11 = x[base + W + 1];
+      int arg = 0;
+      float m = v00;
+      if (v01 > m || v01 != v01) { m = v01; arg = 1; }
+      if (v10 > m || v10 != v10) { m = v10; arg = 2; }
+      if (v11 > m || v11 != v11) { m = v11; arg = 3; }
+      const float g = dy[(pl * P + p) * Q + q];
+      dx[base] = arg == 0 ? g : 0.f;
+      dx[base + 1] = arg == 1 ? g : 0.f;
+      dx[base + W] = arg == 2 ? g : 0.f;
+      dx[base + W + 1] = arg == 3 ? g : 0.f;
+    } else {
+      // trailing odd row / column never pooled: zero gradient
+      const int h = 2 * p, w = 2 * q;
+      for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b)
+          if (h + a < H && w + b < W) dx[(pl * H + h + a) * W + w + b] = 0.f;
+    }
+  }
+}
+
+static inline int ew_grid(long long total) { return (int)std::min<long long>(cdiv64(total, 256), 8192); }
+
+extern "C" int fcd_maxpool2_fwd(const float* x, float* y, int NC, int H, int W, void* stream) {
+  FCD_CHECK_ARG(x && y && NC > 0 && H >= 2 && W >= 2, "fcd_maxpool2_fwd: bad arguments");
+  const int P = H / 2, Q = W / 2;
+  const long long total = (long long)NC * P * Q;
+  FcdProfScope prof(FCD_K_POOL, (hipStream_t)stream, 0.0, 4.0 * NC * ((double)H * W + (double)P * Q));
+  if ((W & 1) == 0) {
+    hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, y, NC, H, W,
+                       P, Q);
+  } else {
+    // odd width: rows are not 8-byte aligned -> scalar variant through the bwd-style reader
+    hipLaunchKernelGGL(maxpool2_fwd_scalar_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, y, NC,
+                       H, W, P, Q);
+  }
+  FCD_LAUNCH_CHECK("maxpool2_fwd");
+  return FCD_OK;
+}
+
+extern "C" int fcd_maxpool2_bwd(const float* x, const float* dy, float* dx, int NC, int H, int W, void* stream) {
+  FCD_CHECK_ARG(x && dy && dx && NC > 0 && H >= 2 && W >= 2, "fcd_maxpool2_bwd: bad arguments");
+  const int P = H / 2, Q = W / 2;
+  const long long total = (long long)NC * ((H + 1) / 2) * ((W + 1) / 2);
+  FcdProfScope prof(FCD_K_POOL, (hipStream_t)stream, 0.0, 4.0 * NC * (2.0 * H * W + (double)P * Q));
+  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, NC, H,
+                     W, P, Q);
+  FCD_LAUNCH_CHECK("maxpool2_bwd");
+  return FCD_OK;
+}
+
+// ---- bilinear x2, align_corners=True ------------------------------------------
+// src = dst * (in-1)/(out-1);  i0 = (int)src, i1 = i0 + (i0 < in-1), l1 = src - i0
+__device__ __forceinline__ void ac_src(int dst, float scale, int in, int* i0, int* i1, float* l1) {
+  const float src = scale * (float)dst;
+  int a = (int)src;
+  if (a > in - 1) a = in - 1;
+  *i0 = a;
+  *i1 = a + (a < in - 1 ? 1 : 0);
+  *l1 = src - (float)a;
+}
+
+__global__ void upsample2x_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int NC, int H, int W,
+                                      float sh, float sw) {
+  const int OH = 2 * H, OW = 2 * W;
+  const long long total = (long long)NC * OH * OW;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int ow = (int)(i % OW);
+    const long long t = i / OW;
+    const int oh = (int)(t % OH);
+    const long long pl = t / OH;
+    int h0, h1, w0, w1;
+    float lh, lw;
+    ac_src(oh, sh, H, &h0, &h1, &lh);
+    ac_src(ow, sw, W, &w0, &w1, &lw);
+    const float* s = x + pl * H * W;
+    const float h0l = 1.f - lh, w0l = 1.f - lw;
+    y[i] = h0l * (w0l * s[h0 * W + w0] + lw * s[h0 * W + w1]) + lh * (w0l * s[h1 * W + w0] + lw * s[h1 * W + w1]);
+  }
+}
+
+// gather form of the adjoint: each input pixel sums the (<= ~3x3.. 5x5) outputs that read it
+__global__ void upsample2x_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int NC, int H, int W,
+                                      float sh, float sw) {
+  const int OH = 2 * H, OW = 2 * W;
+  const long long total = (long long)NC * H * W;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int w = (int)(i % W);
+    const long long t = i / W;
+    const int h = (int)(t % H);
+    const long long pl = t / H;
+    // candidate output rows: those whose src lies in (h-1, h+1)
+    int oh_lo = (sh > 0.f) ? (int)floorf((float)(h - 1) / sh) : 0;
+    int oh_hi = (sh > 0.f) ? (int)ceilf((float)(h + 1) / sh) : OH - 1;
+    int ow_lo = (sw > 0.f) ? (int)floorf((float)(w - 1) / sw) : 0;
+    int ow_hi = (sw > 0.f) ? (int)ceilf((float)(w + 1) / sw) : OW - 1;
+    oh_lo = max(oh_lo - 1, 0); oh_hi = min(oh_hi + 1, OH - 1);
+    ow_lo = max(ow_lo - 1, 0); ow_hi = min(ow_hi + 1, OW - 1);
+    const float* g = dy + pl * OH * OW;
+    float acc = 0.f;
+    for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+      int h0, h1; float lh;
+      ac_src(oh, sh, H, &h0, &h1, &lh);
+      float wh = 0.f;
+      if (h0 == h) wh += 1.f - lh;
+      if (h1 == h) wh += lh;
+      if (wh == 0.f) continue;
+      float rowacc = 0.f;
+      for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+        int w0, w1; float lw;
+        ac_src(ow, sw, W, &w0, &w1, &lw);
+        float ww = 0.f;
+        if (w0 == w) ww += 1.f - lw;
+        if (w1 == w) ww += lw;
+        if (ww != 0.f) rowacc += ww * g[oh * OW + ow];
+      }
+      acc += wh * rowacc;
+    }
+    dx[i] = acc;
+  }
+}
+
+static inline float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
+
+extern "C" int fcd_upsample2x_fwd(const float* x, float* y, int NC, int H, int W, void* stream) {
+  FCD_CHECK_ARG(x && y && NC > 0 && H > 0 && W > 0, "fcd_upsample2x_fwd: bad arguments");
+  const long long total = (long long)NC * 4 * H * W;
+  FcdProfScope prof(FCD_K_POOL, (hipStream_t)stream, 0.0, 4.0 * NC * 5.0 * H * W);
+  hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, y, NC, H, W,
+                     ac_scale(H, 2 * H), ac_scale(W, 2 * W));
+  FCD_LAUNCH_CHECK("upsample2x_fwd");
+  return FCD_OK;
+}
+
+extern "C" int fcd_upsample2x_bwd(const float* dy, float* dx, int NC, int H, int W, void* stream) {
+  FCD_CHECK_ARG(dy && dx && NC > 0 && H > 0 && W > 0, "fcd_upsample2x_bwd: bad arguments");
+  const long long total = (long long)NC * H * W;
+  FcdProfScope prof(FCD_K_POOL, (hipStream_t)stream, 0.0, 4.0 * NC * 5.0 * H * W);
+  hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, dx, NC, H, W,
+                     ac_scale(H, 2 * H), ac_scale(W, 2 * W));
+  FCD_LAUNCH_CHECK("upsample2x_bwd");
+  return FCD_OK;
+}
+
+// ---- F.avg_pool2d(kernel 2, stride 2, padding = size % 2, count_include_pad) ----
+// output size: floor((S + 2p - 2)/2) + 1 ; window of output o covers inputs 2o-p, 2o-p+1
+__global__ void avgpool2_pad_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int NC, int H, int W,
+                                        int P, int Q, int ph, int pw) {
+  const long long total = (long long)NC * P * Q;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % Q);
+    const long long t = i / Q;
+    const int p = (int)(t % P);
+    const long long pl = t / P;
+    const float* s = x + pl * H * W;
+    float acc = 0.f;
+    for (int a = 0; a < 2; ++a) {
+      const int h = 2 * p - ph + a;
+      if (h < 0 || h >= H) continue;
+      for (int b = 0; b < 2; ++b) {
+        const int w = 2 * q - pw + b;
+        if (w < 0 || w >= W) continue;
+        acc += s[h * W + w];
+      }
+    }
+    y[i] = acc / 4.f;
+  }
+}
+
+__global__ void avgpool2_pad_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int NC, int H, int W,
+                                        int P, int Q, int ph, int pw) {
+  const long long total = (long long)NC * H * W;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int w = (int)(i % W);
+    const long long t = i / W;
+    const int h = (int)(t % H);
+    const long long pl = t / H;
+    const int p = (h + ph) >> 1, q = (w + pw) >> 1;
+    dx[i] = (p < P && q < Q) ? dy[(pl * P + p) * Q + q] * 0.25f : 0.f;
+  }
+}
+
+extern "C" int fcd_avgpool2_pad_fwd(const float* x, float* y, int NC, int H, int W, void* stream) {
+  FCD_CHECK_ARG(x && y && NC > 0 && H > 0 && W > 0, "fcd_avgpool2_pad_fwd: bad arguments");
+  const int ph = H & 1, pw = W & 1;
+  const int P = (H + 2 * ph - 2) / 2 + 1, Q = (W + 2 * pw - 2) / 2 + 1;
+  const long long total = (long long)NC * P * Q;
+  FcdProfScope prof(FCD_K_POOL, (hipStream_t)stream, 0.0, 4.0 * NC * 1.25 * H * W);
+  hipLaunchKernelGGL(avgpool2_pad_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, y, NC, H, W,
+                     P, Q, ph, pw);
+  FCD_LAUNCH_CHECK("avgpool2_pad_fwd");
+  return FCD_OK;
+}
+
+extern "C" int fcd_avgpool2_pad_bwd(const float* dy, float* dx, int NC, int H, int W, void* stream) {
+  FCD_CHECK_ARG(dy && dx && NC > 0 && H > 0 && W > 0, "fcd_avgpool2_pad_bwd: bad arguments");
+  const int ph = H & 1, pw = W & 1;
+  const int P = (H + 2 * ph - 2) / 2 + 1, Q = (W + 2 * pw - 2) / 2 + 1;
+  const long long total = (long long)NC * H * W;
+  FcdProfScope prof(FCD_K_POOL, (hipStream_t)stream, 0.0, 4.0 * NC * 1.25 * H * W);
+  hipLaunchKernelGGL(avgpool2_pad_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, dx, NC, H,
+                     W, P, Q, ph, pw);
+  FCD_LAUNCH_CHECK("avgpool2_pad_bwd");
+  return FCD_OK;
+}

@@ -1,0 +1,172 @@
+/* libfcdgan_hip.so -- C ABI of the MI355X (gfx950) FCD-GAN hot path.
+ *
+ * The reference (Cwuwhu/FCD-GAN-pytorch) has NO native/FFI layer: its only
+ * boundary is the Python nn.Module surface of Module.py / Loss.py / ssim.py,
+ * and every arithmetic op below is reached through torch.nn (ATen).  Each entry
+ * point here therefore replaces one ATen operator *as invoked from* the cited
+ * reference line; the Python host mirror (fcd_gan_pytorch_amd/) binds them with
+ * ctypes.
+ *
+ * Conventions
+ *  - plain C symbols, POD arguments, no torch types; all tensors fp32 NCHW
+ *    contiguous device pointers owned by the CALLER (incl. workspaces);
+ *  - return 0 on success, negative fcd_status otherwise (never throws);
+ *    fcd_last_error_string() describes the last failure of the calling thread;
+ *  - every launch is asynchronous on the hipStream_t passed last (as void*),
+ *    no internal synchronisation, no persistent device allocation.
+ */
+#ifndef FCDGAN_HIP_H
+#define FCDGAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum fcd_status {
+  FCD_OK = 0,
+  FCD_ERR_INVALID = -1,     /* bad argument / unsupported shape */
+  FCD_ERR_LAUNCH = -2,      /* HIP launch error */
+  FCD_ERR_WORKSPACE = -3    /* workspace too small */
+} fcd_status;
+
+enum { FCD_ACT_NONE = 0, FCD_ACT_RELU = 1, FCD_ACT_LEAKY = 2, FCD_ACT_PRELU = 3 };
+
+int fcd_version(void);
+const char* fcd_last_error_string(void);
+
+/* ---- convolution ---------------------------------------------------------
+ * Replaces nn.Conv2d as used at Module.py:25,29 (3x3 p1), :146,158 (9x9 p4),
+ * :85 (1x1), :196-205 (3x3 s2 p1), :212,214 (1x1 on 1x1 maps), the VGG16
+ * 3x3 stack of Loss.py:25, and nn.ConvTranspose2d(k2,s2) at Module.py:63.
+ *
+ * desc: input (N,C,H,W), filter (K,C,R,S), stride (1|2), pad, output (N,K,P,Q)
+ *   with P = (H+2*pad-R)/stride+1.  Supported filters: 3x3 s1/s2, 9x9 s1,
+ *   1x1 s1, 2x2 s2 (the conv whose data-gradient is ConvTranspose2d k2 s2).
+ */
+typedef struct fcd_conv_desc {
+  int32_t N, C, H, W;
+  int32_t K, R, S;
+  int32_t stride, pad;
+  int32_t P, Q;
+} fcd_conv_desc;
+
+/* Packed ("GEMM-A") weight layouts consumed by the MFMA kernels.
+ * mode 0 (forward):   wp[(c*R*S + r*S + s) * Kpad + k] = w[k][c][r][s]
+ * mode 1 (data-grad): wp[(k*R*S + r*S + s) * Cpad2 + c] = w[k][c][R-1-r][S-1-s]
+ * zero-filled up to the padded extents reported by fcd_conv_packed_elems(). */
+int64_t fcd_conv_packed_elems(int K, int C, int R, int S, int mode);
+int fcd_conv_pack_weights(const float* w, float* wp, int K, int C, int R, int S, int mode, void* stream);
+
+/* y = conv(x, w) + bias (bias may be NULL).  wp: mode-0 packed weights. */
+int fcd_conv2d_fwd(const fcd_conv_desc* d, const float* x, const float* wp, const float* bias,
+                   float* y, void* stream);
+/* dx = conv_transpose(dy, w): desc describes the FORWARD conv; wp_bwd: mode-1
+ * packed weights.  dx has shape (N,C,H,W). */
+int fcd_conv2d_bwd_data(const fcd_conv_desc* d, const float* dy, const float* wp_bwd, float* dx,
+                        void* stream);
+/* dw[k][c][r][s] = sum_{n,p,q} dy[n,k,p,q] * x[n,c,p*stride+r-pad,q*stride+s-pad]
+ * (plain, unpacked layout).  Needs ws of fcd_conv2d_bwd_weight_ws_bytes(). */
+size_t fcd_conv2d_bwd_weight_ws_bytes(const fcd_conv_desc* d);
+int fcd_conv2d_bwd_weight(const fcd_conv_desc* d, const float* x, const float* dy, float* dw,
+                          void* ws, size_t ws_bytes, void* stream);
+/* out[c] = sum over (n, hw) of x[n,c,hw]  -- bias gradients. */
+int fcd_channel_sum(const float* x, float* out, int N, int C, int HW, void* stream);
+
+/* ---- BatchNorm2d (+ fused activation) -------------------------------------
+ * Replaces nn.BatchNorm2d + nn.ReLU / nn.LeakyReLU(0.2) / nn.PReLU chains at
+ * Module.py:26-31,156,178-181,197-209 and the bare activations at :147,197.
+ *
+ * The batch is split into `groups` equal sample groups that are normalised
+ * independently and update the running statistics one after the other, in
+ * order -- this is how the Siamese encoder (Module.py:114-131) and the
+ * Discriminator's shared net (Module.py:220-221) call one BN layer several
+ * times per step; groups=1 is the ordinary layer.
+ *  has_bn=0: pure activation (gamma..save_invstd ignored).
+ *  training=1: batch statistics (biased var), running stats updated with
+ *    `momentum` using the unbiased variance; save_mean/save_invstd [groups*C].
+ *  training=0: running statistics.
+ *  act: FCD_ACT_*; slope: device pointer to the scalar slope (PReLU weight) or
+ *    NULL with slope_imm used instead (LeakyReLU).
+ */
+int fcd_bn_act_fwd(const float* x, float* y, int N, int C, int HW, int groups, int has_bn,
+                   const float* gamma, const float* beta, float* running_mean, float* running_var,
+                   float momentum, float eps, int training, float* save_mean, float* save_invstd,
+                   int act, const float* slope, float slope_imm, void* ws, size_t ws_bytes,
+                   void* stream);
+size_t fcd_bn_act_ws_bytes(int C, int groups);
+/* Backward of the above.  dz: grad wrt the activated output.  Writes dx and
+ * OVERWRITES dgamma/dbeta [C] (sum over groups) and dslope [1] when non-NULL. */
+int fcd_bn_act_bwd(const float* dz, const float* x, float* dx, int N, int C, int HW, int groups,
+                   int has_bn, const float* gamma, const float* beta, const float* running_mean,
+                   const float* running_var, float eps, int training, const float* save_mean,
+                   const float* save_invstd, int act, const float* slope, float slope_imm,
+                   float* dgamma, float* dbeta, float* dslope, void* ws, size_t ws_bytes,
+                   void* stream);
+
+/* ---- pooling / resampling --------------------------------------------------
+ * nn.MaxPool2d(2) Module.py:43 and VGG pools (Loss.py:25); nn.Upsample(x2,
+ * bilinear, align_corners=True) Module.py:60; F.avg_pool2d(k2, padding=s%2)
+ * ssim.py:213-215; nn.AdaptiveAvgPool2d(1) Module.py:211. */
+int fcd_maxpool2_fwd(const float* x, float* y, int NC, int H, int W, void* stream);
+int fcd_maxpool2_bwd(const float* x, const float* dy, float* dx, int NC, int H, int W, void* stream);
+int fcd_upsample2x_fwd(const float* x, float* y, int NC, int H, int W, void* stream);
+int fcd_upsample2x_bwd(const float* dy, float* dx, int NC, int H, int W, void* stream);
+int fcd_avgpool2_pad_fwd(const float* x, float* y, int NC, int H, int W, void* stream);
+int fcd_avgpool2_pad_bwd(const float* dy, float* dx, int NC, int H, int W, void* stream);
+
+/* ---- loss terms ------------------------------------------------------------
+ * Masked per-sample sums -- the reconstruction terms of Loss.py:76-84 (L1) and
+ * :110-119 (MSE), and region_loss Loss.py:127-141:
+ *   d = (a - b) * w,  w = complement ? (1 - m) : m   (m is (N,1,HW), broadcast
+ *   over the C channels of a, b; b may be NULL = 0)
+ *   num[n]  = sum_{c,p} |d|  (kind 0)   or   d^2  (kind 1)
+ *   wsum[n] = sum_p w
+ * out2[2*N] = {num[0..N), wsum[0..N)}.  The per-sample ratio / skip-if-zero
+ * logic on these N numbers is host side. */
+size_t fcd_masked_recon_ws_bytes(int N);
+int fcd_masked_recon_fwd(const float* a, const float* b, const float* m, float* out2, int N, int C,
+                         int HW, int kind, int complement, void* ws, size_t ws_bytes, void* stream);
+/* Backward of  L = sum_n coef[n]*num[n] + cw[n]*wsum[n]  (coef, cw: device
+ * arrays of N).  Writes (each optional, may be NULL) da, db (N,C,HW), dm (N,1,HW). */
+int fcd_masked_recon_bwd(const float* a, const float* b, const float* m, const float* coef,
+                         const float* cw, float* da, float* db, float* dm, int N, int C, int HW,
+                         int kind, int complement, void* stream);
+
+/* SSIM level (ssim.py:55-92): 11-tap (win) separable VALID Gaussian window
+ * statistics of X,Y -> per-(n,c) means of ssim_map and cs_map.
+ * out[2*NC] = {ssim_mean[NC], cs_mean[NC]}. Requires H,W >= win_size. */
+int fcd_ssim_level_fwd(const float* X, const float* Y, const float* win, int win_size, float* out,
+                       int NC, int H, int W, float C1, float C2, void* ws, size_t ws_bytes,
+                       void* stream);
+size_t fcd_ssim_ws_bytes(int NC, int H, int W);
+/* Backward: g_ssim[NC], g_cs[NC] are the upstream grads of the two means;
+ * writes dX, dY (N*C*H*W each).  ws: fcd_ssim_ws_bytes() (adjoint maps). */
+int fcd_ssim_level_bwd(const float* X, const float* Y, const float* win, int win_size,
+                       const float* g_ssim, const float* g_cs, float* dX, float* dY, int NC, int H,
+                       int W, float C1, float C2, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- optimizers (torch.optim.Adam / RMSprop defaults; Demo_RSSS.py:151-158)
+ * Flat fp32 buffers of n elements.  grad_scale multiplies the gradient first
+ * (1/world_size after an all-reduce-sum).  step: 1-based step count. */
+int fcd_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int step, float grad_scale,
+                  void* stream);
+int fcd_rmsprop_step(float* p, const float* g, float* sq, int64_t n, float lr, float alpha,
+                     float eps, float weight_decay, float grad_scale, void* stream);
+
+/* ---- profiling -------------------------------------------------------------
+ * When enabled every launch is bracketed by HIP events on its stream; read()
+ * synchronises and returns per-family totals: out[f*4+0]=ms, +1=launches,
+ * +2=algorithmic FLOPs, +3=algorithmic bytes (f < fcd_prof_families()). */
+void fcd_prof_enable(int on);
+int fcd_prof_families(void);
+int fcd_prof_read(double* out, int reset);
+const char* fcd_prof_family_name(int f);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
