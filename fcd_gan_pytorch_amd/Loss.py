@@ -1,0 +1,190 @@
+"""Drop-in for the reference's ``Loss.py``: ``PerceptionLoss``, ``CNetLoss``,
+``CGeneratorLoss``, ``region_loss`` with the same constructor / forward
+signatures and return-tuple orders, on the HIP kernels.
+
+ * the masked reconstruction terms (reference Loss.py:76-84 L1, :110-119 MSE) and
+   region_loss (:127-141) are ONE fused per-sample reduction kernel each
+   (csrc/losses.hip) -- no Python loop over samples, no ``num_wnc[i] == 0`` host
+   sync; the skip-if-zero / divide logic runs on the N per-sample numbers on
+   device;
+ * MS-SSIM is the fused level kernel of ``ssim.py``;
+ * the VGG16 perception term runs every band (and both images) as ONE batch
+   through the MFMA conv kernels instead of a Python loop over bands.
+"""
+import os
+import warnings
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _ops as ops
+from .ssim import MS_SSIM
+
+_VGG_CFG = (64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512, 'M')
+_TAPS = (29, 22, 15, 8, 3)     # reference Loss.py:30
+
+
+def _vgg16_features():
+    """torchvision's vgg16().features layout (31 entries: conv/ReLU/MaxPool) as
+    parameter holders, so ``state_dict`` keys match the reference's ``self.net``."""
+    layers, cin = [], 3
+    for v in _VGG_CFG:
+        if v == 'M':
+            layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+        else:
+            layers += [nn.Conv2d(cin, v, kernel_size=3, padding=1), nn.ReLU(inplace=True)]
+            cin = v
+    return nn.Sequential(*layers)
+
+
+def _load_vgg_weights(net):
+    """The reference downloads torchvision's ImageNet checkpoint (Loss.py:25).  There
+    is no network here: point FCDGAN_VGG16_WEIGHTS at a torch-saved state_dict of
+    ``vgg16().features`` (keys '0.weight'... or 'features.0.weight'...).  Without it
+    the stack gets a fixed-seed He initialisation and a warning."""
+    path = os.environ.get('FCDGAN_VGG16_WEIGHTS', '')
+    if path and os.path.exists(path):
+        sd = torch.load(path, map_location='cpu')
+        sd = {k.replace('features.', ''): v for k, v in sd.items() if 'classifier' not in k}
+        net.load_state_dict(sd)
+        return True
+    warnings.warn('PerceptionLoss: pretrained VGG16 weights unavailable offline (set FCDGAN_VGG16_WEIGHTS); '
+                  'using a fixed-seed He initialisation.')
+    g = torch.Generator().manual_seed(16)
+    with torch.no_grad():
+        for m in net:
+            if isinstance(m, nn.Conv2d):
+                fan_in = m.weight.shape[1] * 9
+                m.weight.copy_(torch.randn(m.weight.shape, generator=g) * (2.0 / fan_in) ** 0.5)
+                m.bias.zero_()
+    return False
+
+
+class PerceptionLoss(nn.Module):
+    """VGG16 feature MSE -- reference Loss.py:17-61."""
+
+    def __init__(self, feature_layer=1, perception_perBand=False):
+        super(PerceptionLoss, self).__init__()
+        vgg = _vgg16_features().eval()
+        self.pretrained = _load_vgg_weights(vgg)
+        for param in vgg.parameters():
+            param.requires_grad = False
+        self.net = vgg
+        feature_layer = feature_layer if feature_layer > 0 else 1
+        feature_layer = feature_layer if feature_layer < 6 else 5
+        self.feature_layer_list = list(_TAPS[:feature_layer])
+        self.perception_perBand = perception_perBand
+        self.loss = nn.MSELoss()
+
+    def _features(self, z):
+        """All 31 layers (the reference runs the stack to the end, Loss.py:45-49);
+        returns {tap index: activation}."""
+        taps = {}
+        for i, layer in enumerate(self.net):
+            if isinstance(layer, nn.Conv2d):
+                z = ops.conv2d(z, layer.weight, layer.bias, 1, 1)
+            elif isinstance(layer, nn.ReLU):
+                z = ops.bn_act(z, None, ops.ACT_RELU)
+            else:
+                z = ops.maxpool2(z)
+            if i in self.feature_layer_list:
+                taps[i] = z
+        return taps
+
+    def forward(self, target_image, generate_image, cmask):
+        n = target_image.shape[0]
+        nl = len(self.feature_layer_list)
+        if not self.perception_perBand:
+            assert target_image.shape[1] >= 3
+            keep = 1 - cmask
+            z = torch.cat([target_image[:, 0:3] * keep, generate_image[:, 0:3] * keep], dim=0)
+            nb = n
+        else:
+            # every band becomes its own 3-channel image (band replicated), all bands of
+            # both images in one batch: rows [0, n*C) target, [n*C, 2*n*C) generated
+            C, H, W = target_image.shape[1:]
+            keep = 1 - cmask
+            tb = (target_image * keep).reshape(n * C, 1, H, W)
+            gb = (generate_image * keep).reshape(n * C, 1, H, W)
+            z = torch.cat([tb, gb], dim=0).expand(-1, 3, -1, -1).contiguous()
+            nb = n * C
+        feats = self._features(z)
+        total = 0
+        for i in sorted(self.feature_layer_list):
+            f = feats[i]
+            # sum over bands of per-band MSE / C  ==  MSE over the band-batched tensor
+            total = total + F.mse_loss(f[:nb], f[nb:]) / nl
+        return total
+
+
+def _per_sample_ratio(num, wsum, scale, skip_zero):
+    """mean_i( num_i * scale / wsum_i ), optionally skipping wsum_i == 0 samples
+    (reference Loss.py:115-119 `continue`) -- on device, no host sync."""
+    if skip_zero:
+        ok = wsum != 0
+        terms = torch.where(ok, num * scale / torch.where(ok, wsum, torch.ones_like(wsum)), torch.zeros_like(num))
+    else:
+        terms = num * scale / wsum
+    return terms.sum() / num.shape[0]
+
+
+class CNetLoss(nn.Module):
+    """USSS criterion -- reference Loss.py:64-95.  Returns
+    (generator_loss, l1_loss, perception_loss, ssim_loss)."""
+
+    def __init__(self, channel=4, perception_layer=1, perception_perBand=True):
+        super(CNetLoss, self).__init__()
+        self.mse = nn.MSELoss()
+        self.loss_generator = nn.L1Loss()
+        self.loss_perception = PerceptionLoss(feature_layer=perception_layer, perception_perBand=perception_perBand)
+        self.ssim = MS_SSIM(data_range=1.0, channel=channel)
+
+    def forward(self, target_image, generate_image, cmap, generator_mask_switch=False):
+        C = target_image.shape[1]
+        cmask = (torch.sign(cmap - 0.5) + 1) / 2
+        # L1(mask_t_i, mask_g_i) * HW / num_wnc_i  ==  num_i / (C * wsum_i)   (no zero guard, as the reference)
+        num, wsum = ops.masked_sums(target_image, generate_image, cmap, 0, True)
+        generator_loss = _per_sample_ratio(num, wsum, 1.0 / C, skip_zero=False)
+        l1_loss = torch.mean(abs(cmap))
+        perception_loss = self.loss_perception(target_image, generate_image,
+                                               cmask if generator_mask_switch else cmap)
+        keep = 1 - cmap
+        ssim_loss = 1 - self.ssim(target_image * keep, generate_image * keep)
+        return generator_loss, l1_loss, perception_loss, ssim_loss
+
+
+class CGeneratorLoss(nn.Module):
+    """WSSS / RSSS criterion -- reference Loss.py:100-124.  Returns
+    (generator_loss, ssim_loss, perception_loss)."""
+
+    def __init__(self, channel=3, perception_layer=1, perception_perBand=False):
+        super(CGeneratorLoss, self).__init__()
+        self.loss_generator = nn.MSELoss()
+        self.ssim = MS_SSIM(data_range=1.0, channel=channel)
+        self.loss_perception = PerceptionLoss(feature_layer=perception_layer, perception_perBand=perception_perBand)
+
+    def forward(self, target_image, generate_image, cmap):
+        C = target_image.shape[1]
+        num, wsum = ops.masked_sums(target_image, generate_image, cmap, 1, True)
+        generator_loss = _per_sample_ratio(num, wsum, 1.0 / C, skip_zero=True)
+        keep = 1 - cmap
+        ssim_loss = 1 - self.ssim(target_image * keep, generate_image * keep)
+        perception_loss = self.loss_perception(target_image, generate_image, cmap)
+        return generator_loss, ssim_loss, perception_loss
+
+
+def region_loss(cmap, region, criterion):
+    """mean_i[ criterion(cmap_i * region_i, 0) * HW / sum(region_i) ], empty regions
+    skipped -- reference Loss.py:127-141.  ``criterion``: nn.L1Loss() or nn.MSELoss()
+    instance (as the demos pass) or the strings 'l1' / 'mse'."""
+    if isinstance(criterion, str):
+        kind = {'l1': 0, 'mse': 1}[criterion]
+    elif isinstance(criterion, nn.L1Loss):
+        kind = 0
+    elif isinstance(criterion, nn.MSELoss):
+        kind = 1
+    else:
+        raise TypeError('region_loss: criterion must be nn.L1Loss / nn.MSELoss')
+    num, wsum = ops.masked_sums(cmap, None, region, kind, False)
+    return _per_sample_ratio(num, wsum, 1.0 / cmap.shape[1], skip_zero=True)

@@ -1,0 +1,25 @@
+"""fcd_gan_pytorch_amd -- MI355X (gfx950) native hot path of FCD-GAN.
+
+Drop-in surface (same names as the reference's top-level modules):
+    from fcd_gan_pytorch_amd.Module import Generator, Segmentor, Discriminator_SRGAN_simple, ...
+    from fcd_gan_pytorch_amd.Loss   import CNetLoss, CGeneratorLoss, PerceptionLoss, region_loss
+    from fcd_gan_pytorch_amd.ssim   import MS_SSIM, SSIM, ms_ssim, ssim
+or call ``install_as_reference_modules()`` once and keep the reference scripts'
+``from Module import *`` / ``from Loss import *`` / ``from ssim import MS_SSIM`` lines.
+
+Importing the package loads ``libfcdgan_hip.so`` (hand-written HIP kernels, C ABI in
+include/fcdgan_hip.h) and raises if it is missing: there is no CPU/eager fallback.
+"""
+import sys
+
+from . import _lib          # noqa: F401  (fails loudly when the HIP library is absent)
+from . import Module, Loss, ssim, optim, steps  # noqa: F401
+
+__version__ = '0.1.0'
+
+
+def install_as_reference_modules():
+    """Register this package's modules under the reference's top-level names."""
+    sys.modules['Module'] = Module
+    sys.modules['Loss'] = Loss
+    sys.modules['ssim'] = ssim

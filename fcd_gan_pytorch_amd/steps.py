@@ -1,0 +1,236 @@
+"""The train-step bodies of Demo_USSS / Demo_RSSS / Demo_WSSS, data-parallel aware.
+
+Each function is ONE iteration of the corresponding reference loop, taking the
+already-constructed nets / criterion / fcd optimizers and device tensors, and
+returning the loss tensors (no ``.item()`` host syncs; the caller decides when to
+look).  Two modes:
+
+ ``literal=True``  -- the reference's exact autograd call sequence, including the
+    work whose results it throws away (S backward inside the D step, G / D weight
+    gradients inside the S step).
+ ``literal=False`` (default) -- result-identical for every parameter that is
+    actually stepped, without the discarded work: the D step runs on a detached
+    change map, all four D branches go through the shared net as one batch
+    (``forward_pairs``), the S step freezes D and runs the eval-mode G without a
+    graph.  This is the "minimal-necessary" FLOP count of SURVEY.md section 8(d).
+
+Data parallelism (one process per GPU): gradients of the network being stepped
+are all-reduced (sum) over RCCL as one flat buffer and averaged inside the
+optimizer kernel; BatchNorm uses per-replica batch statistics (DDP semantics).
+"""
+import contextlib
+
+import torch
+import torch.nn as nn
+
+from .Loss import region_loss
+
+
+@contextlib.contextmanager
+def _frozen(net):
+    """Temporarily drop requires_grad on a net's parameters (data-gradient only)."""
+    flags = [p.requires_grad for p in net.parameters()]
+    for p in net.parameters():
+        p.requires_grad_(False)
+    try:
+        yield
+    finally:
+        for p, f in zip(net.parameters(), flags):
+            p.requires_grad_(f)
+
+
+def _bcast_keep(cmask, C):
+    return 1 - cmask            # (N,1,H,W) broadcasts over the C bands (reference uses .repeat)
+
+
+# ------------------------------------------------------------------------ RSSS
+def rsss_g_pretrain_step(netG, crit, optG, x, y, region, perception_weight=0.1, ssim_weight=0, group=None):
+    """Demo_RSSS.py:190-208."""
+    optG.zero_grad()
+    y_fake = netG(x)
+    generator_loss, ssim_loss, perception_loss = crit(y, y_fake, region)
+    g_loss = generator_loss + perception_weight * perception_loss + ssim_weight * ssim_loss
+    g_loss.backward()
+    optG.allreduce_grads(group)
+    optG.step()
+    return dict(g_loss=g_loss, generator_loss=generator_loss, perception_loss=perception_loss, ssim_loss=ssim_loss)
+
+
+def rsss_adversarial_step(netS, netD, netG, crit, optS, optD, x, y, region, perception_weight=0.1,
+                          ssim_weight=0, l1_weight=0.02, g_weight=0.5, d_weight=1, r_weight=2,
+                          discriminator_continuous=True, literal=False, group=None):
+    """Demo_RSSS.py:285-332 (netG in eval mode, Demo_RSSS.py:240)."""
+    cmap = netS(x, y)
+    cmask = cmap if discriminator_continuous else (torch.sign(cmap - 0.5) + 1) / 2
+    y_unc = y * (1 - region) + x * region
+    # ---- D step
+    if literal:
+        keep = _bcast_keep(cmask, x.shape[1])
+        x_mask, y_mask = x * keep, y * keep
+        c_out = netD(x_mask, y_mask)
+        nc_out = netD(x * keep, y_unc * keep)
+        optD.zero_grad()
+        d_loss = 1 + nc_out.mean() - c_out.mean()
+        d_loss.backward(retain_graph=True)
+    else:
+        keep_d = _bcast_keep(cmask.detach(), x.shape[1])
+        xm_d = x * keep_d
+        c_out, nc_out = netD.forward_pairs([(xm_d, y * keep_d), (xm_d, y_unc * keep_d)])
+        optD.zero_grad()
+        d_loss = 1 + nc_out.mean() - c_out.mean()
+        d_loss.backward()
+    optD.allreduce_grads(group)
+    optD.step()
+    # ---- S step
+    if literal:
+        c_out = netD(x_mask, y_mask)
+        y_fake = netG(x)
+    else:
+        keep = _bcast_keep(cmask, x.shape[1])
+        with _frozen(netD):
+            c_out = netD(x * keep, y * keep)
+        with torch.no_grad():
+            y_fake = netG(x)
+    generator_loss, ssim_loss, perception_loss = crit(y, y_fake, cmap)
+    g_loss = generator_loss + perception_weight * perception_loss + ssim_weight * ssim_loss
+    l1_loss = region_loss(cmap, region, 'l1')
+    s_d_loss = c_out.mean()
+    r_loss = region_loss(cmap, 1 - region, 'mse')
+    s_loss = d_weight * s_d_loss + l1_weight * l1_loss + g_weight * g_loss + r_weight * r_loss
+    optS.zero_grad()
+    s_loss.backward()
+    optS.allreduce_grads(group)
+    optS.step()
+    return dict(d_loss=d_loss, s_loss=s_loss, s_d_loss=s_d_loss, g_loss=g_loss, l1_loss=l1_loss, r_loss=r_loss,
+                generator_loss=generator_loss, ssim_loss=ssim_loss, perception_loss=perception_loss, cmap=cmap)
+
+
+# ------------------------------------------------------------------------ WSSS
+def wsss_adversarial_step(netS, netD, netG, crit, optS, optD, x, y, x_nc, y_nc, perception_weight=0.5,
+                          ssim_weight=0, g_weight=0.2, l1_weight=1.6, d_weight=1, nc_weight=1.5,
+                          discriminator_continuous=True, literal=False, group=None):
+    """Demo_WSSS.py:249-323 (netG in eval mode, Demo_WSSS.py:206).  The unchanged pair
+    is masked with the CHANGED pair's map (:278-279)."""
+    cmap = netS(x, y)
+    cmask = cmap if discriminator_continuous else (torch.sign(cmap - 0.5) + 1) / 2
+    if literal:
+        keep = _bcast_keep(cmask, x.shape[1])
+        x_mask, y_mask = x * keep, y * keep
+        c_out = netD(x_mask, y_mask)
+        ncmap = netS(x_nc, y_nc)
+        nc_out = netD(x_nc * keep, y_nc * keep)
+        optD.zero_grad()
+        d_loss = 1 + nc_out.mean() - c_out.mean()
+        d_loss.backward(retain_graph=True)
+    else:
+        ncmap = netS(x_nc, y_nc)
+        keep_d = _bcast_keep(cmask.detach(), x.shape[1])
+        c_out, nc_out = netD.forward_pairs([(x * keep_d, y * keep_d), (x_nc * keep_d, y_nc * keep_d)])
+        optD.zero_grad()
+        d_loss = 1 + nc_out.mean() - c_out.mean()
+        d_loss.backward()
+    optD.allreduce_grads(group)
+    optD.step()
+    nc_loss = torch.mean(torch.pow(ncmap, 2))
+    if literal:
+        c_out = netD(x_mask, y_mask)
+        if g_weight != 0:
+            y_fake = netG(x)
+    else:
+        keep = _bcast_keep(cmask, x.shape[1])
+        with _frozen(netD):
+            c_out = netD(x * keep, y * keep)
+        if g_weight != 0:
+            with torch.no_grad():
+                y_fake = netG(x)
+    if g_weight != 0:
+        generator_loss, ssim_loss, perception_loss = crit(y, y_fake, cmap)
+    else:
+        generator_loss = ssim_loss = perception_loss = torch.zeros((), device=x.device)
+    g_loss = generator_loss + perception_weight * perception_loss + ssim_weight * ssim_loss
+    l1_loss = torch.mean(abs(cmap))
+    s_d_loss = c_out.mean()
+    s_loss = d_weight * s_d_loss + l1_weight * l1_loss + g_weight * g_loss + nc_weight * nc_loss
+    optS.zero_grad()
+    s_loss.backward()
+    optS.allreduce_grads(group)
+    optS.step()
+    return dict(d_loss=d_loss, s_loss=s_loss, s_d_loss=s_d_loss, g_loss=g_loss, l1_loss=l1_loss, nc_loss=nc_loss,
+                generator_loss=generator_loss, ssim_loss=ssim_loss, perception_loss=perception_loss, cmap=cmap,
+                ncmap=ncmap)
+
+
+# ------------------------------------------------------------------------ USSS
+def usss_g_pretrain_step(netG, crit, optG, x, y, perception_weight=0.4, ssim_weight=0, group=None):
+    """Demo_USSS.py:142-159 (cmap = 0)."""
+    optG.zero_grad()
+    y_fake = netG(x)
+    cmap = torch.zeros((x.shape[0], 1, x.shape[2], x.shape[3]), device=x.device)
+    generator_loss, l1_loss, perception_loss, ssim_loss = crit(y, y_fake, cmap)
+    loss = generator_loss + perception_weight * perception_loss + ssim_weight * ssim_loss
+    loss.backward()
+    optG.allreduce_grads(group)
+    optG.step()
+    return dict(loss=loss, generator_loss=generator_loss, perception_loss=perception_loss, ssim_loss=ssim_loss)
+
+
+def usss_s_pretrain_step(netS, netG, crit, optS, x, y, perception_weight=0.4, l1_weight=0.65, ssim_weight=0,
+                         literal=False, group=None):
+    """Demo_USSS.py:219-228: G forward in train mode (its BN running stats keep moving),
+    only S is stepped."""
+    if literal:
+        y_fake = netG(x)
+    else:
+        with torch.no_grad():
+            y_fake = netG(x)
+    cmap = netS(x, y)
+    generator_loss, l1_loss, perception_loss, ssim_loss = crit(y, y_fake, cmap)
+    net_loss = generator_loss + l1_weight * l1_loss + perception_weight * perception_loss + ssim_weight * ssim_loss
+    optS.zero_grad()
+    net_loss.backward()
+    optS.allreduce_grads(group)
+    optS.step()
+    return dict(net_loss=net_loss, generator_loss=generator_loss, l1_loss=l1_loss, perception_loss=perception_loss,
+                ssim_loss=ssim_loss, cmap=cmap)
+
+
+def usss_joint_step(netS, netG, crit, optS, optG, x, y, perception_weight=0.4, l1_weight=0.65, ssim_weight=0,
+                    literal=False, group=None):
+    """Demo_USSS.py:310-341.  The reference backpropagates ``Loss`` (retain_graph) and then
+    ``NetLoss = Loss + l1_weight*l1`` over the same graph: G ends with grad(Loss)+grad(NetLoss)
+    = 2*grad(Loss) (l1 does not depend on G), S with grad(NetLoss) only (zero_grad in
+    between).  literal=False does ONE backward of NetLoss and doubles G's gradient."""
+    optG.zero_grad()
+    y_fake = netG(x)
+    cmap = netS(x, y)
+    generator_loss, l1_loss, perception_loss, ssim_loss = crit(y, y_fake, cmap)
+    loss = generator_loss + perception_weight * perception_loss + ssim_weight * ssim_loss
+    net_loss = generator_loss + l1_weight * l1_loss + perception_weight * perception_loss + ssim_weight * ssim_loss
+    if literal:
+        loss.backward(retain_graph=True)
+        optS.zero_grad()
+        net_loss.backward()
+    else:
+        optS.zero_grad()
+        net_loss.backward()
+        optG.flat_g.mul_(2.0)
+    optG.allreduce_grads(group)
+    optS.allreduce_grads(group)
+    optG.step()
+    optS.step()
+    return dict(loss=loss, net_loss=net_loss, generator_loss=generator_loss, l1_loss=l1_loss,
+                perception_loss=perception_loss, ssim_loss=ssim_loss, cmap=cmap)
+
+
+# ------------------------------------------------------- on-device confusion matrix
+def confusion_counts(cmap, ref_changed, prob_thresh=0.5, group=None):
+    """2x2 confusion counts of the thresholded map vs. a {0,1} reference on device
+    (replaces the per-sample D2H + NumPy loop of Demo_RSSS.py:345-354); returns an
+    int64 tensor [tn, fp, fn, tp], all-reduced across ranks when distributed."""
+    import torch.distributed as dist
+    pred = cmap > prob_thresh
+    ref = ref_changed > 0.5
+    counts = torch.stack([(~pred & ~ref).sum(), (pred & ~ref).sum(), (~pred & ref).sum(), (pred & ref).sum()])
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(counts, group=group)
+    return counts

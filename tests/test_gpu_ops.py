@@ -1,0 +1,263 @@
+"""GPU parity of every C-ABI op against the same ATen op on CPU (the arithmetic the
+reference reaches through torch.nn), seeded inputs, fp32.  Tolerances: the MFMA
+kernels are exact-fp32 fma chains in a different summation order than oneDNN, so
+per-op error is ~1e-6 relative to sum|a*b|; tests use 2e-5 * scale."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from fcd_gan_pytorch_amd import _ops as ops
+    return ops
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    rng = np.random.default_rng([seed, len(shape)] + list(shape))
+    return torch.from_numpy((rng.standard_normal(shape) * scale).astype(np.float32))
+
+
+def assert_close(got, ref, tol=2e-5, what=''):
+    got = got.detach().cpu().double()
+    ref = ref.detach().double()
+    scale = max(ref.abs().max().item(), 1e-6)
+    err = (got - ref).abs().max().item()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    assert err <= tol * scale + 1e-7, '%s: max err %.3e (scale %.3e)' % (what, err, scale)
+
+
+CONV_CASES = [
+    # N, C, H, W, K, R, stride, pad
+    (2, 4, 32, 32, 64, 3, 1, 1),
+    (1, 13, 24, 40, 64, 3, 1, 1),
+    (2, 64, 40, 56, 64, 3, 1, 1),
+    (1, 64, 16, 16, 128, 3, 1, 1),
+    (2, 128, 20, 28, 256, 3, 1, 1),
+    (1, 256, 10, 14, 96, 3, 1, 1),
+    (3, 24, 5, 7, 40, 3, 1, 1),
+    (2, 8, 2, 2, 16, 3, 1, 1),
+    (2, 4, 32, 32, 64, 3, 2, 1),
+    (3, 64, 24, 20, 128, 3, 2, 1),
+    (2, 128, 19, 25, 256, 3, 2, 1),
+    (2, 4, 32, 32, 64, 9, 1, 4),
+    (1, 13, 24, 40, 64, 9, 1, 4),
+    (2, 64, 24, 40, 13, 9, 1, 4),
+    (2, 64, 20, 36, 4, 9, 1, 4),
+    (2, 128, 40, 56, 1, 1, 1, 0),
+    (3, 512, 1, 1, 1024, 1, 1, 0),
+    (3, 1024, 1, 1, 1, 1, 1, 0),
+    (2, 3, 48, 40, 64, 3, 1, 1),
+    (2, 512, 6, 5, 512, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: 'x'.join(map(str, c)))
+def test_conv2d_fwd_bwd(case):
+    ops = _ops()
+    N, C, H, W, K, R, st, pad = case
+    x = rnd(N, C, H, W, seed=1)
+    w = rnd(K, C, R, R, seed=2, scale=(2.0 / (C * R * R)) ** 0.5)
+    b = rnd(K, seed=3, scale=0.1)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br, stride=st, padding=pad)
+    g = rnd(*yr.shape, seed=4)
+    yr.backward(g)
+    xg, wg, bg = (t.cuda().requires_grad_(True) for t in (x, w, b))
+    y = ops.conv2d(xg, wg, bg, st, pad)
+    y.backward(g.cuda())
+    assert_close(y, yr, what='y')
+    assert_close(xg.grad, xr.grad, what='dx')
+    assert_close(wg.grad, wr.grad, tol=5e-5, what='dw')
+    assert_close(bg.grad, br.grad, what='db')
+
+
+@pytest.mark.parametrize('shape', [(2, 16, 5, 7), (1, 64, 12, 16), (3, 32, 1, 1)])
+def test_conv_transpose2x2(shape):
+    ops = _ops()
+    N, Cin, h, w = shape
+    Cout = Cin // 2
+    x, wt, b = rnd(N, Cin, h, w, seed=5), rnd(Cin, Cout, 2, 2, seed=6, scale=0.2), rnd(Cout, seed=7, scale=0.1)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, wt, b))
+    yr = F.conv_transpose2d(xr, wr, br, stride=2)
+    g = rnd(*yr.shape, seed=8)
+    yr.backward(g)
+    xg, wg, bg = (t.cuda().requires_grad_(True) for t in (x, wt, b))
+    y = ops.conv_transpose2x2(xg, wg, bg)
+    y.backward(g.cuda())
+    assert_close(y, yr, what='y')
+    assert_close(xg.grad, xr.grad, what='dx')
+    assert_close(wg.grad, wr.grad, tol=5e-5, what='dw')
+    assert_close(bg.grad, br.grad, what='db')
+
+
+class _BN:
+    pass
+
+
+def _mk_bn(C, training, seed):
+    bn = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.copy_(1 + 0.1 * rnd(C, seed=seed))
+        bn.bias.copy_(0.1 * rnd(C, seed=seed + 1))
+        bn.running_mean.copy_(0.1 * rnd(C, seed=seed + 2))
+        bn.running_var.copy_(1 + 0.2 * torch.tanh(rnd(C, seed=seed + 3)))
+    bn.train(training)
+    return bn
+
+
+@pytest.mark.parametrize('training', [True, False])
+@pytest.mark.parametrize('act', ['none', 'relu', 'leaky', 'prelu'])
+@pytest.mark.parametrize('shape,groups', [((4, 16, 12, 20), 1), ((4, 8, 9, 7), 2), ((8, 32, 4, 4), 4), ((2, 64, 33, 1), 1)])
+def test_bn_act(training, act, shape, groups):
+    ops = _ops()
+    import copy
+    N, C, H, W = shape
+    x = rnd(*shape, seed=11) * 1.5 + 0.3
+    g = rnd(*shape, seed=12)
+    bn_ref = _mk_bn(C, training, 20)
+    bn_gpu = copy.deepcopy(bn_ref).cuda()
+    slope_ref = torch.tensor([0.25], requires_grad=True)
+    slope_gpu = torch.tensor([0.25], device='cuda', requires_grad=True)
+
+    def actf(t, sl):
+        if act == 'relu':
+            return F.relu(t)
+        if act == 'leaky':
+            return F.leaky_relu(t, 0.2)
+        if act == 'prelu':
+            return F.prelu(t, sl)
+        return t
+    xr = x.clone().requires_grad_(True)
+    Ng = N // groups
+    outs = [actf(bn_ref(xr[i * Ng:(i + 1) * Ng]), slope_ref) for i in range(groups)]   # sequential calls
+    yr = torch.cat(outs, 0)
+    yr.backward(g)
+    code = {'none': ops.ACT_NONE, 'relu': ops.ACT_RELU, 'leaky': ops.ACT_LEAKY, 'prelu': ops.ACT_PRELU}[act]
+    xg = x.cuda().requires_grad_(True)
+    y = ops.bn_act(xg, bn_gpu, code, slope=slope_gpu if act == 'prelu' else None, slope_imm=0.2, groups=groups)
+    y.backward(g.cuda())
+    assert_close(y, yr, what='y')
+    assert_close(xg.grad, xr.grad, tol=5e-5, what='dx')
+    assert_close(bn_gpu.weight.grad, bn_ref.weight.grad, tol=5e-5, what='dgamma')
+    assert_close(bn_gpu.bias.grad, bn_ref.bias.grad, tol=5e-5, what='dbeta')
+    if act == 'prelu':
+        assert_close(slope_gpu.grad, slope_ref.grad, tol=5e-5, what='dslope')
+    assert_close(bn_gpu.running_mean, bn_ref.running_mean, what='running_mean')
+    assert_close(bn_gpu.running_var, bn_ref.running_var, what='running_var')
+    assert int(bn_gpu.num_batches_tracked) == int(bn_ref.num_batches_tracked)
+
+
+@pytest.mark.parametrize('act', ['leaky', 'prelu', 'relu'])
+def test_bare_activation(act):
+    ops = _ops()
+    x, g = rnd(2, 8, 7, 9, seed=31), rnd(2, 8, 7, 9, seed=32)
+    sr = torch.tensor([0.3], requires_grad=True)
+    sg = torch.tensor([0.3], device='cuda', requires_grad=True)
+    xr = x.clone().requires_grad_(True)
+    yr = {'leaky': lambda t: F.leaky_relu(t, 0.2), 'prelu': lambda t: F.prelu(t, sr), 'relu': F.relu}[act](xr)
+    yr.backward(g)
+    xg = x.cuda().requires_grad_(True)
+    code = {'relu': ops.ACT_RELU, 'leaky': ops.ACT_LEAKY, 'prelu': ops.ACT_PRELU}[act]
+    y = ops.bn_act(xg, None, code, slope=sg if act == 'prelu' else None, slope_imm=0.2)
+    y.backward(g.cuda())
+    assert_close(y, yr, what='y')
+    assert_close(xg.grad, xr.grad, what='dx')
+    if act == 'prelu':
+        assert_close(sg.grad, sr.grad, tol=5e-5, what='dslope')
+
+
+@pytest.mark.parametrize('shape', [(2, 3, 8, 8), (1, 5, 11, 13), (2, 4, 27, 55), (1, 2, 2, 2), (1, 2, 3, 3)])
+def test_maxpool_upsample_avgpool(shape):
+    ops = _ops()
+    x = rnd(*shape, seed=41)
+    for name, ref_fn, fn in (
+            ('maxpool', lambda t: F.max_pool2d(t, 2), ops.maxpool2),
+            ('upsample', lambda t: F.interpolate(t, scale_factor=2, mode='bilinear', align_corners=True), ops.upsample2x),
+            ('avgpool', lambda t: F.avg_pool2d(t, kernel_size=2, padding=[s % 2 for s in t.shape[2:]]), ops.avgpool2_pad)):
+        xr = x.clone().requires_grad_(True)
+        yr = ref_fn(xr)
+        g = rnd(*yr.shape, seed=42)
+        yr.backward(g)
+        xg = x.cuda().requires_grad_(True)
+        y = fn(xg)
+        y.backward(g.cuda())
+        assert_close(y, yr, tol=1e-6, what=name + ' y')
+        assert_close(xg.grad, xr.grad, tol=2e-6, what=name + ' dx')
+
+
+@pytest.mark.parametrize('kind', [0, 1])
+@pytest.mark.parametrize('complement', [True, False])
+def test_masked_sums(kind, complement):
+    ops = _ops()
+    N, C, H, W = 3, 5, 17, 23
+    a, b = rnd(N, C, H, W, seed=51), rnd(N, C, H, W, seed=52)
+    m = torch.sigmoid(rnd(N, 1, H, W, seed=53))
+    ar, br_, mr = (t.clone().requires_grad_(True) for t in (a, b, m))
+    w = (1 - mr) if complement else mr
+    d = (ar - br_) * w
+    num = (d.abs() if kind == 0 else d * d).sum((1, 2, 3))
+    ws = w.sum((1, 2, 3))
+    coef, cw = rnd(N, seed=54), rnd(N, seed=55)
+    (num * coef + ws * cw).sum().backward()
+    ag, bg, mg = (t.cuda().requires_grad_(True) for t in (a, b, m))
+    n2, w2 = ops.masked_sums(ag, bg, mg, kind, complement)
+    (n2 * coef.cuda() + w2 * cw.cuda()).sum().backward()
+    assert_close(n2, num, what='num')
+    assert_close(w2, ws, what='wsum')
+    assert_close(ag.grad, ar.grad, what='da')
+    assert_close(bg.grad, br_.grad, what='db')
+    assert_close(mg.grad, mr.grad, what='dm')
+
+
+def test_adam_rmsprop_match_torch():
+    ops = _ops()
+    n = 10007
+    p0, gs = rnd(n, seed=61), [rnd(n, seed=62 + i) * (0.1 if i else 1.0) for i in range(3)]
+    for kind in ('adam', 'rmsprop'):
+        pr = p0.clone().requires_grad_(True)
+        opt = torch.optim.Adam([pr], lr=2e-4, betas=(0.9, 0.99)) if kind == 'adam' else torch.optim.RMSprop([pr], lr=5e-5)
+        pg = p0.cuda()
+        s1, s2 = torch.zeros_like(pg), torch.zeros_like(pg)
+        for step, g in enumerate(gs, 1):
+            pr.grad = g.clone()
+            opt.step()
+            if kind == 'adam':
+                ops.adam_step(pg, g.cuda(), s1, s2, 2e-4, 0.9, 0.99, 1e-8, 0.0, step)
+            else:
+                ops.rmsprop_step(pg, g.cuda(), s1, 5e-5, 0.99, 1e-8, 0.0)
+        assert_close(pg, pr, tol=1e-6, what=kind)
+
+
+@pytest.mark.parametrize('shape', [(2, 3, 40, 52), (1, 4, 176, 176), (1, 2, 200, 184), (2, 1, 11, 11), (1, 1, 13, 31)])
+def test_ssim_level_and_msssim(shape):
+    """fused SSIM level vs the oracle's op-by-op restatement of ssim.py:55-92."""
+    ops = _ops()
+    from oracle import losses as ol
+    from fcd_gan_pytorch_amd import ssim as pssim
+    N, C, H, W = shape
+    x = rnd(*shape, seed=71)
+    y = x + 0.3 * rnd(*shape, seed=72)
+    g = ol.gauss_window()
+    xr, yr = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+    s_ref, cs_ref = ol.ssim_level(xr, yr, g)
+    ws, wc = rnd(N, C, seed=73), rnd(N, C, seed=74)
+    ((s_ref * ws).sum() + (cs_ref * wc).sum()).backward()
+    xg, yg = x.cuda().requires_grad_(True), y.cuda().requires_grad_(True)
+    s, cs = ops.ssim_level(xg, yg, g.cuda(), 0.01 ** 2, 0.03 ** 2)
+    ((s * ws.cuda()).sum() + (cs * wc.cuda()).sum()).backward()
+    assert_close(s, s_ref, tol=2e-5, what='ssim')
+    assert_close(cs, cs_ref, tol=2e-5, what='cs')
+    assert_close(xg.grad, xr.grad, tol=1e-4, what='dX')
+    assert_close(yg.grad, yr.grad, tol=1e-4, what='dY')
+    if min(H, W) > 160:
+        xr.grad = None; yr.grad = None; xg.grad = None; yg.grad = None
+        v_ref = ol.ms_ssim(xr, yr, data_range=1.0)
+        v_ref.backward()
+        v = pssim.MS_SSIM(data_range=1.0, channel=C)(xg, yg)
+        v.backward()
+        assert abs(v.item() - v_ref.item()) < 1e-5
+        assert_close(xg.grad, xr.grad, tol=1e-4, what='ms dX')
+        assert_close(yg.grad, yr.grad, tol=1e-4, what='ms dY')
