@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""Headline benchmark: tile-pairs/s of the FCD-GAN RSSS adversarial train step
+(Demo_RSSS.py:285-332: S fwd, D step, S step incl. eval-mode G, masked MSE,
+MS-SSIM, per-band VGG16 perception, region losses, RMSprop) on 13-band 256x256
+synthetic bi-temporal tiles, fp32, one process per GPU (weak scaling: fixed tiles
+per GPU, gradients all-reduced over RCCL).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+Prints ONE JSON line on rank 0 (see the driver contract) with two extra objects:
+  roofline     -- the dominant kernel family (MFMA implicit-GEMM conv, forward +
+                  data-gradient launches) timed with HIP events on the launch stream
+                  over the timed region: algorithmic FLOPs / event time vs the fp32
+                  MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md)
+  cpu_baseline -- the CPU oracle (port of the reference's step on stock torch CPU ops)
+                  timed on this box's host cores on a bounded sample (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import warnings
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+PEAK_F32_MFMA_TFLOPS = 157.3
+
+
+def build_workload(args, dev, rank):
+    import fcd_gan_pytorch_amd as fcd
+    from fcd_gan_pytorch_amd.synthetic import synthetic_tiles
+    C, H, W, N = args.bands, args.size, args.size, args.batch
+    torch.manual_seed(0)
+    netD = fcd.Module.Discriminator_SRGAN_simple(n_channels=C)
+    netS = fcd.Module.Segmentor(n_channels=C, bilinear=True)
+    netG = fcd.Module.Generator(n_channels=C)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        crit = fcd.Loss.CGeneratorLoss(channel=C, perception_layer=1, perception_perBand=True)
+    for m in (netD, netS, netG, crit):
+        m.to(dev)
+    netS.train(); netD.train(); netG.eval()          # Demo_RSSS.py:146-148,240
+    optS = fcd.optim.RMSprop(netS.parameters(), lr=5e-5)
+    optD = fcd.optim.RMSprop(netD.parameters(), lr=5e-5)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(optS.flat_p, 0)
+        dist.broadcast(optD.flat_p, 0)
+        for t in list(netG.state_dict().values()) + list(netS.buffers()) + list(netD.buffers()):
+            dist.broadcast(t, 0)
+    x, y, region = (t.to(dev) for t in synthetic_tiles(1234 + rank, N, C, H, W))
+
+    def step():
+        return fcd.steps.rsss_adversarial_step(netS, netD, netG, crit, optS, optD, x, y, region)
+    return step
+
+
+def effective_cores():
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota
+    (the GPU box advertises 256 logical CPUs but the container is quota-limited)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(args):
+    """Oracle step (CPU port of the reference loop body, literal call order) on the host cores."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+    from oracle import nets as onets, steps as osteps
+    from fcd_gan_pytorch_amd.synthetic import synthetic_tiles
+    import fcd_gan_pytorch_amd as fcd
+    C, H, W = args.bands, args.size, args.size
+    n = 1
+    cores = effective_cores()
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        sdD = fcd.Module.Discriminator_SRGAN_simple(C).state_dict()
+        sdS = fcd.Module.Segmentor(C, bilinear=True).state_dict()
+        sdG = fcd.Module.Generator(C).state_dict()
+        sdV = fcd.Loss.PerceptionLoss(1, True).net.state_dict()
+    nets = osteps.Nets(sdG, sdS, sdD, sdV).make_optimizers('rsss')
+    x, y, region = synthetic_tiles(1234, n, C, H, W)
+    osteps.rsss_adversarial_step(nets, x, y, region)            # warm-up (oneDNN primitive creation)
+    iters, t0 = 0, time.perf_counter()
+    while iters < 2 and (time.perf_counter() - t0) < 25.0 or iters == 0:
+        osteps.rsss_adversarial_step(nets, x, y, region)
+        iters += 1
+    dt = time.perf_counter() - t0
+    model = ''
+    try:
+        with open('/proc/cpuinfo') as f:
+            model = [l.split(':', 1)[1].strip() for l in f if l.startswith('model name')][0]
+    except Exception:
+        pass
+    return {'value': n * iters / dt, 'unit': 'tile-pairs/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d iteration(s) of the literal Demo_RSSS adversarial step, batch %d, %dx%dx%d, '
+                      'torch CPU (oneDNN) fp32, %d threads, after 1 warm-up' % (iters, n, H, W, C, cores),
+            'cpu_model': model, 'seconds': dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=8, help='tile pairs per GPU per step')
+    ap.add_argument('--bands', type=int, default=13)
+    ap.add_argument('--size', type=int, default=256)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-prof', action='store_true', help='do not bracket launches with HIP events')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the product has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+    n_gpus = world
+
+    from fcd_gan_pytorch_amd import _lib
+    step = build_workload(args, dev, rank)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    if not args.no_prof:
+        _lib.prof_read(reset=True)
+        _lib.lib.fcd_prof_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    _lib.lib.fcd_prof_enable(0)
+    prof = _lib.prof_read(reset=True) if not args.no_prof else {}
+    losses = {k: float(v) for k, v in out.items() if v.dim() == 0}
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        total_pairs = args.batch * n_gpus * args.steps
+        res = {
+            'metric': 'tile-pairs/sec (train step) on 256x256x13 OSCD',
+            'value': total_pairs / dt, 'unit': 'tile-pairs/s', 'n_gpus': n_gpus, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'Demo_RSSS adversarial step (S+D+G, masked MSE, MS-SSIM, per-band VGG16 '
+                                   'perception, region losses, RMSprop), %d bands %dx%d, random-init weights'
+                                   % (args.bands, args.size, args.size),
+                       'tile_pairs_per_gpu': args.batch, 'global_batch': args.batch * n_gpus,
+                       'parallelism': 'dp%d' % n_gpus, 'bn': 'per-replica statistics'},
+            'losses_last_step': losses,
+        }
+        if prof:
+            fwd, dg, wg = prof['conv_igemm_fwd'], prof['conv_igemm_dgrad'], prof['conv_wgrad']
+            ms = fwd['ms'] + dg['ms']
+            flops = fwd['flops'] + dg['flops']
+            launches = fwd['launches'] + dg['launches']
+            ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            res['roofline'] = {
+                'bound': 'mfma', 'kernel': 'conv_igemm_kernel (fp32 MFMA implicit GEMM; forward + data-gradient launches)',
+                'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS,
+                'traffic': None, 'launches_per_step': launches / args.steps,
+                'avg_launch_ms': ms / max(launches, 1), 'algorithmic_gflop_per_launch': flops / max(launches, 1) / 1e9,
+                'share_of_step_time': ms / (1e3 * dt) if dt > 0 else None,
+            }
+            res['kernel_families'] = {
+                k: {'ms_per_step': v['ms'] / args.steps, 'launches_per_step': v['launches'] / args.steps,
+                    'tflops': (v['flops'] / (v['ms'] * 1e-3) / 1e12) if v['ms'] > 0 and v['flops'] > 0 else None,
+                    'gbps': (v['bytes'] / (v['ms'] * 1e-3) / 1e9) if v['ms'] > 0 and v['bytes'] > 0 else None}
+                for k, v in prof.items() if v['launches'] > 0}
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline(args)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
