@@ -15,6 +15,7 @@
 // gradient (mode-1 packed = flipped/transposed taps, pad' = R-1-pad) and, with
 // DIL=2, the data gradient of stride-2 convolutions (reads a zero-dilated dY).
 #include "common.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -33,7 +34,7 @@ struct ConvArgs {
 
 template <int R, int S, int RCH, int STRIDE, int DIL, int CB, int MI, int NI, int WM, int WN, int TH,
           int TW>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, 3) void conv_igemm_kernel(ConvArgs a) {
   constexpr int BM = 32 * MI * WM;
   constexpr int BN = 32 * NI * WN;
   static_assert(WM * WN == 4, "4 waves");
@@ -83,69 +84,76 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
+  // ---- staging registers and their (loop-invariant) addresses, computed once --------
   float4 wr[W_PER_T];
   float xr[X_PER_T];
-
-  const float* xin = a.x + (size_t)n * a.C * a.H * a.W;
+  int w_goff[W_PER_T];      // packed-weight offset of this thread's i-th float4 within a step slab
+  int x_goff[X_PER_T];      // input offset of this thread's i-th patch element within a channel chunk
+  int x_loff[X_PER_T];      // ... and its LDS slot
+  int x_cc[X_PER_T];        // ... and its channel within the chunk (-1: out of the image => always 0)
   const int ih0 = p0 * STRIDE - a.pad, iw0 = q0 * STRIDE - a.pad;
+#pragma unroll
+  for (int i = 0; i < W_PER_T; ++i) {
+    const int idx = tid + i * 256;
+    const int row = idx / (BM / 4), col4 = idx % (BM / 4);
+    const int cc = row / (RCH * S), rem = row % (RCH * S);
+    w_goff[i] = (cc * (R * S) + rem) * a.Kpad + ko0 + col4 * 4;
+  }
+#pragma unroll
+  for (int i = 0; i < X_PER_T; ++i) {
+    const int idx = tid + i * 256;
+    const int cc = idx / (PH * PW), rem = idx % (PH * PW);
+    const int ph = rem / PW, pw = rem % PW;
+    int ih = ih0 + ph, iw = iw0 + pw;
+    bool ok = idx < X_ELEMS && ih >= 0 && iw >= 0;
+    if (DIL == 2) {
+      ok = ok && !((ih | iw) & 1);
+      ih >>= 1;
+      iw >>= 1;
+    }
+    ok = ok && ih < a.H && iw < a.W;
+    x_cc[i] = ok ? cc : -1;
+    x_goff[i] = (cc * a.H + ih) * a.W + iw;
+    x_loff[i] = cc * PLANE + ph * PWP + pw;
+  }
+  const float* xin = a.x + (size_t)n * a.C * a.H * a.W;
+  const int chunk_elems = CB * a.H * a.W;
 
-  auto load_w = [&](int cchunk, int rr) {
-#pragma unroll
-    for (int i = 0; i < W_PER_T; ++i) {
-      const int idx = tid + i * 256;
-      if (W_F4 % 256 == 0 || idx < W_F4) {
-        const int row = idx / (BM / 4), col4 = idx % (BM / 4);
-        const int cc = row / (RCH * S), rem = row % (RCH * S);
-        const int grow = (cchunk * CB + cc) * (R * S) + rr * (RCH * S) + rem;
-        wr[i] = *reinterpret_cast<const float4*>(a.wp + (size_t)grow * a.Kpad + ko0 + col4 * 4);
-      }
-    }
-  };
-  auto store_w = [&]() {
-#pragma unroll
-    for (int i = 0; i < W_PER_T; ++i) {
-      const int idx = tid + i * 256;
-      if (W_F4 % 256 == 0 || idx < W_F4) *reinterpret_cast<float4*>(Ws + idx * 4) = wr[i];
-    }
-  };
-  auto load_x = [&](int cchunk) {
-#pragma unroll
-    for (int i = 0; i < X_PER_T; ++i) {
-      const int idx = tid + i * 256;
-      float v = 0.f;
-      if (idx < X_ELEMS) {
-        const int cc = idx / (PH * PW), rem = idx % (PH * PW);
-        const int ph = rem / PW, pw = rem % PW;
-        const int c = cchunk * CB + cc;
-        int ih = ih0 + ph, iw = iw0 + pw;
-        bool ok = (c < a.C) && ih >= 0 && iw >= 0;
-        if (DIL == 2) {
-          ok = ok && !((ih | iw) & 1);
-          ih >>= 1;
-          iw >>= 1;
-        }
-        ok = ok && ih < a.H && iw < a.W;
-        if (ok) v = xin[((size_t)c * a.H + ih) * a.W + iw];
-      }
-      xr[i] = v;
-    }
-  };
-  auto store_x = [&]() {
-#pragma unroll
-    for (int i = 0; i < X_PER_T; ++i) {
-      const int idx = tid + i * 256;
-      if (idx < X_ELEMS) {
-        const int cc = idx / (PH * PW), rem = idx % (PH * PW);
-        Xs[cc * PLANE + (rem / PW) * PWP + (rem % PW)] = xr[i];
-      }
-    }
-  };
+#define FCD_LOAD_W(CCHUNK, RR)                                                                        \
+  {                                                                                                   \
+    const float* wsrc = a.wp + ((size_t)(CCHUNK) * CB * (R * S) + (RR) * (RCH * S)) * a.Kpad;         \
+    _Pragma("unroll") for (int i = 0; i < W_PER_T; ++i) {                                             \
+      if (W_F4 % 256 == 0 || tid + i * 256 < W_F4) wr[i] = *reinterpret_cast<const float4*>(wsrc + w_goff[i]); \
+    }                                                                                                 \
+  }
+#define FCD_STORE_W()                                                                                 \
+  {                                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < W_PER_T; ++i) {                                             \
+      if (W_F4 % 256 == 0 || tid + i * 256 < W_F4) *reinterpret_cast<float4*>(Ws + (tid + i * 256) * 4) = wr[i]; \
+    }                                                                                                 \
+  }
+#define FCD_LOAD_X(CCHUNK)                                                                            \
+  {                                                                                                   \
+    const float* xsrc = xin + (size_t)(CCHUNK) * chunk_elems;                                         \
+    const int cleft = a.C - (CCHUNK) * CB;                                                            \
+    _Pragma("unroll") for (int i = 0; i < X_PER_T; ++i) {                                             \
+      float v = 0.f;                                                                                  \
+      if (x_cc[i] >= 0 && x_cc[i] < cleft) v = xsrc[x_goff[i]];                                       \
+      xr[i] = v;                                                                                      \
+    }                                                                                                 \
+  }
+#define FCD_STORE_X()                                                                                 \
+  {                                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < X_PER_T; ++i) {                                             \
+      if (X_ELEMS % 256 == 0 || tid + i * 256 < X_ELEMS) Xs[x_loff[i]] = xr[i];                      \
+    }                                                                                                 \
+  }
 
   const int nsteps = a.nchunks * NR;
-  load_x(0);
-  load_w(0, 0);
-  store_x();
-  store_w();
+  FCD_LOAD_X(0)
+  FCD_LOAD_W(0, 0)
+  FCD_STORE_X()
+  FCD_STORE_W()
   __syncthreads();
 
   for (int step = 0; step < nsteps; ++step) {
@@ -154,8 +162,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const bool have_next = nxt < nsteps;
     const bool next_patch = have_next && (NR == 1 || nxt % NR == 0);
     if (have_next) {
-      if (next_patch) load_x(nxt / NR);
-      load_w(nxt / NR, (NR == 1) ? 0 : nxt % NR);
+      if (next_patch) FCD_LOAD_X(nxt / NR)
+      FCD_LOAD_W(nxt / NR, (NR == 1) ? 0 : nxt % NR)
     }
 
     const float* wl = Ws + woff;
@@ -181,13 +189,202 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     }
     __syncthreads();
     if (have_next) {
-      if (next_patch) store_x();
-      store_w();
+      if (next_patch) FCD_STORE_X()
+      FCD_STORE_W()
     }
     __syncthreads();
   }
+#undef FCD_LOAD_W
+#undef FCD_STORE_W
+#undef FCD_LOAD_X
+#undef FCD_STORE_X
 
   // epilogue: D layout col = lane&31 (pixel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (channel)
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int pidx = wn * (32 * NI) + ni * 32 + l31;
+    const int p = p0 + pidx / TW, q = q0 + pidx % TW;
+    if (p >= a.P || q >= a.Q) continue;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ko = ko0 + wm * (32 * MI) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (ko < a.K) {
+          float v = acc[mi][ni][r];
+          if (a.bias) v += a.bias[ko];
+          a.y[(((size_t)n * a.K + ko) * a.P + p) * a.Q + q] = v;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// v2: same math, different staging.  The packed filter slab of a step is a set of
+// KC rows of BM contiguous floats, i.e. its LDS image [KC][BM] is lane-linear, so it is
+// DMA'd straight into LDS with global_load_lds (16 B per lane, no VGPR staging, no
+// ds_write pass).  Both LDS buffers (filter slab + input patch) are double-buffered:
+// one s_barrier per step instead of two, and the registers freed by the filter staging
+// buy a third resident workgroup per CU.
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+
+template <int R, int S, int RCH, int STRIDE, int DIL, int CB, int MI, int NI, int WM, int WN, int TH,
+          int TW>
+__global__ __launch_bounds__(256, 3) void conv_igemm_glds_kernel(ConvArgs a) {
+  constexpr int BM = 32 * MI * WM;
+  constexpr int BN = 32 * NI * WN;
+  static_assert(WM * WN == 4, "4 waves");
+  static_assert(TH * TW == BN, "pixel tile");
+  static_assert(R % RCH == 0 && CB % 2 == 0, "chunks");
+  constexpr int PH = (TH - 1) * STRIDE + R;
+  constexpr int PW = (TW - 1) * STRIDE + S;
+  constexpr int PWP = PW | 1;
+  constexpr int PLANE = PH * PWP;
+  constexpr int KC = CB * RCH * S;
+  constexpr int NR = R / RCH;
+  constexpr int W_INSTR = KC * BM / 256;           // 1 KiB wave-instructions per slab
+  static_assert((KC * BM) % 256 == 0, "slab must be a whole number of wave loads");
+  constexpr int W_PER_WAVE = (W_INSTR + 3) / 4;
+  constexpr int X_ELEMS = CB * PH * PW;
+  constexpr int X_PER_T = (X_ELEMS + 255) / 256;
+  constexpr int WS_SZ = KC * BM, XS_SZ = CB * PLANE;
+
+  __shared__ __attribute__((aligned(16))) float smem[2 * WS_SZ + 2 * XS_SZ];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wm = wave / WN, wn = wave % WN;
+
+  int bx = blockIdx.x;
+  const int tq = bx % a.tiles_q;
+  bx /= a.tiles_q;
+  const int tp = bx % a.tiles_p;
+  const int n = bx / a.tiles_p;
+  const int ko0 = blockIdx.y * BM;
+  const int p0 = tp * TH, q0 = tq * TW;
+
+  int xoff[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int pidx = wn * (32 * NI) + ni * 32 + l31;
+    xoff[ni] = half * PLANE + (pidx / TW) * STRIDE * PWP + (pidx % TW) * STRIDE;
+  }
+  const int woff = half * (RCH * S) * BM + wm * (32 * MI) + l31;
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  // loop-invariant addresses
+  int w_goff[W_PER_WAVE];
+#pragma unroll
+  for (int j = 0; j < W_PER_WAVE; ++j) {
+    const int f = (wave + 4 * j) * 256 + lane * 4;     // float index inside the slab
+    const int row = f / BM, col = f % BM;
+    const int cc = row / (RCH * S), rem = row % (RCH * S);
+    w_goff[j] = (cc * (R * S) + rem) * a.Kpad + ko0 + col;
+  }
+  float xr[X_PER_T];
+  int x_goff[X_PER_T], x_loff[X_PER_T], x_cc[X_PER_T];
+  const int ih0 = p0 * STRIDE - a.pad, iw0 = q0 * STRIDE - a.pad;
+#pragma unroll
+  for (int i = 0; i < X_PER_T; ++i) {
+    const int idx = tid + i * 256;
+    const int cc = idx / (PH * PW), rem = idx % (PH * PW);
+    const int ph = rem / PW, pw = rem % PW;
+    int ih = ih0 + ph, iw = iw0 + pw;
+    bool ok = idx < X_ELEMS && ih >= 0 && iw >= 0;
+    if (DIL == 2) {
+      ok = ok && !((ih | iw) & 1);
+      ih >>= 1;
+      iw >>= 1;
+    }
+    ok = ok && ih < a.H && iw < a.W;
+    x_cc[i] = ok ? cc : -1;
+    x_goff[i] = (cc * a.H + ih) * a.W + iw;
+    x_loff[i] = cc * PLANE + ph * PWP + pw;
+  }
+  const float* xin = a.x + (size_t)n * a.C * a.H * a.W;
+  const int chunk_elems = CB * a.H * a.W;
+
+#define FCD_GLDS_W(CCHUNK, RR, BUF)                                                                   \
+  {                                                                                                   \
+    const float* wsrc = a.wp + ((size_t)(CCHUNK) * CB * (R * S) + (RR) * (RCH * S)) * a.Kpad;         \
+    _Pragma("unroll") for (int j = 0; j < W_PER_WAVE; ++j) {                                          \
+      if (W_INSTR % 4 == 0 || wave + 4 * j < W_INSTR)                                                 \
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(wsrc + w_goff[j]),                             \
+                                         (lds_void_t*)(smem + (BUF) * WS_SZ + (wave + 4 * j) * 256), 16, 0, 0); \
+    }                                                                                                 \
+  }
+#define FCD_LOAD_X2(CCHUNK)                                                                           \
+  {                                                                                                   \
+    const float* xsrc = xin + (size_t)(CCHUNK) * chunk_elems;                                         \
+    const int cleft = a.C - (CCHUNK) * CB;                                                            \
+    _Pragma("unroll") for (int i = 0; i < X_PER_T; ++i) {                                             \
+      float v = 0.f;                                                                                  \
+      if (x_cc[i] >= 0 && x_cc[i] < cleft) v = xsrc[x_goff[i]];                                       \
+      xr[i] = v;                                                                                      \
+    }                                                                                                 \
+  }
+#define FCD_STORE_X2(BUF)                                                                             \
+  {                                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < X_PER_T; ++i) {                                             \
+      if (X_ELEMS % 256 == 0 || tid + i * 256 < X_ELEMS) smem[2 * WS_SZ + (BUF) * XS_SZ + x_loff[i]] = xr[i]; \
+    }                                                                                                 \
+  }
+
+  const int nsteps = a.nchunks * NR;
+  FCD_GLDS_W(0, 0, 0)
+  FCD_LOAD_X2(0)
+  FCD_STORE_X2(0)
+  __syncthreads();
+
+  for (int step = 0; step < nsteps; ++step) {
+    const int nxt = step + 1;
+    const int rr = (NR == 1) ? 0 : step % NR;
+    const int chunk = (NR == 1) ? step : step / NR;
+    const bool have_next = nxt < nsteps;
+    const bool next_patch = have_next && (NR == 1 || nxt % NR == 0);
+    const int wb = step & 1, xb = chunk & 1;
+    if (have_next) {
+      FCD_GLDS_W((NR == 1) ? nxt : nxt / NR, (NR == 1) ? 0 : nxt % NR, wb ^ 1)
+      if (next_patch) FCD_LOAD_X2(chunk + 1)
+    }
+    const float* wl = smem + wb * WS_SZ + woff;
+    const float* xl = smem + 2 * WS_SZ + xb * XS_SZ + rr * RCH * PWP;
+#pragma unroll
+    for (int cc2 = 0; cc2 < CB / 2; ++cc2) {
+#pragma unroll
+      for (int rl = 0; rl < RCH; ++rl) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+          float av[MI], bv[NI];
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) av[mi] = wl[((cc2 * 2) * (RCH * S) + rl * S + s) * BM + mi * 32];
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) bv[ni] = xl[xoff[ni] + (cc2 * 2) * PLANE + rl * PWP + s];
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+        }
+      }
+    }
+    if (next_patch) FCD_STORE_X2(xb ^ 1)
+    __syncthreads();
+  }
+#undef FCD_GLDS_W
+#undef FCD_LOAD_X2
+#undef FCD_STORE_X2
+
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
     const int pidx = wn * (32 * NI) + ni * 32 + l31;
@@ -265,6 +462,15 @@ extern "C" int fcd_conv_pack_weights(const float* w, float* wp, int K, int C, in
 
 // ---------------------------------------------------------------------------
 // dispatch
+static int use_v2() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("FCD_CONV_V2");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v;
+}
+
 template <int R, int S, int RCH, int STRIDE, int DIL, int CB, int MI, int NI, int WM, int WN, int TH,
           int TW>
 static int launch_cfg(const ConvArgs& a0, hipStream_t st) {
@@ -272,10 +478,22 @@ static int launch_cfg(const ConvArgs& a0, hipStream_t st) {
   constexpr int BM = 32 * MI * WM;
   a.tiles_p = cdiv(a.P, TH);
   a.tiles_q = cdiv(a.Q, TW);
-  a.nchunks = cdiv(a.C, CB);
   dim3 grid((unsigned)(a.N * a.tiles_p * a.tiles_q), (unsigned)cdiv(a.K, BM));
-  hipLaunchKernelGGL((conv_igemm_kernel<R, S, RCH, STRIDE, DIL, CB, MI, NI, WM, WN, TH, TW>), grid,
-                     dim3(256), 0, st, a);
+  constexpr int CB2 = 4;
+  constexpr bool kHasV2 = (R == 3 && S == 3) && ((CB2 * RCH * S * BM) % 256 == 0);
+  if constexpr (kHasV2) {
+    if (use_v2()) {
+      a.nchunks = cdiv(a.C, CB2);
+      hipLaunchKernelGGL((conv_igemm_glds_kernel<R, S, RCH, STRIDE, DIL, CB2, MI, NI, WM, WN, TH, TW>), grid,
+                         dim3(256), 0, st, a);
+      return 0;
+    }
+  }
+  {
+    a.nchunks = cdiv(a.C, CB);
+    hipLaunchKernelGGL((conv_igemm_kernel<R, S, RCH, STRIDE, DIL, CB, MI, NI, WM, WN, TH, TW>), grid,
+                       dim3(256), 0, st, a);
+  }
   return 0;
 }
 
