@@ -2,50 +2,81 @@
 //
 //   dW[k][c][r][s] = sum_{n,p,q} dY[n,k,p,q] * X[n,c,p*stride+r-pad,q*stride+s-pad]
 //
-// GEMM view: M = K (64 per workgroup), N = C (64 per workgroup) x filter taps,
-// reduction = output pixels.  A workgroup owns a 64x64x(RB*S taps) slab of dW
-// and walks a range of pixel tiles (split-K over pixels across workgroups);
-// each tile stages dY[64][TH*TW] and the input patch X[64][(TH-1)*st+RB][(TW-1)*st+S]
-// in LDS once and feeds every tap's MFMA from the SAME staged patch (shifted
-// reads), so X is read from HBM/L2 once per tile, not once per tap.  Wave
-// layout 2x2: each wave accumulates 32(k) x 32(c) x taps in registers
-// (v_mfma_f32_32x32x2_f32, two pixels per instruction).
-// Partial slabs of different pixel splits are written to a workspace and summed
-// by a second small kernel (deterministic; no atomics).
+// GEMM view: M = K, N = C x taps, reduction = output pixels.  The MFMA wants the
+// NON-reduced index (k resp. c) across lanes, while NCHW keeps the reduced index
+// (pixels) contiguous -- so the operands are first re-laid out channel-minor
+// ("NHWC", channels zero-padded to a multiple of 64) by a small transpose kernel
+// (one extra read+write of X and dY, ~1-2 % of the GEMM time).  In that layout
+//   * the dY slab of a pixel-row tile is [TW pixels][64 k]   (256 B per pixel)
+//   * the input patch is              [RB rows][PW cols][64 c]
+// both lane-linear, so they are DMA'd straight into LDS with global_load_lds (no
+// VGPR staging, zeros for halo/out-of-range lanes come from a zero page), every
+// MFMA operand read is a conflict-free ds_read_b32 (lanes = consecutive channels),
+// and every tap's MFMA reuses the SAME staged patch (shifted reads).
+// Workgroup: 64(k) x 64(c) x (RB*S taps) slab of dW, 4 waves as 2x2, each wave
+// 32x32xtaps accumulators (v_mfma_f32_32x32x2_f32, two pixels per instruction);
+// LDS double-buffered, one barrier per pixel tile.  Split-K over pixel tiles across
+// workgroups; partial slabs are summed by a second kernel (deterministic, no atomics).
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+
+// ---- NCHW -> N,HW,Cp (channels minor, zero padded) ---------------------------------
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                           int C, int HW, int Cp) {
+  __shared__ float tile[32][33];
+  const int n = blockIdx.z;
+  const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  const float* s = src + (size_t)n * C * HW;
+  float* d = dst + (size_t)n * HW * Cp;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = c0 + ty + j * 8, p = p0 + tx;
+    tile[ty + j * 8][tx] = (c < C && p < HW) ? s[(size_t)c * HW + p] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int p = p0 + ty + j * 8, c = c0 + tx;
+    if (p < HW && c < Cp) d[(size_t)p * Cp + c] = tile[tx][ty + j * 8];
+  }
+}
 
 struct WgradArgs {
-  const float* x;
-  const float* dy;
+  const float* xt;    // [N][H][W][Cp]
+  const float* dyt;   // [N][P][Q][Kp]
+  const float* zeros; // >= 256 B of zeros
   float* out;
   int N, C, H, W, K, P, Q, pad;
-  int tiles_p, tiles_q, total_tiles, tiles_per_split;
+  int Cp, Kp;
+  int tiles_q, total_tiles, tiles_per_split;
   int c_tiles;
   long long split_stride;
 };
 
-template <int R, int S, int RB, int STRIDE, int TH, int TW>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
-  constexpr int PT = TH * TW;
-  constexpr int PTP = PT + 1;
+template <int R, int S, int RB, int STRIDE, int TW>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
   constexpr int T = RB * S;
-  constexpr int PH = (TH - 1) * STRIDE + RB;
   constexpr int PW = (TW - 1) * STRIDE + S;
-  constexpr int PLANE = (PH * PW) | 1;
-  static_assert(TW % 2 == 0, "pixel pairs must not straddle rows");
-  __shared__ __attribute__((aligned(16))) float smem[64 * PTP + 64 * PLANE];
-  float* dYs = smem;
-  float* Xs = smem + 64 * PTP;
+  constexpr int NPOS = RB * PW;                       // patch positions (each 64 channels)
+  constexpr int X_INSTR = (NPOS + 3) / 4;             // 4 positions (1 KiB) per wave instruction
+  constexpr int DY_INSTR = TW / 4;
+  constexpr int XS_SZ = X_INSTR * 4 * 64, DYS_SZ = TW * 64;
+  constexpr int X_PER_WAVE = (X_INSTR + 3) / 4, DY_PER_WAVE = (DY_INSTR + 3) / 4;
+  static_assert(TW % 4 == 0, "tile width");
+  __shared__ __attribute__((aligned(16))) float smem[2 * (XS_SZ + DYS_SZ)];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int wm = wave >> 1, wc = wave & 1;
-  const int ko0 = (blockIdx.y / a.c_tiles) * 64;
-  const int c0 = (blockIdx.y % a.c_tiles) * 64;
+  const int ko0 = (blockIdx.x / a.c_tiles) * 64;
+  const int c0 = (blockIdx.x % a.c_tiles) * 64;
   const int r0 = blockIdx.z * RB;
-  const int split = blockIdx.x;
+  const int split = blockIdx.y;
+  const int sub = lane >> 4, col4 = (lane & 15) * 4;   // position within an instruction, channel quad
 
   f32x16 acc[T];
 #pragma unroll
@@ -53,54 +84,67 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  const float* a_base = dYs + (wm * 32 + l31) * PTP + half;
-  const float* b_base = Xs + (wc * 32 + l31) * PLANE + half * STRIDE;
-
   const int tile_beg = split * a.tiles_per_split;
   const int tile_end = min(tile_beg + a.tiles_per_split, a.total_tiles);
+
+#define FCD_WG_STAGE(TILE, BUF)                                                                       \
+  {                                                                                                   \
+    int tt = (TILE);                                                                                  \
+    const int tq = tt % a.tiles_q;                                                                    \
+    tt /= a.tiles_q;                                                                                  \
+    const int p = tt % a.P, n = tt / a.P;                                                             \
+    const int q0 = tq * TW;                                                                           \
+    float* xs = smem + (BUF) * (XS_SZ + DYS_SZ);                                                      \
+    float* dys = xs + XS_SZ;                                                                          \
+    _Pragma("unroll") for (int j = 0; j < DY_PER_WAVE; ++j) {                                         \
+      const int ins = wave + 4 * j;                                                                   \
+      if (DY_INSTR % 4 == 0 || ins < DY_INSTR) {                                                      \
+        const int q = q0 + ins * 4 + sub;                                                             \
+        const float* src = (q < a.Q) ? a.dyt + (((size_t)n * a.P + p) * a.Q + q) * a.Kp + ko0 + col4  \
+                                     : a.zeros + col4;                                                \
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(dys + ins * 256), 16, 0, 0); \
+      }                                                                                               \
+    }                                                                                                 \
+    const int ih0 = p * STRIDE - a.pad + r0, iw0 = q0 * STRIDE - a.pad;                               \
+    _Pragma("unroll") for (int j = 0; j < X_PER_WAVE; ++j) {                                          \
+      const int ins = wave + 4 * j;                                                                   \
+      if (X_INSTR % 4 == 0 || ins < X_INSTR) {                                                        \
+        const int pos = ins * 4 + sub;                                                                \
+        const int ph = pos / PW, pw = pos % PW;                                                       \
+        const int ih = ih0 + ph, iw = iw0 + pw;                                                       \
+        const bool ok = pos < NPOS && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;                     \
+        const float* src = ok ? a.xt + (((size_t)n * a.H + ih) * a.W + iw) * a.Cp + c0 + col4         \
+                              : a.zeros + col4;                                                       \
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(xs + ins * 256), 16, 0, 0);  \
+      }                                                                                               \
+    }                                                                                                 \
+  }
+
+  if (tile_beg < tile_end) {
+    FCD_WG_STAGE(tile_beg, 0)
+  }
+  __syncthreads();
+  int buf = 0;
   for (int tile = tile_beg; tile < tile_end; ++tile) {
-    int tt = tile;
-    const int tq = tt % a.tiles_q;
-    tt /= a.tiles_q;
-    const int tp = tt % a.tiles_p;
-    const int n = tt / a.tiles_p;
-    const int p0 = tp * TH, q0 = tq * TW;
-    __syncthreads();  // previous tile's reads done
-    // stage dY tile
-    for (int idx = tid; idx < 64 * PT; idx += 256) {
-      const int ko = idx / PT, pix = idx % PT;
-      const int p = p0 + pix / TW, q = q0 + pix % TW;
-      float v = 0.f;
-      if (ko0 + ko < a.K && p < a.P && q < a.Q) v = a.dy[(((size_t)n * a.K + ko0 + ko) * a.P + p) * a.Q + q];
-      dYs[ko * PTP + pix] = v;
-    }
-    // stage input patch
-    const int ih0 = p0 * STRIDE - a.pad + r0, iw0 = q0 * STRIDE - a.pad;
-    for (int idx = tid; idx < 64 * PH * PW; idx += 256) {
-      const int c = idx / (PH * PW), rem = idx % (PH * PW);
-      const int ph = rem / PW, pw = rem % PW;
-      const int ih = ih0 + ph, iw = iw0 + pw;
-      float v = 0.f;
-      if (c0 + c < a.C && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W)
-        v = a.x[(((size_t)n * a.C + c0 + c) * a.H + ih) * a.W + iw];
-      Xs[c * PLANE + ph * PW + pw] = v;
-    }
-    __syncthreads();
+    if (tile + 1 < tile_end) FCD_WG_STAGE(tile + 1, buf ^ 1)
+    const float* xs = smem + buf * (XS_SZ + DYS_SZ);
+    const float* a_base = xs + XS_SZ + half * 64 + wm * 32 + l31;
+    const float* b_base = xs + half * STRIDE * 64 + wc * 32 + l31;
 #pragma unroll
-    for (int t2 = 0; t2 < PT / 2; ++t2) {
-      constexpr int dummy = 0;
-      (void)dummy;
-      const int row = (2 * t2) / TW, col = (2 * t2) % TW;
-      const float av = a_base[2 * t2];
+    for (int t2 = 0; t2 < TW / 2; ++t2) {
+      const float av = a_base[(2 * t2) * 64];
 #pragma unroll
       for (int rl = 0; rl < RB; ++rl)
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-          const float bv = b_base[(row * STRIDE + rl) * PW + col * STRIDE + s];
+          const float bv = b_base[(rl * PW + (2 * t2) * STRIDE + s) * 64];
           acc[rl * S + s] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[rl * S + s], 0, 0, 0);
         }
     }
+    __syncthreads();
+    buf ^= 1;
   }
+#undef FCD_WG_STAGE
 
   float* out = a.out + (size_t)split * a.split_stride;
   const int c = c0 + wc * 32 + l31;
@@ -151,24 +195,26 @@ extern "C" int fcd_channel_sum(const float* x, float* out, int N, int C, int HW,
 
 // ---------------------------------------------------------------------------
 struct WgradPlan {
-  int TH, TW, RB, tiles_p, tiles_q, total_tiles, tiles_per_split, splits, k_tiles, c_tiles, r_groups;
+  int TW, RB, tiles_q, total_tiles, tiles_per_split, splits, k_tiles, c_tiles, r_groups, Cp, Kp;
+  size_t xt_bytes, dyt_bytes, part_bytes, zero_bytes;
 };
 
 static bool wgrad_plan(const fcd_conv_desc* d, WgradPlan* pl) {
   const int R = d->R, S = d->S, st = d->stride;
-  if (R == 3 && S == 3 && st == 1) { pl->TH = 2; pl->TW = 32; pl->RB = 3; }
-  else if (R == 3 && S == 3 && st == 2) { pl->TH = 2; pl->TW = 16; pl->RB = 3; }
-  else if (R == 9 && S == 9 && st == 1) { pl->TH = 2; pl->TW = 32; pl->RB = 1; }
-  else if (R == 1 && S == 1 && st == 1) { pl->TH = 2; pl->TW = 32; pl->RB = 1; }
-  else if (R == 2 && S == 2 && st == 2) { pl->TH = 2; pl->TW = 16; pl->RB = 2; }
+  if (R == 3 && S == 3 && st == 1) { pl->TW = 32; pl->RB = 3; }
+  else if (R == 3 && S == 3 && st == 2) { pl->TW = 16; pl->RB = 3; }
+  else if (R == 9 && S == 9 && st == 1) { pl->TW = 32; pl->RB = 1; }
+  else if (R == 1 && S == 1 && st == 1) { pl->TW = 32; pl->RB = 1; }
+  else if (R == 2 && S == 2 && st == 2) { pl->TW = 16; pl->RB = 2; }
   else return false;
-  if (d->Q <= 16 && pl->TW == 32) { pl->TH = 4; pl->TW = 16; }
-  pl->tiles_p = cdiv(d->P, pl->TH);
+  if (d->Q <= 16) pl->TW = 16;
   pl->tiles_q = cdiv(d->Q, pl->TW);
-  pl->total_tiles = d->N * pl->tiles_p * pl->tiles_q;
+  pl->total_tiles = d->N * d->P * pl->tiles_q;
   pl->k_tiles = cdiv(d->K, 64);
   pl->c_tiles = cdiv(d->C, 64);
   pl->r_groups = R / pl->RB;
+  pl->Cp = pl->c_tiles * 64;
+  pl->Kp = pl->k_tiles * 64;
   const int base = pl->k_tiles * pl->c_tiles * pl->r_groups;
   int splits = cdiv(1024, base);
   const long long dw_bytes = 4LL * d->K * d->C * R * S;
@@ -178,20 +224,23 @@ static bool wgrad_plan(const fcd_conv_desc* d, WgradPlan* pl) {
   if (splits < 1) splits = 1;
   pl->tiles_per_split = cdiv(pl->total_tiles, splits);
   pl->splits = cdiv(pl->total_tiles, pl->tiles_per_split);
+  pl->xt_bytes = (size_t)d->N * d->H * d->W * pl->Cp * sizeof(float);
+  pl->dyt_bytes = (size_t)d->N * d->P * d->Q * pl->Kp * sizeof(float);
+  pl->part_bytes = pl->splits > 1 ? (size_t)pl->splits * dw_bytes : 0;
+  pl->zero_bytes = 1024;
   return true;
 }
 
 extern "C" size_t fcd_conv2d_bwd_weight_ws_bytes(const fcd_conv_desc* d) {
   WgradPlan pl;
   if (!d || !wgrad_plan(d, &pl)) return 0;
-  if (pl.splits <= 1) return 0;
-  return (size_t)pl.splits * d->K * d->C * d->R * d->S * sizeof(float);
+  return pl.zero_bytes + pl.xt_bytes + pl.dyt_bytes + pl.part_bytes;
 }
 
-template <int R, int S, int RB, int STRIDE, int TH, int TW>
+template <int R, int S, int RB, int STRIDE, int TW>
 static void launch_wgrad(const WgradArgs& a, const WgradPlan& pl, hipStream_t st) {
-  dim3 grid((unsigned)pl.splits, (unsigned)(pl.k_tiles * pl.c_tiles), (unsigned)pl.r_groups);
-  hipLaunchKernelGGL((conv_wgrad_kernel<R, S, RB, STRIDE, TH, TW>), grid, dim3(256), 0, st, a);
+  dim3 grid((unsigned)(pl.k_tiles * pl.c_tiles), (unsigned)pl.splits, (unsigned)pl.r_groups);
+  hipLaunchKernelGGL((conv_wgrad_kernel<R, S, RB, STRIDE, TW>), grid, dim3(256), 0, st, a);
 }
 
 extern "C" int fcd_conv2d_bwd_weight(const fcd_conv_desc* d, const float* x, const float* dy, float* dw,
@@ -201,41 +250,59 @@ extern "C" int fcd_conv2d_bwd_weight(const fcd_conv_desc* d, const float* x, con
   FCD_CHECK_ARG(wgrad_plan(d, &pl), "fcd_conv2d_bwd_weight: unsupported filter %dx%d stride %d", d->R, d->S,
                 d->stride);
   const size_t need = fcd_conv2d_bwd_weight_ws_bytes(d);
-  if (need > 0 && (ws == nullptr || ws_bytes < need)) {
+  if (ws == nullptr || ws_bytes < need) {
     fcd_set_error("fcd_conv2d_bwd_weight: workspace %zu < %zu bytes", ws_bytes, need);
     return FCD_ERR_WORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
-  WgradArgs a;
-  memset(&a, 0, sizeof(a));
-  a.x = x; a.dy = dy;
-  a.out = pl.splits > 1 ? (float*)ws : dw;
-  a.N = d->N; a.C = d->C; a.H = d->H; a.W = d->W; a.K = d->K; a.P = d->P; a.Q = d->Q; a.pad = d->pad;
-  a.tiles_p = pl.tiles_p; a.tiles_q = pl.tiles_q; a.total_tiles = pl.total_tiles;
-  a.tiles_per_split = pl.tiles_per_split; a.c_tiles = pl.c_tiles;
-  a.split_stride = (long long)d->K * d->C * d->R * d->S;
+  char* wsp = (char*)ws;
+  float* zeros = (float*)wsp; wsp += pl.zero_bytes;
+  float* xt = (float*)wsp;    wsp += pl.xt_bytes;
+  float* dyt = (float*)wsp;   wsp += pl.dyt_bytes;
+  float* part = (float*)wsp;
   const double flops = 2.0 * d->N * d->K * (double)d->P * d->Q * d->C * d->R * d->S;
   const double bytes = 4.0 * ((double)d->N * d->C * d->H * d->W + (double)d->N * d->K * d->P * d->Q +
                               (double)d->K * d->C * d->R * d->S);
   FcdProfScope prof(FCD_K_CONV_WGRAD, st, flops, bytes);
+  if (hipMemsetAsync(zeros, 0, pl.zero_bytes, st) != hipSuccess) {
+    fcd_set_error("fcd_conv2d_bwd_weight: memset failed");
+    return FCD_ERR_LAUNCH;
+  }
+  {
+    const int HW = d->H * d->W;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(cdiv(HW, 32), pl.Cp / 32, d->N), dim3(256), 0, st, x, xt, d->C, HW,
+                       pl.Cp);
+    const int PQ = d->P * d->Q;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(cdiv(PQ, 32), pl.Kp / 32, d->N), dim3(256), 0, st, dy, dyt, d->K, PQ,
+                       pl.Kp);
+  }
+  WgradArgs a;
+  memset(&a, 0, sizeof(a));
+  a.xt = xt; a.dyt = dyt; a.zeros = zeros;
+  a.out = pl.splits > 1 ? part : dw;
+  a.N = d->N; a.C = d->C; a.H = d->H; a.W = d->W; a.K = d->K; a.P = d->P; a.Q = d->Q; a.pad = d->pad;
+  a.Cp = pl.Cp; a.Kp = pl.Kp;
+  a.tiles_q = pl.tiles_q; a.total_tiles = pl.total_tiles;
+  a.tiles_per_split = pl.tiles_per_split; a.c_tiles = pl.c_tiles;
+  a.split_stride = (long long)d->K * d->C * d->R * d->S;
   const int R = d->R, S = d->S, sd = d->stride;
-  const bool narrow = (pl.TW == 16 && pl.TH == 4);
+  const bool narrow = pl.TW == 16;
   if (R == 3 && S == 3 && sd == 1) {
-    if (narrow) launch_wgrad<3, 3, 3, 1, 4, 16>(a, pl, st); else launch_wgrad<3, 3, 3, 1, 2, 32>(a, pl, st);
+    if (narrow) launch_wgrad<3, 3, 3, 1, 16>(a, pl, st); else launch_wgrad<3, 3, 3, 1, 32>(a, pl, st);
   } else if (R == 3 && S == 3 && sd == 2) {
-    launch_wgrad<3, 3, 3, 2, 2, 16>(a, pl, st);
+    launch_wgrad<3, 3, 3, 2, 16>(a, pl, st);
   } else if (R == 9 && S == 9) {
-    if (narrow) launch_wgrad<9, 9, 1, 1, 4, 16>(a, pl, st); else launch_wgrad<9, 9, 1, 1, 2, 32>(a, pl, st);
+    if (narrow) launch_wgrad<9, 9, 1, 1, 16>(a, pl, st); else launch_wgrad<9, 9, 1, 1, 32>(a, pl, st);
   } else if (R == 1 && S == 1) {
-    if (narrow) launch_wgrad<1, 1, 1, 1, 4, 16>(a, pl, st); else launch_wgrad<1, 1, 1, 1, 2, 32>(a, pl, st);
+    if (narrow) launch_wgrad<1, 1, 1, 1, 16>(a, pl, st); else launch_wgrad<1, 1, 1, 1, 32>(a, pl, st);
   } else {
-    launch_wgrad<2, 2, 2, 2, 2, 16>(a, pl, st);
+    launch_wgrad<2, 2, 2, 2, 16>(a, pl, st);
   }
   FCD_LAUNCH_CHECK("conv2d_bwd_weight");
   if (pl.splits > 1) {
     const long long n = a.split_stride;
     const int grid = (int)std::min<long long>(cdiv64(n, 256), 2048);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, (const float*)ws, dw, n, pl.splits);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, (const float*)part, dw, n, pl.splits);
     FCD_LAUNCH_CHECK("wgrad_reduce");
   }
   return FCD_OK;
