@@ -24,8 +24,8 @@ class _FlatOptimizer:
         if not self.params:
             raise ValueError('optimizer got an empty parameter list')
         dev = self.params[0].device
-        if dev.type != 'cuda':
-            raise ops._lib.FcdError('fcd optimizers need parameters on a CUDA/ROCm device (call net.to(device) first)')
+        # (the flat-buffer / all-reduce host logic also works on CPU tensors -- used by the gloo
+        # tests -- but step() is a HIP kernel and refuses them)
         n = sum(p.numel() for p in self.params)
         self.flat_p = torch.empty(n, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -70,6 +70,11 @@ class _FlatOptimizer:
         else:
             self.grad_scale = 1.0
 
+    def _require_device(self):
+        if self.flat_p.device.type != 'cuda':
+            raise ops._lib.FcdError('fcd optimizers step on a CUDA/ROCm device only (call net.to(device) before '
+                                    'constructing the optimizer); there is no CPU fallback')
+
     def _after_step(self):
         self.steps += 1
         self.grad_scale = 1.0
@@ -89,6 +94,7 @@ class Adam(_FlatOptimizer):
 
     @torch.no_grad()
     def step(self):
+        self._require_device()
         ops.adam_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0],
                       self.betas[1], self.eps, self.weight_decay, self.steps + 1, self.grad_scale)
         self._after_step()
@@ -102,6 +108,7 @@ class RMSprop(_FlatOptimizer):
 
     @torch.no_grad()
     def step(self):
+        self._require_device()
         ops.rmsprop_step(self.flat_p, self.flat_g, self.square_avg, self.lr, self.alpha, self.eps,
                          self.weight_decay, self.grad_scale)
         self._after_step()
