@@ -81,15 +81,24 @@ class PerceptionLoss(nn.Module):
         """All 31 layers (the reference runs the stack to the end, Loss.py:45-49);
         returns {tap index: activation}."""
         taps = {}
-        for i, layer in enumerate(self.net):
+        layers = list(self.net)
+        i = 0
+        while i < len(layers):
+            layer = layers[i]
             if isinstance(layer, nn.Conv2d):
-                z = ops.conv2d(z, layer.weight, layer.bias, 1, 1)
+                fuse = i + 1 < len(layers) and isinstance(layers[i + 1], nn.ReLU)
+                # conv + bias + ReLU in one kernel (epilogue); the ReLU mask is re-derived from
+                # the output inside the data-gradient kernel's loader
+                z = ops.conv2d(z, layer.weight, layer.bias, 1, 1, relu=fuse)
+                if fuse:
+                    i += 1          # the ReLU entry (tapped indices are all ReLU outputs)
             elif isinstance(layer, nn.ReLU):
                 z = ops.bn_act(z, None, ops.ACT_RELU)
             else:
                 z = ops.maxpool2(z)
             if i in self.feature_layer_list:
                 taps[i] = z
+            i += 1
         return taps
 
     def forward(self, target_image, generate_image, cmask):

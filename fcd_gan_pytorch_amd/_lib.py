@@ -42,11 +42,12 @@ _SIGS = {
     'fcd_last_error_string': (c_char_p, []),
     'fcd_conv_packed_elems': (c_int64, [c_int, c_int, c_int, c_int, c_int]),
     'fcd_conv_pack_weights': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
-    'fcd_conv2d_fwd': (c_int, [POINTER(ConvDesc), P, P, P, P, P]),
-    'fcd_conv2d_bwd_data': (c_int, [POINTER(ConvDesc), P, P, P, P]),
+    'fcd_conv2d_fwd': (c_int, [POINTER(ConvDesc), P, P, P, P, c_int, P]),
+    'fcd_conv2d_bwd_data': (c_int, [POINTER(ConvDesc), P, P, P, P, P]),
     'fcd_conv2d_bwd_weight_ws_bytes': (c_size_t, [POINTER(ConvDesc)]),
-    'fcd_conv2d_bwd_weight': (c_int, [POINTER(ConvDesc), P, P, P, P, c_size_t, P]),
-    'fcd_channel_sum': (c_int, [P, P, c_int, c_int, c_int, P]),
+    'fcd_conv2d_bwd_weight': (c_int, [POINTER(ConvDesc), P, P, P, P, P, c_size_t, P]),
+    'fcd_channel_sum_ws_bytes': (c_size_t, [c_int]),
+    'fcd_channel_sum': (c_int, [P, P, P, c_int, c_int, c_int, P, c_size_t, P]),
     'fcd_bn_act_ws_bytes': (c_size_t, [c_int, c_int]),
     'fcd_bn_act_fwd': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_float, c_float, c_int,
                                P, P, c_int, P, c_float, P, c_size_t, P]),

@@ -71,46 +71,54 @@ def invalidate_packs(params):
         p.__dict__.pop('_fcd_pack', None)
 
 
+def _channel_sum(t, mask, N, C, HW):
+    out = torch.empty(C, dtype=torch.float32, device=t.device)
+    ws = _ws(lib.fcd_channel_sum_ws_bytes(C), t.device)
+    check(lib.fcd_channel_sum(_p(t), _p(mask), _p(out), N, C, HW, _p(ws), ws.numel(), _stream()), 'fcd_channel_sum')
+    return out
+
+
 class _Conv2d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad):
+    def forward(ctx, x, weight, bias, stride, pad, relu):
         x = _dev(x, 'conv input')
-        weight_c = _dev(weight, 'conv weight')
+        _dev(weight, 'conv weight')
         d = _desc(x.shape, weight.shape, stride, pad)
         y = torch.empty((d.N, d.K, d.P, d.Q), dtype=torch.float32, device=x.device)
         wp = packed_weight(weight, 0)
         b = _dev(bias, 'conv bias') if bias is not None else None
-        check(lib.fcd_conv2d_fwd(ctypes.byref(d), _p(x), _p(wp), _p(b), _p(y), _stream()), 'fcd_conv2d_fwd')
-        ctx.save_for_backward(x, weight)
-        ctx.geom = (stride, pad, bias is not None)
-        del weight_c
+        check(lib.fcd_conv2d_fwd(ctypes.byref(d), _p(x), _p(wp), _p(b), _p(y), int(relu), _stream()),
+              'fcd_conv2d_fwd')
+        # x is only needed for the weight gradient; the fused-ReLU output doubles as the backward mask
+        ctx.save_for_backward(x if weight.requires_grad else None, weight, y if relu else None)
+        ctx.geom = (stride, pad, bias is not None, tuple(x.shape))
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
-        stride, pad, has_bias = ctx.geom
+        x, weight, yrelu = ctx.saved_tensors
+        stride, pad, has_bias, xshape = ctx.geom
         dy = _dev(dy, 'conv grad')
-        d = _desc(x.shape, weight.shape, stride, pad)
+        d = _desc(xshape, weight.shape, stride, pad)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
+            dx = torch.empty(xshape, dtype=torch.float32, device=dy.device)
             wpb = packed_weight(weight, 1)
-            check(lib.fcd_conv2d_bwd_data(ctypes.byref(d), _p(dy), _p(wpb), _p(dx), _stream()), 'fcd_conv2d_bwd_data')
+            check(lib.fcd_conv2d_bwd_data(ctypes.byref(d), _p(dy), _p(yrelu), _p(wpb), _p(dx), _stream()),
+                  'fcd_conv2d_bwd_data')
         if ctx.needs_input_grad[1]:
-            dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
-            nb = lib.fcd_conv2d_bwd_weight_ws_bytes(ctypes.byref(d))
-            ws = _ws(nb, x.device)
-            check(lib.fcd_conv2d_bwd_weight(ctypes.byref(d), _p(x), _p(dy), _p(dw), _p(ws), ws.numel(), _stream()),
-                  'fcd_conv2d_bwd_weight')
+            dw = torch.empty(weight.shape, dtype=torch.float32, device=dy.device)
+            ws = _ws(lib.fcd_conv2d_bwd_weight_ws_bytes(ctypes.byref(d)), dy.device)
+            check(lib.fcd_conv2d_bwd_weight(ctypes.byref(d), _p(x), _p(dy), _p(yrelu), _p(dw), _p(ws), ws.numel(),
+                                            _stream()), 'fcd_conv2d_bwd_weight')
         if has_bias and ctx.needs_input_grad[2]:
-            db = torch.empty(d.K, dtype=torch.float32, device=x.device)
-            check(lib.fcd_channel_sum(_p(dy), _p(db), d.N, d.K, d.P * d.Q, _stream()), 'fcd_channel_sum')
-        return dx, dw, db, None, None
+            db = _channel_sum(dy, yrelu, d.N, d.K, d.P * d.Q)
+        return dx, dw, db, None, None, None
 
 
-def conv2d(x, weight, bias=None, stride=1, padding=0):
-    return _Conv2d.apply(x, weight, bias, int(stride), int(padding))
+def conv2d(x, weight, bias=None, stride=1, padding=0, relu=False):
+    """conv2d (+bias) (+fused ReLU epilogue when ``relu``)."""
+    return _Conv2d.apply(x, weight, bias, int(stride), int(padding), bool(relu))
 
 
 class _ConvT2x2(torch.autograd.Function):
@@ -126,7 +134,7 @@ class _ConvT2x2(torch.autograd.Function):
         d = ConvDesc(N, Cout, 2 * h, 2 * w, Cin, 2, 2, 2, 0, h, w)
         y = torch.empty((N, Cout, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
         wpb = packed_weight(weight, 1)
-        check(lib.fcd_conv2d_bwd_data(ctypes.byref(d), _p(x), _p(wpb), _p(y), _stream()), 'convT fwd')
+        check(lib.fcd_conv2d_bwd_data(ctypes.byref(d), _p(x), None, _p(wpb), _p(y), _stream()), 'convT fwd')
         if bias is not None:
             y += bias.view(1, -1, 1, 1)
         ctx.save_for_backward(x, weight)
@@ -144,15 +152,14 @@ class _ConvT2x2(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             wp = packed_weight(weight, 0)
-            check(lib.fcd_conv2d_fwd(ctypes.byref(d), _p(dy), _p(wp), None, _p(dx), _stream()), 'convT bwd data')
+            check(lib.fcd_conv2d_fwd(ctypes.byref(d), _p(dy), _p(wp), None, _p(dx), 0, _stream()), 'convT bwd data')
         if ctx.needs_input_grad[1]:
             dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
             ws = _ws(lib.fcd_conv2d_bwd_weight_ws_bytes(ctypes.byref(d)), x.device)
-            check(lib.fcd_conv2d_bwd_weight(ctypes.byref(d), _p(dy), _p(x), _p(dw), _p(ws), ws.numel(), _stream()),
+            check(lib.fcd_conv2d_bwd_weight(ctypes.byref(d), _p(dy), _p(x), None, _p(dw), _p(ws), ws.numel(), _stream()),
                   'convT bwd weight')
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = torch.empty(Cout, dtype=torch.float32, device=x.device)
-            check(lib.fcd_channel_sum(_p(dy), _p(db), N, Cout, 4 * h * w, _stream()), 'fcd_channel_sum')
+            db = _channel_sum(dy, None, N, Cout, 4 * h * w)
         return dx, dw, db
 
 

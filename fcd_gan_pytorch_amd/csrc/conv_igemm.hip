@@ -23,7 +23,9 @@ struct ConvArgs {
   const float* x;
   const float* wp;
   const float* bias;
+  const float* mask;  // optional, same shape as x: x is read as x * (mask > 0)  (ReLU backward fused in)
   float* y;
+  int relu;           // epilogue: y = max(y, 0)
   int N, C, H, W;   // stored input tensor
   int K, Kpad;      // real / packed output channels
   int P, Q;         // output extent
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_kernel(ConvArgs a) {
 
   // ---- staging registers and their (loop-invariant) addresses, computed once --------
   float4 wr[W_PER_T];
-  float xr[X_PER_T];
+  float xr[X_PER_T], mr[X_PER_T];
   int w_goff[W_PER_T];      // packed-weight offset of this thread's i-th float4 within a step slab
   int x_goff[X_PER_T];      // input offset of this thread's i-th patch element within a channel chunk
   int x_loff[X_PER_T];      // ... and its LDS slot
@@ -117,6 +119,7 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_kernel(ConvArgs a) {
     x_loff[i] = cc * PLANE + ph * PWP + pw;
   }
   const float* xin = a.x + (size_t)n * a.C * a.H * a.W;
+  const float* min_ = a.mask ? a.mask + (size_t)n * a.C * a.H * a.W : nullptr;
   const int chunk_elems = CB * a.H * a.W;
 
 #define FCD_LOAD_W(CCHUNK, RR)                                                                        \
@@ -137,15 +140,19 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_kernel(ConvArgs a) {
     const float* xsrc = xin + (size_t)(CCHUNK) * chunk_elems;                                         \
     const int cleft = a.C - (CCHUNK) * CB;                                                            \
     _Pragma("unroll") for (int i = 0; i < X_PER_T; ++i) {                                             \
-      float v = 0.f;                                                                                  \
-      if (x_cc[i] >= 0 && x_cc[i] < cleft) v = xsrc[x_goff[i]];                                       \
+      float v = 0.f, m = 1.f;                                                                         \
+      if (x_cc[i] >= 0 && x_cc[i] < cleft) {                                                          \
+        v = xsrc[x_goff[i]];                                                                          \
+        if (min_) m = min_[(size_t)(CCHUNK) * chunk_elems + x_goff[i]];                               \
+      }                                                                                               \
       xr[i] = v;                                                                                      \
+      mr[i] = m;                                                                                      \
     }                                                                                                 \
   }
 #define FCD_STORE_X()                                                                                 \
   {                                                                                                   \
     _Pragma("unroll") for (int i = 0; i < X_PER_T; ++i) {                                             \
-      if (X_ELEMS % 256 == 0 || tid + i * 256 < X_ELEMS) Xs[x_loff[i]] = xr[i];                      \
+      if (X_ELEMS % 256 == 0 || tid + i * 256 < X_ELEMS) Xs[x_loff[i]] = (mr[i] > 0.f) ? xr[i] : 0.f; \
     }                                                                                                 \
   }
 
@@ -213,6 +220,7 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_kernel(ConvArgs a) {
         if (ko < a.K) {
           float v = acc[mi][ni][r];
           if (a.bias) v += a.bias[ko];
+          if (a.relu) v = v > 0.f ? v : 0.f;
           a.y[(((size_t)n * a.K + ko) * a.P + p) * a.Q + q] = v;
         }
       }
@@ -291,7 +299,7 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_glds_kernel(ConvArgs a) {
     const int cc = row / (RCH * S), rem = row % (RCH * S);
     w_goff[j] = (cc * (R * S) + rem) * a.Kpad + ko0 + col;
   }
-  float xr[X_PER_T];
+  float xr[X_PER_T], mr[X_PER_T];
   int x_goff[X_PER_T], x_loff[X_PER_T], x_cc[X_PER_T];
   const int ih0 = p0 * STRIDE - a.pad, iw0 = q0 * STRIDE - a.pad;
 #pragma unroll
@@ -312,6 +320,7 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_glds_kernel(ConvArgs a) {
     x_loff[i] = cc * PLANE + ph * PWP + pw;
   }
   const float* xin = a.x + (size_t)n * a.C * a.H * a.W;
+  const float* min_ = a.mask ? a.mask + (size_t)n * a.C * a.H * a.W : nullptr;
   const int chunk_elems = CB * a.H * a.W;
 
 #define FCD_GLDS_W(CCHUNK, RR, BUF)                                                                   \
@@ -328,15 +337,21 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_glds_kernel(ConvArgs a) {
     const float* xsrc = xin + (size_t)(CCHUNK) * chunk_elems;                                         \
     const int cleft = a.C - (CCHUNK) * CB;                                                            \
     _Pragma("unroll") for (int i = 0; i < X_PER_T; ++i) {                                             \
-      float v = 0.f;                                                                                  \
-      if (x_cc[i] >= 0 && x_cc[i] < cleft) v = xsrc[x_goff[i]];                                       \
+      float v = 0.f, m = 1.f;                                                                         \
+      if (x_cc[i] >= 0 && x_cc[i] < cleft) {                                                          \
+        v = xsrc[x_goff[i]];                                                                          \
+        if (min_) m = min_[(size_t)(CCHUNK) * chunk_elems + x_goff[i]];                               \
+      }                                                                                               \
       xr[i] = v;                                                                                      \
+      mr[i] = m;                                                                                      \
     }                                                                                                 \
   }
+  /* the ReLU-mask select is applied HERE (after the MFMA block), so neither load is waited for early */ \
 #define FCD_STORE_X2(BUF)                                                                             \
   {                                                                                                   \
     _Pragma("unroll") for (int i = 0; i < X_PER_T; ++i) {                                             \
-      if (X_ELEMS % 256 == 0 || tid + i * 256 < X_ELEMS) smem[2 * WS_SZ + (BUF) * XS_SZ + x_loff[i]] = xr[i]; \
+      if (X_ELEMS % 256 == 0 || tid + i * 256 < X_ELEMS)                                              \
+        smem[2 * WS_SZ + (BUF) * XS_SZ + x_loff[i]] = (mr[i] > 0.f) ? xr[i] : 0.f;                    \
     }                                                                                                 \
   }
 
@@ -398,6 +413,7 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_glds_kernel(ConvArgs a) {
         if (ko < a.K) {
           float v = acc[mi][ni][r];
           if (a.bias) v += a.bias[ko];
+          if (a.relu) v = v > 0.f ? v : 0.f;
           a.y[(((size_t)n * a.K + ko) * a.P + p) * a.Q + q] = v;
         }
       }
@@ -535,13 +551,13 @@ static int check_desc(const fcd_conv_desc* d, const char* who) {
 }
 
 extern "C" int fcd_conv2d_fwd(const fcd_conv_desc* d, const float* x, const float* wp, const float* bias,
-                              float* y, void* stream) {
+                              float* y, int fuse_relu, void* stream) {
   int rc = check_desc(d, "fcd_conv2d_fwd");
   if (rc) return rc;
   FCD_CHECK_ARG(x && wp && y, "fcd_conv2d_fwd: null pointer");
   ConvArgs a;
   memset(&a, 0, sizeof(a));
-  a.x = x; a.wp = wp; a.bias = bias; a.y = y;
+  a.x = x; a.wp = wp; a.bias = bias; a.y = y; a.relu = fuse_relu ? 1 : 0;
   a.N = d->N; a.C = d->C; a.H = d->H; a.W = d->W;
   a.K = d->K; a.Kpad = round_up(d->K, 128);
   a.P = d->P; a.Q = d->Q; a.pad = d->pad;
@@ -555,15 +571,15 @@ extern "C" int fcd_conv2d_fwd(const fcd_conv_desc* d, const float* x, const floa
   return FCD_OK;
 }
 
-extern "C" int fcd_conv2d_bwd_data(const fcd_conv_desc* d, const float* dy, const float* wp_bwd, float* dx,
-                                   void* stream) {
+extern "C" int fcd_conv2d_bwd_data(const fcd_conv_desc* d, const float* dy, const float* relu_out,
+                                   const float* wp_bwd, float* dx, void* stream) {
   int rc = check_desc(d, "fcd_conv2d_bwd_data");
   if (rc) return rc;
   FCD_CHECK_ARG(dy && wp_bwd && dx, "fcd_conv2d_bwd_data: null pointer");
   FCD_CHECK_ARG(d->R - 1 - d->pad >= 0, "fcd_conv2d_bwd_data: pad > R-1 unsupported");
   ConvArgs a;
   memset(&a, 0, sizeof(a));
-  a.x = dy; a.wp = wp_bwd; a.bias = nullptr; a.y = dx;
+  a.x = dy; a.wp = wp_bwd; a.bias = nullptr; a.y = dx; a.mask = relu_out;
   a.N = d->N; a.C = d->K; a.H = d->P; a.W = d->Q;     // "input" of the transposed conv = dy
   a.K = d->C; a.Kpad = round_up(d->C, 128);
   a.P = d->H; a.Q = d->W; a.pad = d->R - 1 - d->pad;

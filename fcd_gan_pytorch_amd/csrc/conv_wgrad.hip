@@ -24,7 +24,8 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 
 // ---- NCHW -> N,HW,Cp (channels minor, zero padded) ---------------------------------
-__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst,
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src,
+                                                           const float* __restrict__ mask, float* __restrict__ dst,
                                                            int C, int HW, int Cp) {
   __shared__ float tile[32][33];
   const int n = blockIdx.z;
@@ -35,7 +36,12 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int c = c0 + ty + j * 8, p = p0 + tx;
-    tile[ty + j * 8][tx] = (c < C && p < HW) ? s[(size_t)c * HW + p] : 0.f;
+    float v = 0.f;
+    if (c < C && p < HW) {
+      v = s[(size_t)c * HW + p];
+      if (mask && !(mask[(size_t)n * C * HW + (size_t)c * HW + p] > 0.f)) v = 0.f;
+    }
+    tile[ty + j * 8][tx] = v;
   }
   __syncthreads();
 #pragma unroll
@@ -171,24 +177,56 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __res
   }
 }
 
-__global__ void channel_sum_kernel(const float* __restrict__ x, float* __restrict__ out, int N, int C,
-                                   int HW) {
+// out[c] = sum_{n,i} x[n,c,i] (* [mask > 0]); grid (C, N-splits): per-block partial via fp64 atomics-free
+// two-stage reduce (partials in ws, finalized by the last kernel)
+__global__ __launch_bounds__(256) void channel_sum_part_kernel(const float* __restrict__ x,
+                                                               const float* __restrict__ mask,
+                                                               double* __restrict__ part, int N, int C, int HW,
+                                                               int nsplit) {
   __shared__ double red[16];
-  const int c = blockIdx.x;
+  const int c = blockIdx.x, sp = blockIdx.y;
+  const long long total = (long long)N * HW;
+  const long long chunk = (total + nsplit - 1) / nsplit;
+  const long long beg = sp * chunk, end = min(beg + chunk, total);
   double s = 0.0;
-  for (int n = 0; n < N; ++n) {
-    const float* p = x + ((size_t)n * C + c) * HW;
-    for (int i = threadIdx.x; i < HW; i += blockDim.x) s += (double)p[i];
+  for (long long e = beg + threadIdx.x; e < end; e += 256) {
+    const int n = (int)(e / HW), i = (int)(e % HW);
+    const size_t off = ((size_t)n * C + c) * HW + i;
+    float v = x[off];
+    if (mask && !(mask[off] > 0.f)) v = 0.f;
+    s += (double)v;
   }
   s = block_sum_d(s, red);
-  if (threadIdx.x == 0) out[c] = (float)s;
+  if (threadIdx.x == 0) part[(size_t)c * nsplit + sp] = s;
 }
 
-extern "C" int fcd_channel_sum(const float* x, float* out, int N, int C, int HW, void* stream) {
+__global__ void channel_sum_fin_kernel(const double* __restrict__ part, float* __restrict__ out, int C, int nsplit) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int i = 0; i < nsplit; ++i) s += part[(size_t)c * nsplit + i];
+  out[c] = (float)s;
+}
+
+#define CS_MAX_SPLIT 64
+extern "C" size_t fcd_channel_sum_ws_bytes(int C) { return (size_t)C * CS_MAX_SPLIT * sizeof(double); }
+
+extern "C" int fcd_channel_sum(const float* x, const float* relu_out, float* out, int N, int C, int HW, void* ws,
+                               size_t ws_bytes, void* stream) {
   FCD_CHECK_ARG(x && out && N > 0 && C > 0 && HW > 0, "fcd_channel_sum: bad arguments");
-  FcdProfScope prof(FCD_K_MISC, (hipStream_t)stream, 0.0, 4.0 * N * C * (double)HW);
-  hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(HW >= 1024 ? 512 : 128), 0, (hipStream_t)stream, x,
-                     out, N, C, HW);
+  if (!ws || ws_bytes < fcd_channel_sum_ws_bytes(C)) {
+    fcd_set_error("fcd_channel_sum: workspace too small");
+    return FCD_ERR_WORKSPACE;
+  }
+  int nsplit = cdiv(1024, C);
+  const long long maxs = std::max<long long>(1, (long long)N * HW / 1024);
+  if (nsplit > maxs) nsplit = (int)maxs;
+  if (nsplit > CS_MAX_SPLIT) nsplit = CS_MAX_SPLIT;
+  hipStream_t st = (hipStream_t)stream;
+  FcdProfScope prof(FCD_K_MISC, st, 0.0, 4.0 * N * C * (double)HW);
+  hipLaunchKernelGGL(channel_sum_part_kernel, dim3(C, nsplit), dim3(256), 0, st, x, relu_out, (double*)ws, N, C, HW,
+                     nsplit);
+  hipLaunchKernelGGL(channel_sum_fin_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, (const double*)ws, out, C, nsplit);
   FCD_LAUNCH_CHECK("channel_sum");
   return FCD_OK;
 }
@@ -243,8 +281,8 @@ static void launch_wgrad(const WgradArgs& a, const WgradPlan& pl, hipStream_t st
   hipLaunchKernelGGL((conv_wgrad_kernel<R, S, RB, STRIDE, TW>), grid, dim3(256), 0, st, a);
 }
 
-extern "C" int fcd_conv2d_bwd_weight(const fcd_conv_desc* d, const float* x, const float* dy, float* dw,
-                                     void* ws, size_t ws_bytes, void* stream) {
+extern "C" int fcd_conv2d_bwd_weight(const fcd_conv_desc* d, const float* x, const float* dy, const float* relu_out,
+                                     float* dw, void* ws, size_t ws_bytes, void* stream) {
   FCD_CHECK_ARG(d && x && dy && dw, "fcd_conv2d_bwd_weight: null pointer");
   WgradPlan pl;
   FCD_CHECK_ARG(wgrad_plan(d, &pl), "fcd_conv2d_bwd_weight: unsupported filter %dx%d stride %d", d->R, d->S,
@@ -270,11 +308,11 @@ extern "C" int fcd_conv2d_bwd_weight(const fcd_conv_desc* d, const float* x, con
   }
   {
     const int HW = d->H * d->W;
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(cdiv(HW, 32), pl.Cp / 32, d->N), dim3(256), 0, st, x, xt, d->C, HW,
-                       pl.Cp);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(cdiv(HW, 32), pl.Cp / 32, d->N), dim3(256), 0, st, x,
+                       (const float*)nullptr, xt, d->C, HW, pl.Cp);
     const int PQ = d->P * d->Q;
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(cdiv(PQ, 32), pl.Kp / 32, d->N), dim3(256), 0, st, dy, dyt, d->K, PQ,
-                       pl.Kp);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(cdiv(PQ, 32), pl.Kp / 32, d->N), dim3(256), 0, st, dy, relu_out, dyt, d->K,
+                       PQ, pl.Kp);
   }
   WgradArgs a;
   memset(&a, 0, sizeof(a));

@@ -60,20 +60,24 @@ typedef struct fcd_conv_desc {
 int64_t fcd_conv_packed_elems(int K, int C, int R, int S, int mode);
 int fcd_conv_pack_weights(const float* w, float* wp, int K, int C, int R, int S, int mode, void* stream);
 
-/* y = conv(x, w) + bias (bias may be NULL).  wp: mode-0 packed weights. */
+/* y = conv(x, w) + bias (bias may be NULL), then ReLU when fuse_relu != 0 (the
+ * conv+ReLU pairs of the VGG16 stack, Loss.py:25).  wp: mode-0 packed weights. */
 int fcd_conv2d_fwd(const fcd_conv_desc* d, const float* x, const float* wp, const float* bias,
-                   float* y, void* stream);
-/* dx = conv_transpose(dy, w): desc describes the FORWARD conv; wp_bwd: mode-1
- * packed weights.  dx has shape (N,C,H,W). */
-int fcd_conv2d_bwd_data(const fcd_conv_desc* d, const float* dy, const float* wp_bwd, float* dx,
-                        void* stream);
+                   float* y, int fuse_relu, void* stream);
+/* dx = conv_transpose(dy', w): desc describes the FORWARD conv; wp_bwd: mode-1
+ * packed weights.  dx has shape (N,C,H,W).  relu_out (optional, shape of dy): the
+ * fused-ReLU forward output; dy' = dy * [relu_out > 0] is formed while staging. */
+int fcd_conv2d_bwd_data(const fcd_conv_desc* d, const float* dy, const float* relu_out,
+                        const float* wp_bwd, float* dx, void* stream);
 /* dw[k][c][r][s] = sum_{n,p,q} dy[n,k,p,q] * x[n,c,p*stride+r-pad,q*stride+s-pad]
  * (plain, unpacked layout).  Needs ws of fcd_conv2d_bwd_weight_ws_bytes(). */
 size_t fcd_conv2d_bwd_weight_ws_bytes(const fcd_conv_desc* d);
-int fcd_conv2d_bwd_weight(const fcd_conv_desc* d, const float* x, const float* dy, float* dw,
-                          void* ws, size_t ws_bytes, void* stream);
-/* out[c] = sum over (n, hw) of x[n,c,hw]  -- bias gradients. */
-int fcd_channel_sum(const float* x, float* out, int N, int C, int HW, void* stream);
+int fcd_conv2d_bwd_weight(const fcd_conv_desc* d, const float* x, const float* dy,
+                          const float* relu_out, float* dw, void* ws, size_t ws_bytes, void* stream);
+/* out[c] = sum over (n, hw) of x[n,c,hw] (* [relu_out > 0] when given) -- bias gradients. */
+size_t fcd_channel_sum_ws_bytes(int C);
+int fcd_channel_sum(const float* x, const float* relu_out, float* out, int N, int C, int HW,
+                    void* ws, size_t ws_bytes, void* stream);
 
 /* ---- BatchNorm2d (+ fused activation) -------------------------------------
  * Replaces nn.BatchNorm2d + nn.ReLU / nn.LeakyReLU(0.2) / nn.PReLU chains at

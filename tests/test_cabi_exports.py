@@ -30,7 +30,7 @@ def test_argument_validation_without_gpu():
     lib = _lib.lib
     assert lib.fcd_version() >= 100
     d = _lib.ConvDesc(1, 4, 8, 8, 8, 3, 3, 1, 1, 7, 7)      # wrong P,Q
-    rc = lib.fcd_conv2d_fwd(ctypes.byref(d), 16, 16, None, 16, None)
+    rc = lib.fcd_conv2d_fwd(ctypes.byref(d), 16, 16, None, 16, 0, None)
     assert rc == -1 and b'output size' in lib.fcd_last_error_string()
     d = _lib.ConvDesc(1, 4, 8, 8, 8, 5, 5, 1, 2, 8, 8)      # unsupported 5x5
     assert lib.fcd_conv2d_bwd_weight_ws_bytes(ctypes.byref(d)) == 0

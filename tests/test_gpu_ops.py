@@ -74,6 +74,29 @@ def test_conv2d_fwd_bwd(case):
     assert_close(bg.grad, br.grad, what='db')
 
 
+@pytest.mark.parametrize('case', [(2, 3, 24, 40, 64, 3, 1, 1), (2, 64, 20, 28, 128, 3, 1, 1), (3, 16, 9, 7, 24, 3, 1, 1),
+                                  (2, 8, 16, 16, 40, 3, 2, 1)], ids=lambda c: 'x'.join(map(str, c)))
+def test_conv2d_fused_relu(case):
+    """conv + bias + ReLU in the kernel epilogue; backward re-derives the mask from the output."""
+    ops = _ops()
+    N, C, H, W, K, R, st, pad = case
+    x = rnd(N, C, H, W, seed=91)
+    w = rnd(K, C, R, R, seed=92, scale=(2.0 / (C * R * R)) ** 0.5)
+    b = rnd(K, seed=93, scale=0.1)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yr = F.relu(F.conv2d(xr, wr, br, stride=st, padding=pad))
+    g = rnd(*yr.shape, seed=94)
+    yr.backward(g)
+    xg, wg, bg = (t.cuda().requires_grad_(True) for t in (x, w, b))
+    y = ops.conv2d(xg, wg, bg, st, pad, relu=True)
+    y.backward(g.cuda())
+    assert_close(y, yr, what='y')
+    # elements whose pre-activation is within rounding of 0 may flip: compare in aggregate
+    for got, ref, what in ((xg.grad, xr.grad, 'dx'), (wg.grad, wr.grad, 'dw'), (bg.grad, br.grad, 'db')):
+        d = (got.cpu().double() - ref.double())
+        assert (d.norm() / ref.double().norm()).item() < 1e-4, what
+
+
 @pytest.mark.parametrize('shape', [(2, 16, 5, 7), (1, 64, 12, 16), (3, 32, 1, 1)])
 def test_conv_transpose2x2(shape):
     ops = _ops()

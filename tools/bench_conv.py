@@ -71,15 +71,15 @@ def main():
         wp, wpb = ops.packed_weight(w, 0), ops.packed_weight(w, 1)
         s = ops._stream()
         flops = 2.0 * N * K * d.P * d.Q * C * R * R
-        t_f = timeit(lambda: check(lib.fcd_conv2d_fwd(ctypes.byref(d), ops._p(x), ops._p(wp), ops._p(b), ops._p(y), s)))
-        t_d = timeit(lambda: check(lib.fcd_conv2d_bwd_data(ctypes.byref(d), ops._p(dy), ops._p(wpb), ops._p(dx), s)))
+        t_f = timeit(lambda: check(lib.fcd_conv2d_fwd(ctypes.byref(d), ops._p(x), ops._p(wp), ops._p(b), ops._p(y), 0, s)))
+        t_d = timeit(lambda: check(lib.fcd_conv2d_bwd_data(ctypes.byref(d), ops._p(dy), None, ops._p(wpb), ops._p(dx), s)))
         res = '%8.1f %8.1f' % (flops / t_f / 1e9, flops / t_d / 1e9)
         ms = '%6.2f %6.2f' % (t_f, t_d)
         tot['fwd'] += t_f; tot['dgrad'] += t_d
         if wg:
             nb = lib.fcd_conv2d_bwd_weight_ws_bytes(ctypes.byref(d))
             ws = torch.empty(max(nb, 16), dtype=torch.uint8, device='cuda')
-            t_w = timeit(lambda: check(lib.fcd_conv2d_bwd_weight(ctypes.byref(d), ops._p(x), ops._p(dy), ops._p(dw),
+            t_w = timeit(lambda: check(lib.fcd_conv2d_bwd_weight(ctypes.byref(d), ops._p(x), ops._p(dy), None, ops._p(dw),
                                                                  ops._p(ws), ws.numel(), s)))
             res += ' %8.1f' % (flops / t_w / 1e9)
             ms += ' %6.2f' % t_w
