@@ -119,7 +119,8 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_kernel(ConvArgs a) {
     x_loff[i] = cc * PLANE + ph * PWP + pw;
   }
   const float* xin = a.x + (size_t)n * a.C * a.H * a.W;
-  const float* min_ = a.mask ? a.mask + (size_t)n * a.C * a.H * a.W : nullptr;
+  const bool has_mask = a.mask != nullptr;
+  const float* min_ = (has_mask ? a.mask : a.x) + (size_t)n * a.C * a.H * a.W;
   const int chunk_elems = CB * a.H * a.W;
 
 #define FCD_LOAD_W(CCHUNK, RR)                                                                        \
@@ -138,21 +139,21 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_kernel(ConvArgs a) {
 #define FCD_LOAD_X(CCHUNK)                                                                            \
   {                                                                                                   \
     const float* xsrc = xin + (size_t)(CCHUNK) * chunk_elems;                                         \
+    const float* msrc = min_ + (size_t)(CCHUNK) * chunk_elems;                                        \
     const int cleft = a.C - (CCHUNK) * CB;                                                            \
     _Pragma("unroll") for (int i = 0; i < X_PER_T; ++i) {                                             \
-      float v = 0.f, m = 1.f;                                                                         \
-      if (x_cc[i] >= 0 && x_cc[i] < cleft) {                                                          \
-        v = xsrc[x_goff[i]];                                                                          \
-        if (min_) m = min_[(size_t)(CCHUNK) * chunk_elems + x_goff[i]];                               \
-      }                                                                                               \
-      xr[i] = v;                                                                                      \
-      mr[i] = m;                                                                                      \
+      /* branch-free: out-of-range lanes read element 0 of the chunk and are zeroed by select */     \
+      const bool ok = (unsigned)x_cc[i] < (unsigned)cleft;                                            \
+      const unsigned off = ok ? (unsigned)x_goff[i] : 0u;                                             \
+      const float v = xsrc[off];                                                                      \
+      xr[i] = ok ? v : 0.f;                                                                           \
+      if (has_mask) mr[i] = msrc[off];                                                                \
     }                                                                                                 \
   }
 #define FCD_STORE_X()                                                                                 \
   {                                                                                                   \
     _Pragma("unroll") for (int i = 0; i < X_PER_T; ++i) {                                             \
-      if (X_ELEMS % 256 == 0 || tid + i * 256 < X_ELEMS) Xs[x_loff[i]] = (mr[i] > 0.f) ? xr[i] : 0.f; \
+      if (X_ELEMS % 256 == 0 || tid + i * 256 < X_ELEMS) Xs[x_loff[i]] = (!has_mask || mr[i] > 0.f) ? xr[i] : 0.f; \
     }                                                                                                 \
   }
 
@@ -235,6 +236,9 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_kernel(ConvArgs a) {
 // ds_write pass).  Both LDS buffers (filter slab + input patch) are double-buffered:
 // one s_barrier per step instead of two, and the registers freed by the filter staging
 // buy a third resident workgroup per CU.
+#ifndef FCD_MFMA_PRIO
+#define FCD_MFMA_PRIO 0
+#endif
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 
@@ -320,7 +324,8 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_glds_kernel(ConvArgs a) {
     x_loff[i] = cc * PLANE + ph * PWP + pw;
   }
   const float* xin = a.x + (size_t)n * a.C * a.H * a.W;
-  const float* min_ = a.mask ? a.mask + (size_t)n * a.C * a.H * a.W : nullptr;
+  const bool has_mask = a.mask != nullptr;
+  const float* min_ = (has_mask ? a.mask : a.x) + (size_t)n * a.C * a.H * a.W;
   const int chunk_elems = CB * a.H * a.W;
 
 #define FCD_GLDS_W(CCHUNK, RR, BUF)                                                                   \
@@ -335,15 +340,15 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_glds_kernel(ConvArgs a) {
 #define FCD_LOAD_X2(CCHUNK)                                                                           \
   {                                                                                                   \
     const float* xsrc = xin + (size_t)(CCHUNK) * chunk_elems;                                         \
+    const float* msrc = min_ + (size_t)(CCHUNK) * chunk_elems;                                        \
     const int cleft = a.C - (CCHUNK) * CB;                                                            \
     _Pragma("unroll") for (int i = 0; i < X_PER_T; ++i) {                                             \
-      float v = 0.f, m = 1.f;                                                                         \
-      if (x_cc[i] >= 0 && x_cc[i] < cleft) {                                                          \
-        v = xsrc[x_goff[i]];                                                                          \
-        if (min_) m = min_[(size_t)(CCHUNK) * chunk_elems + x_goff[i]];                               \
-      }                                                                                               \
-      xr[i] = v;                                                                                      \
-      mr[i] = m;                                                                                      \
+      /* branch-free: out-of-range lanes read element 0 of the chunk and are zeroed by select */     \
+      const bool ok = (unsigned)x_cc[i] < (unsigned)cleft;                                            \
+      const unsigned off = ok ? (unsigned)x_goff[i] : 0u;                                             \
+      const float v = xsrc[off];                                                                      \
+      xr[i] = ok ? v : 0.f;                                                                           \
+      if (has_mask) mr[i] = msrc[off];                                                                \
     }                                                                                                 \
   }
   /* the ReLU-mask select is applied HERE (after the MFMA block), so neither load is waited for early */ \
@@ -351,7 +356,7 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_glds_kernel(ConvArgs a) {
   {                                                                                                   \
     _Pragma("unroll") for (int i = 0; i < X_PER_T; ++i) {                                             \
       if (X_ELEMS % 256 == 0 || tid + i * 256 < X_ELEMS)                                              \
-        smem[2 * WS_SZ + (BUF) * XS_SZ + x_loff[i]] = (mr[i] > 0.f) ? xr[i] : 0.f;                    \
+        smem[2 * WS_SZ + (BUF) * XS_SZ + x_loff[i]] = (!has_mask || mr[i] > 0.f) ? xr[i] : 0.f;                    \
     }                                                                                                 \
   }
 
@@ -372,6 +377,7 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_glds_kernel(ConvArgs a) {
       FCD_GLDS_W((NR == 1) ? nxt : nxt / NR, (NR == 1) ? 0 : nxt % NR, wb ^ 1)
       if (next_patch) FCD_LOAD_X2(chunk + 1)
     }
+    __builtin_amdgcn_s_setprio(FCD_MFMA_PRIO);
     const float* wl = smem + wb * WS_SZ + woff;
     const float* xl = smem + 2 * WS_SZ + xb * XS_SZ + rr * RCH * PWP;
 #pragma unroll
@@ -393,6 +399,7 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_glds_kernel(ConvArgs a) {
         }
       }
     }
+    __builtin_amdgcn_s_setprio(0);
     if (next_patch) FCD_STORE_X2(xb ^ 1)
     __syncthreads();
   }
@@ -520,6 +527,10 @@ static int launch_family(const ConvArgs& a, hipStream_t st) {
     return wide ? launch_cfg<R, S, RCH, STRIDE, DIL, CB, 2, 2, 2, 2, 4, 32>(a, st)
                 : launch_cfg<R, S, RCH, STRIDE, DIL, CB, 2, 2, 2, 2, 8, 16>(a, st);
   } else if (a.K > 32) {
+    // 64 output channels: 64 x 256-pixel tiles (8x32 / 16x16 pixels), each wave 64x64
+    if (R == 3 && a.P >= 8)
+      return wide ? launch_cfg<R, S, RCH, STRIDE, DIL, CB, 2, 2, 1, 4, 8, 32>(a, st)
+                  : launch_cfg<R, S, RCH, STRIDE, DIL, CB, 2, 2, 1, 4, 16, 16>(a, st);
     return wide ? launch_cfg<R, S, RCH, STRIDE, DIL, CB, 2, 1, 1, 4, 4, 32>(a, st)
                 : launch_cfg<R, S, RCH, STRIDE, DIL, CB, 2, 1, 1, 4, 8, 16>(a, st);
   }
