@@ -1,0 +1,148 @@
+"""Parity at BASELINE.json's FULL sizes (13 bands, 256x256, 8 tile pairs) through
+size-independent properties -- adjoint identities of the conv kernels, linearity,
+run-to-run determinism, BatchNorm moments, MS-SSIM invariants -- plus direct oracle
+comparisons of the Segmentor's density map at the real tile sizes (256, and the demos'
+odd patch sizes 200 / 220 that exercise the F.pad path of Up, Module.py:70-74)."""
+import numpy as np
+import pytest
+import torch
+
+from seeded import seeded_state, seeded_tiles
+from oracle import nets as onets
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def pkg():
+    import fcd_gan_pytorch_amd as p
+    return p
+
+
+def ddot(a, b):
+    return (a.double() * b.double()).sum().item()
+
+
+FULL_CONVS = [
+    # N, C, H, K, R, stride, pad      (layers of the headline workload)
+    (8, 64, 256, 64, 3, 1, 1),       # G residual convs / U-Net first stage
+    (16, 13, 256, 64, 3, 1, 1),      # Siamese inc on 13 bands
+    (8, 256, 128, 128, 3, 1, 1),     # decoder up3
+    (8, 2048, 32, 1024, 3, 1, 1),    # decoder up1 (widest K)
+    (32, 64, 128, 128, 3, 2, 1),     # discriminator, stride 2
+    (8, 13, 256, 64, 9, 1, 4),       # generator head 9x9
+    (8, 128, 256, 1, 1, 1, 0),       # OutConv
+]
+
+
+@pytest.mark.parametrize('case', FULL_CONVS, ids=lambda c: 'x'.join(map(str, c)))
+def test_conv_adjoint_linearity_determinism(case):
+    """<conv(x), g> == <x, dgrad(g)> == <w, wgrad(x, g)>  (bias-free), conv is linear in x,
+    and every kernel is bit-reproducible run to run."""
+    ops = pkg()._ops
+    N, C, H, K, R, st, pad = case
+    g0 = torch.Generator(device=DEV).manual_seed(sum(case))
+    x = torch.randn(N, C, H, H, device=DEV, generator=g0).requires_grad_(True)
+    w = (torch.randn(K, C, R, R, device=DEV, generator=g0) * (2.0 / (C * R * R)) ** 0.5).requires_grad_(True)
+    y = ops.conv2d(x, w, None, st, pad)
+    g = torch.randn(y.shape, device=DEV, generator=g0)
+    y.backward(g)
+    a, b, c = ddot(y.detach(), g), ddot(x.detach(), x.grad), ddot(w.detach(), w.grad)
+    scale = max(abs(a), (y.detach().double().norm() * g.double().norm()).item() * 1e-3)
+    assert abs(a - b) <= 2e-5 * scale, ('fwd vs dgrad', a, b)
+    assert abs(a - c) <= 2e-5 * scale, ('fwd vs wgrad', a, c)
+    # linearity
+    x2 = torch.randn(x.shape, device=DEV, generator=g0)
+    with torch.no_grad():
+        lhs = ops.conv2d(2.0 * x + x2, w, None, st, pad)
+        rhs = 2.0 * y.detach() + ops.conv2d(x2, w, None, st, pad)
+    assert (lhs - rhs).abs().max().item() <= 2e-5 * rhs.abs().max().item()
+    # determinism (bitwise)
+    dx1, dw1 = x.grad.clone(), w.grad.clone()
+    x.grad = None
+    w.grad = None
+    y2 = ops.conv2d(x, w, None, st, pad)
+    y2.backward(g)
+    assert torch.equal(y2, y) and torch.equal(x.grad, dx1) and torch.equal(w.grad, dw1)
+
+
+def test_batchnorm_moments_full_size():
+    """train-mode BN output has per-channel mean beta and variance gamma^2 * var/(var+eps)."""
+    ops = pkg()._ops
+    bn = torch.nn.BatchNorm2d(64).to(DEV).train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+    x = torch.randn(16, 64, 256, 256, device=DEV) * 3 + 1
+    y = ops.bn_act(x, bn, ops.ACT_NONE, groups=2)
+    for grp in (y[:8], y[8:]):
+        m = grp.double().mean((0, 2, 3))
+        v = grp.double().var((0, 2, 3), unbiased=False)
+        assert (m - bn.bias.double()).abs().max().item() < 1e-5
+        assert (v / bn.weight.double() ** 2 - 1).abs().max().item() < 1e-4
+    assert int(bn.num_batches_tracked) == 2
+
+
+def test_msssim_invariants_full_size():
+    ssim = pkg().ssim
+    x, y, _ = (t.to(DEV) for t in seeded_tiles(3, 8, 13, 256, 256))
+    crit = ssim.MS_SSIM(data_range=1.0, channel=13)
+    one = crit(x, x).item()
+    ab, ba = crit(x, y).item(), crit(y, x).item()
+    assert abs(one - 1.0) < 1e-5
+    assert abs(ab - ba) < 1e-6 and 0.0 <= ab <= 1.0
+    per = ssim.ms_ssim(x, y, data_range=1.0, size_average=False)
+    assert per.shape == (8,) and abs(per.mean().item() - ab) < 1e-6
+    with pytest.raises(AssertionError):
+        crit(x[:, :, :160, :160], y[:, :, :160, :160])      # ssim.py:194-197
+    with pytest.raises(ValueError):
+        crit(x, y[:, :, :128])
+
+
+@pytest.mark.parametrize('size,N', [(256, 2), (200, 1), (220, 1)])
+def test_segmentor_density_vs_oracle_real_tile_sizes(size, N):
+    """north_star: density map within 1e-4 L_inf of the CPU reference, thresholded map
+    bit-exact (pixels within the achieved error of the threshold excluded)."""
+    C = 13
+    M = pkg().Module
+    sd = seeded_state(onets.segmentor_spec(C, 1, True), 2024)
+    net = M.Segmentor(C, 1, True)
+    net.load_state_dict(sd)
+    net.to(DEV).train()
+    x, y, _ = seeded_tiles(size, N, C, size, size)
+    with torch.no_grad():
+        got = net(x.to(DEV), y.to(DEV)).cpu()
+        ref = onets.segmentor(onets.clone_state(sd, requires_grad=False), x, y, train=True, bilinear=True)
+    err = (got - ref).abs().max().item()
+    assert err <= 1e-4, 'density map L_inf %.2e' % err
+    safe = (ref - 0.5).abs() > max(err, 1e-6) * 2
+    assert torch.equal((got > 0.5)[safe], (ref > 0.5)[safe])
+    assert safe.float().mean().item() > 0.999
+
+
+def test_rsss_step_full_size_is_finite_and_reproducible():
+    import warnings
+    p = pkg()
+    C, N, H = 13, 4, 256
+    x, y, region = (t.to(DEV) for t in seeded_tiles(9, N, C, H, H))
+
+    def run():
+        torch.manual_seed(0)
+        netD = p.Module.Discriminator_SRGAN_simple(C).to(DEV).train()
+        netS = p.Module.Segmentor(C, 1, True).to(DEV).train()
+        netG = p.Module.Generator(C).to(DEV).eval()
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            crit = p.Loss.CGeneratorLoss(channel=C, perception_layer=1, perception_perBand=True).to(DEV)
+        oS, oD = p.optim.RMSprop(netS.parameters(), lr=5e-5), p.optim.RMSprop(netD.parameters(), lr=5e-5)
+        outs = []
+        for _ in range(2):
+            r = p.steps.rsss_adversarial_step(netS, netD, netG, crit, oS, oD, x, y, region)
+            outs.append([float(r[k]) for k in ('d_loss', 's_loss', 'g_loss', 'l1_loss', 'r_loss', 'ssim_loss',
+                                               'perception_loss')])
+        return np.array(outs), oS.flat_p.clone()
+    a, pa = run()
+    b, pb = run()
+    assert np.isfinite(a).all()
+    np.testing.assert_array_equal(a, b)          # every kernel is deterministic (no atomics)
+    assert torch.equal(pa, pb)
