@@ -43,8 +43,36 @@ class DoubleConv(nn.Module):
 
     def forward(self, x, groups=1):
         s = self.double_conv
+        if not self.training and not torch.is_grad_enabled():
+            # inference (Demo_RSSS.py:451-491: netS.eval() + no_grad): eval-mode BatchNorm is an
+            # affine map per channel -> folded into the conv's filter and bias once, and each
+            # conv+BN+ReLU becomes ONE kernel (MFMA conv with the bias+ReLU epilogue)
+            (w0, b0), (w1, b1) = self._folded_params()
+            return ops.conv2d(ops.conv2d(x, w0, b0, 1, 1, relu=True), w1, b1, 1, 1, relu=True)
         x = ops.bn_act(_conv(s[0], x), s[1], ops.ACT_RELU, groups=groups)
         return ops.bn_act(_conv(s[3], x), s[4], ops.ACT_RELU, groups=groups)
+
+    def _folded_params(self):
+        cache = self.__dict__.get('_fcd_folded')
+        if cache is None:
+            cache = []
+            s = self.double_conv
+            with torch.no_grad():
+                for conv, bn in ((s[0], s[1]), (s[3], s[4])):
+                    scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+                    w = (conv.weight * scale.view(-1, 1, 1, 1)).contiguous()
+                    b = ((conv.bias - bn.running_mean) * scale + bn.bias).contiguous()
+                    cache.append((w, b))
+            self.__dict__['_fcd_folded'] = cache
+        return cache
+
+    def train(self, mode=True):
+        self.__dict__.pop('_fcd_folded', None)      # folded filters are only valid for frozen weights
+        return super().train(mode)
+
+    def _apply(self, fn, *a, **k):
+        self.__dict__.pop('_fcd_folded', None)
+        return super()._apply(fn, *a, **k)
 
 
 class Down(nn.Module):

@@ -222,6 +222,17 @@ def usss_joint_step(netS, netG, crit, optS, optG, x, y, perception_weight=0.4, l
                 perception_loss=perception_loss, ssim_loss=ssim_loss, cmap=cmap)
 
 
+# --------------------------------------------------------------------- inference
+@torch.no_grad()
+def infer_density(netS, x, y, prob_thresh=0.5):
+    """Inference body of the demos (Demo_RSSS.py:457-491, Demo_USSS.py:413-470): change-density
+    map and thresholded binary map.  ``netS.eval()`` must have been called; BatchNorm is then
+    folded into the convolutions (Module.DoubleConv).  Demo_WSSS keeps train() mode on purpose
+    (Demo_WSSS.py:389-391) -- in that case the regular batch-statistics path runs."""
+    cmap = netS(x, y)
+    return cmap, (cmap > prob_thresh)
+
+
 # ------------------------------------------------------- on-device confusion matrix
 def confusion_counts(cmap, ref_changed, prob_thresh=0.5, group=None):
     """2x2 confusion counts of the thresholded map vs. a {0,1} reference on device

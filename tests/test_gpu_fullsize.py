@@ -146,3 +146,29 @@ def test_rsss_step_full_size_is_finite_and_reproducible():
     assert np.isfinite(a).all()
     np.testing.assert_array_equal(a, b)          # every kernel is deterministic (no atomics)
     assert torch.equal(pa, pb)
+
+
+@pytest.mark.parametrize('size,N', [(256, 2), (220, 1)])
+def test_inference_path_bn_folded_vs_oracle(size, N):
+    """netS.eval() + no_grad inference (BN folded into the convs, one fused
+    conv+bias+ReLU kernel per layer) vs the oracle's eval-mode forward."""
+    p = pkg()
+    C = 13
+    sd = seeded_state(onets.segmentor_spec(C, 1, True), 77)
+    net = p.Module.Segmentor(C, 1, True)
+    net.load_state_dict(sd)
+    net.to(DEV).eval()
+    x, y, _ = seeded_tiles(size + 1, N, C, size, size)
+    dens, mask = p.steps.infer_density(net, x.to(DEV), y.to(DEV))
+    ref = onets.segmentor(onets.clone_state(sd, requires_grad=False), x, y, train=False, bilinear=True)
+    err = (dens.cpu() - ref).abs().max().item()
+    assert err <= 1e-4, err
+    safe = (ref - 0.5).abs() > 2e-4
+    assert torch.equal(mask.cpu()[safe], (ref > 0.5)[safe])
+    # the unfolded eval path (grad enabled) agrees with the folded one
+    with torch.enable_grad():
+        unfolded = net(x.to(DEV), y.to(DEV)).detach()
+    assert (unfolded - dens).abs().max().item() <= 2e-5
+    # folding is invalidated by train()
+    net.train(); net.eval()
+    assert '_fcd_folded' not in net.inc.__dict__
