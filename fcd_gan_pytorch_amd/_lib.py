@@ -10,7 +10,7 @@ import subprocess
 from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libfcdgan_hip.so')
+LIB_PATH = os.environ.get('FCD_LIB') or os.path.join(_HERE, 'libfcdgan_hip.so')   # FCD_LIB: A/B kernel builds
 CSRC = os.path.join(_HERE, 'csrc')
 
 

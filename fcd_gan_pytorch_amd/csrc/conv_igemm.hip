@@ -236,6 +236,9 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_kernel(ConvArgs a) {
 // ds_write pass).  Both LDS buffers (filter slab + input patch) are double-buffered:
 // one s_barrier per step instead of two, and the registers freed by the filter staging
 // buy a third resident workgroup per CU.
+#ifndef FCD_CB2
+#define FCD_CB2 4
+#endif
 #ifndef FCD_MFMA_PRIO
 #define FCD_MFMA_PRIO 0
 #endif
@@ -502,7 +505,7 @@ static int launch_cfg(const ConvArgs& a0, hipStream_t st) {
   a.tiles_p = cdiv(a.P, TH);
   a.tiles_q = cdiv(a.Q, TW);
   dim3 grid((unsigned)(a.N * a.tiles_p * a.tiles_q), (unsigned)cdiv(a.K, BM));
-  constexpr int CB2 = 4;
+  constexpr int CB2 = FCD_CB2;
   constexpr bool kHasV2 = (R == 3 && S == 3) && ((CB2 * RCH * S * BM) % 256 == 0);
   if constexpr (kHasV2) {
     if (use_v2()) {
