@@ -77,7 +77,18 @@ class PerceptionLoss(nn.Module):
         self.perception_perBand = perception_perBand
         self.loss = nn.MSELoss()
 
-    def _features(self, z):
+    def _first_filter_1ch(self):
+        """A band replicated to 3 channels (Loss.py:52-53) sees the first conv as ONE-channel
+        conv with the filter summed over its input channels: same map, a third of the reads,
+        and its data gradient is directly the gradient of the band."""
+        w = self.net[0].weight
+        hit = self.__dict__.get('_fcd_w1')
+        if hit is None or hit[0] != w._version or hit[1].device != w.device:
+            hit = (w._version, w.detach().sum(dim=1, keepdim=True).contiguous())
+            self.__dict__['_fcd_w1'] = hit
+        return hit[1]
+
+    def _features(self, z, single_band=False):
         """All 31 layers (the reference runs the stack to the end, Loss.py:45-49);
         returns {tap index: activation}."""
         taps = {}
@@ -89,7 +100,8 @@ class PerceptionLoss(nn.Module):
                 fuse = i + 1 < len(layers) and isinstance(layers[i + 1], nn.ReLU)
                 # conv + bias + ReLU in one kernel (epilogue); the ReLU mask is re-derived from
                 # the output inside the data-gradient kernel's loader
-                z = ops.conv2d(z, layer.weight, layer.bias, 1, 1, relu=fuse)
+                wgt = self._first_filter_1ch() if (i == 0 and single_band) else layer.weight
+                z = ops.conv2d(z, wgt, layer.bias, 1, 1, relu=fuse)
                 if fuse:
                     i += 1          # the ReLU entry (tapped indices are all ReLU outputs)
             elif isinstance(layer, nn.ReLU):
@@ -116,9 +128,9 @@ class PerceptionLoss(nn.Module):
             keep = 1 - cmask
             tb = (target_image * keep).reshape(n * C, 1, H, W)
             gb = (generate_image * keep).reshape(n * C, 1, H, W)
-            z = torch.cat([tb, gb], dim=0).expand(-1, 3, -1, -1).contiguous()
+            z = torch.cat([tb, gb], dim=0)          # (2*n*C, 1, H, W): see _first_filter_1ch
             nb = n * C
-        feats = self._features(z)
+        feats = self._features(z, single_band=self.perception_perBand)
         total = 0
         for i in sorted(self.feature_layer_list):
             f = feats[i]

@@ -18,6 +18,8 @@
 #include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+int fcd_try_dgrad_thin(const fcd_conv_desc* d, const float* dy, const float* relu_out, const float* wp_bwd, float* dx,
+                       hipStream_t st);  // conv_thin.hip
 
 struct ConvArgs {
   const float* x;
@@ -601,6 +603,10 @@ extern "C" int fcd_conv2d_bwd_data(const fcd_conv_desc* d, const float* dy, cons
   const double bytes = 4.0 * ((double)d->N * d->C * d->H * d->W + (double)d->N * d->K * d->P * d->Q +
                               (double)d->K * d->C * d->R * d->S);
   FcdProfScope prof(FCD_K_CONV_DGRAD, (hipStream_t)stream, flops, bytes);
+  if (fcd_try_dgrad_thin(d, dy, relu_out, wp_bwd, dx, (hipStream_t)stream) == 0) {   // <= 4 input channels: VALU kernel
+    FCD_LAUNCH_CHECK("conv2d_bwd_data(thin)");
+    return FCD_OK;
+  }
   rc = conv_dispatch(a, d->R, d->S, 1, d->stride, (hipStream_t)stream);
   FCD_CHECK_ARG(rc == 0, "fcd_conv2d_bwd_data: unsupported filter %dx%d stride %d", d->R, d->S, d->stride);
   FCD_LAUNCH_CHECK("conv2d_bwd_data");
