@@ -101,6 +101,13 @@ class PerceptionLoss(nn.Module):
                 # conv + bias + ReLU in one kernel (epilogue); the ReLU mask is re-derived from
                 # the output inside the data-gradient kernel's loader
                 wgt = self._first_filter_1ch() if (i == 0 and single_band) else layer.weight
+                pool_next = fuse and i + 2 < len(layers) and isinstance(layers[i + 2], nn.MaxPool2d)
+                if pool_next and (i + 1) not in self.feature_layer_list:
+                    # conv + bias + ReLU + MaxPool in ONE kernel: the full-resolution activation is
+                    # never written, its backward needs one code byte per pooled element
+                    z = ops.conv2d_relu_maxpool2(z, wgt, layer.bias)
+                    i += 3
+                    continue
                 z = ops.conv2d(z, wgt, layer.bias, 1, 1, relu=fuse)
                 if fuse:
                     i += 1          # the ReLU entry (tapped indices are all ReLU outputs)

@@ -44,6 +44,8 @@ _SIGS = {
     'fcd_conv_pack_weights': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'fcd_conv2d_fwd': (c_int, [POINTER(ConvDesc), P, P, P, P, c_int, P]),
     'fcd_conv2d_bwd_data': (c_int, [POINTER(ConvDesc), P, P, P, P, P]),
+    'fcd_conv2d_fwd_relu_pool': (c_int, [POINTER(ConvDesc), P, P, P, P, P, P]),
+    'fcd_conv2d_bwd_data_pooled': (c_int, [POINTER(ConvDesc), P, P, P, P, P]),
     'fcd_conv2d_bwd_weight_ws_bytes': (c_size_t, [POINTER(ConvDesc)]),
     'fcd_conv2d_bwd_weight': (c_int, [POINTER(ConvDesc), P, P, P, P, P, c_size_t, P]),
     'fcd_channel_sum_ws_bytes': (c_size_t, [c_int]),

@@ -7,6 +7,7 @@ Demo_RSSS.py:305,331, works unchanged).  All arithmetic of the ops below runs
 in the hand-written HIP kernels; CPU tensors are rejected (no fallback).
 """
 import ctypes
+import os
 
 import torch
 
@@ -119,6 +120,53 @@ class _Conv2d(torch.autograd.Function):
 def conv2d(x, weight, bias=None, stride=1, padding=0, relu=False):
     """conv2d (+bias) (+fused ReLU epilogue when ``relu``)."""
     return _Conv2d.apply(x, weight, bias, int(stride), int(padding), bool(relu))
+
+
+class _ConvReluPool(torch.autograd.Function):
+    """conv3x3 + bias + ReLU + MaxPool2d(2) as one kernel (frozen filters only: the VGG stack).
+    Saves just the 1-byte argmax code per pooled element for the backward pass."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = _dev(x, 'conv input')
+        d = _desc(x.shape, weight.shape, 1, 1)
+        yp = torch.empty((d.N, d.K, d.P // 2, d.Q // 2), dtype=torch.float32, device=x.device)
+        code = torch.empty(yp.shape, dtype=torch.uint8, device=x.device)
+        wp = packed_weight(weight, 0)
+        check(lib.fcd_conv2d_fwd_relu_pool(ctypes.byref(d), _p(x), _p(wp), _p(bias), _p(yp), _p(code), _stream()),
+              'fcd_conv2d_fwd_relu_pool')
+        ctx.save_for_backward(weight, code)
+        ctx.xshape = tuple(x.shape)
+        return yp
+
+    @staticmethod
+    def backward(ctx, dyp):
+        weight, code = ctx.saved_tensors
+        dyp = _dev(dyp, 'pooled grad')
+        d = _desc(ctx.xshape, weight.shape, 1, 1)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(ctx.xshape, dtype=torch.float32, device=dyp.device)
+            wpb = packed_weight(weight, 1)
+            check(lib.fcd_conv2d_bwd_data_pooled(ctypes.byref(d), _p(dyp), _p(code), _p(wpb), _p(dx), _stream()),
+                  'fcd_conv2d_bwd_data_pooled')
+        return dx, None, None
+
+
+def conv_relu_pool_supported(x, weight):
+    K, C, R, S = weight.shape
+    if os.environ.get('FCD_NO_POOLFUSE'):          # A/B switch for benchmarking
+        return False
+    return (R == 3 and S == 3 and K > 32 and C > 32 and not weight.requires_grad
+            and x.shape[2] >= 2 and x.shape[3] >= 2)
+
+
+def conv2d_relu_maxpool2(x, weight, bias):
+    """maxpool2(relu(conv3x3(x) + bias)) -- one kernel when supported (frozen 3x3 filters with
+    > 32 in/out channels), the three-op composition otherwise."""
+    if conv_relu_pool_supported(x, weight) and (bias is None or not bias.requires_grad):
+        return _ConvReluPool.apply(x, weight, bias)
+    return maxpool2(conv2d(x, weight, bias, 1, 1, relu=True))
 
 
 class _ConvT2x2(torch.autograd.Function):

@@ -28,6 +28,15 @@ struct ConvArgs {
   const float* mask;  // optional, same shape as x: x is read as x * (mask > 0)  (ReLU backward fused in)
   float* y;
   int relu;           // epilogue: y = max(y, 0)
+  // fused MaxPool2d(2) (v2 kernel only).  Forward: the epilogue writes the 2x2-pooled ReLU
+  // output to pool_y and an argmax code byte (bits 0-1: window slot row*2+col, bit 2: max > 0)
+  // to pool_code_out INSTEAD of y.  Data gradient: x is the POOLED gradient (N,C,H/2,W/2) and
+  // pool_code_in its code bytes; element (h,w) reads x[h/2,w/2] iff its slot is the argmax of a
+  // positive window (ReLU + max-pool backward folded into the patch loader).
+  float* pool_y;
+  unsigned char* pool_code_out;
+  const unsigned char* pool_code_in;
+  int Hp, Wp;         // pooled extents of the dgrad source
   int N, C, H, W;   // stored input tensor
   int K, Kpad;      // real / packed output channels
   int P, Q;         // output extent
@@ -309,7 +318,9 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_glds_kernel(ConvArgs a) {
     w_goff[j] = (cc * (R * S) + rem) * a.Kpad + ko0 + col;
   }
   float xr[X_PER_T], mr[X_PER_T];
+  unsigned mcode[X_PER_T], x_want[X_PER_T];   // raw code byte kept as an integer: no conversion => no early wait
   int x_goff[X_PER_T], x_loff[X_PER_T], x_cc[X_PER_T];
+  const bool pooled_src = a.pool_code_in != nullptr;
   const int ih0 = p0 * STRIDE - a.pad, iw0 = q0 * STRIDE - a.pad;
 #pragma unroll
   for (int i = 0; i < X_PER_T; ++i) {
@@ -327,11 +338,19 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_glds_kernel(ConvArgs a) {
     x_cc[i] = ok ? cc : -1;
     x_goff[i] = (cc * a.H + ih) * a.W + iw;
     x_loff[i] = cc * PLANE + ph * PWP + pw;
+    if (pooled_src) {   // gradient arrives pooled: index the (Hp, Wp) tensors, remember this element's slot
+      const int hp = ih >> 1, wq = iw >> 1;
+      if (hp >= a.Hp || wq >= a.Wp) x_cc[i] = -1;            // trailing odd row / column: never pooled
+      x_goff[i] = (cc * a.Hp + hp) * a.Wp + wq;
+      x_want[i] = (unsigned)((((ih & 1) << 1) | (iw & 1)) | 4);
+    }
   }
-  const float* xin = a.x + (size_t)n * a.C * a.H * a.W;
+  const int in_plane = pooled_src ? a.Hp * a.Wp : a.H * a.W;
+  const float* xin = a.x + (size_t)n * a.C * in_plane;
   const bool has_mask = a.mask != nullptr;
-  const float* min_ = (has_mask ? a.mask : a.x) + (size_t)n * a.C * a.H * a.W;
-  const int chunk_elems = CB * a.H * a.W;
+  const float* min_ = (has_mask ? a.mask : a.x) + (size_t)n * a.C * in_plane;
+  const unsigned char* cin_ = pooled_src ? a.pool_code_in + (size_t)n * a.C * in_plane : nullptr;
+  const int chunk_elems = CB * in_plane;
 
 #define FCD_GLDS_W(CCHUNK, RR, BUF)                                                                   \
   {                                                                                                   \
@@ -354,6 +373,7 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_glds_kernel(ConvArgs a) {
       const float v = xsrc[off];                                                                      \
       xr[i] = ok ? v : 0.f;                                                                           \
       if (has_mask) mr[i] = msrc[off];                                                                \
+      if (pooled_src) mcode[i] = cin_[(size_t)(CCHUNK) * chunk_elems + off];                          \
     }                                                                                                 \
   }
   /* the ReLU-mask select is applied HERE (after the MFMA block), so neither load is waited for early */ \
@@ -361,7 +381,8 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_glds_kernel(ConvArgs a) {
   {                                                                                                   \
     _Pragma("unroll") for (int i = 0; i < X_PER_T; ++i) {                                             \
       if (X_ELEMS % 256 == 0 || tid + i * 256 < X_ELEMS)                                              \
-        smem[2 * WS_SZ + (BUF) * XS_SZ + x_loff[i]] = (!has_mask || mr[i] > 0.f) ? xr[i] : 0.f;                    \
+        smem[2 * WS_SZ + (BUF) * XS_SZ + x_loff[i]] =                                                 \
+            pooled_src ? (mcode[i] == x_want[i] ? xr[i] : 0.f) : ((!has_mask || mr[i] > 0.f) ? xr[i] : 0.f); \
     }                                                                                                 \
   }
 
@@ -411,6 +432,66 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_glds_kernel(ConvArgs a) {
 #undef FCD_GLDS_W
 #undef FCD_LOAD_X2
 #undef FCD_STORE_X2
+
+  if (a.pool_y != nullptr) {
+    // ---- fused bias + ReLU + MaxPool2d(2) epilogue.  D layout: col = l31 (pixel), NI = 2.
+    //  TW == 32: the wave's two n-tiles are image rows 2wn, 2wn+1 -> vertical partner = other
+    //            n-tile (same lane), horizontal partner = lane ^ 1
+    //  TW == 16: one n-tile holds rows (2t, 2t+1) in lanes (0-15, 16-31) -> vertical partner =
+    //            lane ^ 16, horizontal partner = lane ^ 1
+    static_assert(NI == 2 || true, "");
+    const int Pp = a.P >> 1, Qp = a.Q >> 1;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ko = ko0 + wm * (32 * MI) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const float bv = (a.bias && ko < a.K) ? a.bias[ko] : 0.f;
+        float v[NI];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          v[ni] = acc[mi][ni][r] + bv;
+          v[ni] = v[ni] > 0.f ? v[ni] : 0.f;
+        }
+        if (TW >= 32) {
+          if (NI == 2) {
+            const float v01 = __shfl_xor(v[0], 1, 64), v11 = __shfl_xor(v[1], 1, 64);
+            float m = v[0];
+            int arg = 0;
+            if (v01 > m) { m = v01; arg = 1; }
+            if (v[1] > m) { m = v[1]; arg = 2; }
+            if (v11 > m) { m = v11; arg = 3; }
+            const int pidx = wn * 64 + l31;
+            const int pp = (p0 + (pidx / TW)) >> 1, qq = (q0 + (pidx % TW)) >> 1;
+            if (!(l31 & 1) && ko < a.K && pp < Pp && qq < Qp) {
+              const size_t o = (((size_t)n * a.K + ko) * Pp + pp) * Qp + qq;
+              a.pool_y[o] = m;
+              a.pool_code_out[o] = (unsigned char)(arg | (m > 0.f ? 4 : 0));
+            }
+          }
+        } else {
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            const float v01 = __shfl_xor(v[ni], 1, 64), v10 = __shfl_xor(v[ni], 16, 64),
+                        v11 = __shfl_xor(v[ni], 17, 64);
+            float m = v[ni];
+            int arg = 0;
+            if (v01 > m) { m = v01; arg = 1; }
+            if (v10 > m) { m = v10; arg = 2; }
+            if (v11 > m) { m = v11; arg = 3; }
+            const int pidx = wn * (32 * NI) + ni * 32 + l31;
+            const int pp = (p0 + (pidx / TW)) >> 1, qq = (q0 + (pidx % TW)) >> 1;
+            if (!(l31 & 17) && ko < a.K && pp < Pp && qq < Qp) {
+              const size_t o = (((size_t)n * a.K + ko) * Pp + pp) * Qp + qq;
+              a.pool_y[o] = m;
+              a.pool_code_out[o] = (unsigned char)(arg | (m > 0.f ? 4 : 0));
+            }
+          }
+        }
+      }
+    }
+    return;
+  }
 
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
@@ -610,5 +691,61 @@ extern "C" int fcd_conv2d_bwd_data(const fcd_conv_desc* d, const float* dy, cons
   rc = conv_dispatch(a, d->R, d->S, 1, d->stride, (hipStream_t)stream);
   FCD_CHECK_ARG(rc == 0, "fcd_conv2d_bwd_data: unsupported filter %dx%d stride %d", d->R, d->S, d->stride);
   FCD_LAUNCH_CHECK("conv2d_bwd_data");
+  return FCD_OK;
+}
+
+// ---------------------------------------------------------------------------
+// conv3x3 + bias + ReLU + MaxPool2d(2) in one kernel, and its data gradient
+static int pool_supported(const fcd_conv_desc* d, int out_channels, const char* who) {
+  FCD_CHECK_ARG(d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1, "%s: only 3x3 / stride 1 / pad 1", who);
+  FCD_CHECK_ARG(out_channels > 32, "%s: needs > 32 output channels of the launched GEMM (got %d)", who, out_channels);
+  FCD_CHECK_ARG(use_v2(), "%s: requires the global_load_lds kernel (FCD_CONV_V2=0 set)", who);
+  FCD_CHECK_ARG(d->P >= 2 && d->Q >= 2, "%s: map too small to pool", who);
+  return FCD_OK;
+}
+
+extern "C" int fcd_conv2d_fwd_relu_pool(const fcd_conv_desc* d, const float* x, const float* wp, const float* bias,
+                                        float* y_pool, unsigned char* code, void* stream) {
+  int rc = check_desc(d, "fcd_conv2d_fwd_relu_pool");
+  if (rc) return rc;
+  FCD_CHECK_ARG(x && wp && y_pool && code, "fcd_conv2d_fwd_relu_pool: null pointer");
+  rc = pool_supported(d, d->K, "fcd_conv2d_fwd_relu_pool");
+  if (rc) return rc;
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.wp = wp; a.bias = bias; a.y = nullptr; a.relu = 1;
+  a.pool_y = y_pool; a.pool_code_out = code;
+  a.N = d->N; a.C = d->C; a.H = d->H; a.W = d->W;
+  a.K = d->K; a.Kpad = round_up(d->K, 128);
+  a.P = d->P; a.Q = d->Q; a.pad = d->pad;
+  const double flops = 2.0 * d->N * d->K * (double)d->P * d->Q * d->C * 9;
+  const double bytes = 4.0 * ((double)d->N * d->C * d->H * d->W + 0.3125 * d->N * d->K * d->P * d->Q + (double)d->K * d->C * 9);
+  FcdProfScope prof(FCD_K_CONV_FWD, (hipStream_t)stream, flops, bytes);
+  rc = conv_dispatch(a, 3, 3, 1, 1, (hipStream_t)stream);
+  FCD_CHECK_ARG(rc == 0, "fcd_conv2d_fwd_relu_pool: dispatch failed");
+  FCD_LAUNCH_CHECK("conv2d_fwd_relu_pool");
+  return FCD_OK;
+}
+
+extern "C" int fcd_conv2d_bwd_data_pooled(const fcd_conv_desc* d, const float* dy_pool, const unsigned char* code,
+                                          const float* wp_bwd, float* dx, void* stream) {
+  int rc = check_desc(d, "fcd_conv2d_bwd_data_pooled");
+  if (rc) return rc;
+  FCD_CHECK_ARG(dy_pool && code && wp_bwd && dx, "fcd_conv2d_bwd_data_pooled: null pointer");
+  rc = pool_supported(d, d->C, "fcd_conv2d_bwd_data_pooled");
+  if (rc) return rc;
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = dy_pool; a.wp = wp_bwd; a.y = dx;
+  a.pool_code_in = code; a.Hp = d->P / 2; a.Wp = d->Q / 2;
+  a.N = d->N; a.C = d->K; a.H = d->P; a.W = d->Q;
+  a.K = d->C; a.Kpad = round_up(d->C, 128);
+  a.P = d->H; a.Q = d->W; a.pad = 1;
+  const double flops = 2.0 * d->N * d->K * (double)d->P * d->Q * d->C * 9;
+  const double bytes = 4.0 * ((double)d->N * d->C * d->H * d->W + 0.3125 * d->N * d->K * d->P * d->Q + (double)d->K * d->C * 9);
+  FcdProfScope prof(FCD_K_CONV_DGRAD, (hipStream_t)stream, flops, bytes);
+  rc = conv_dispatch(a, 3, 3, 1, 1, (hipStream_t)stream);
+  FCD_CHECK_ARG(rc == 0, "fcd_conv2d_bwd_data_pooled: dispatch failed");
+  FCD_LAUNCH_CHECK("conv2d_bwd_data_pooled");
   return FCD_OK;
 }

@@ -69,6 +69,17 @@ int fcd_conv2d_fwd(const fcd_conv_desc* d, const float* x, const float* wp, cons
  * fused-ReLU forward output; dy' = dy * [relu_out > 0] is formed while staging. */
 int fcd_conv2d_bwd_data(const fcd_conv_desc* d, const float* dy, const float* relu_out,
                         const float* wp_bwd, float* dx, void* stream);
+/* conv3x3(s1,p1) + bias + ReLU + MaxPool2d(2) in ONE kernel (the conv/ReLU/pool triples of
+ * the VGG16 stack, Loss.py:25).  Writes y_pool (N,K,P/2,Q/2) and an argmax code byte per
+ * pooled element (bits 0-1: window slot row*2+col of the first maximum, bit 2: max > 0); the
+ * full-resolution activation never goes to memory.  Needs K > 32. */
+int fcd_conv2d_fwd_relu_pool(const fcd_conv_desc* d, const float* x, const float* wp,
+                             const float* bias, float* y_pool, unsigned char* code, void* stream);
+/* Data gradient of the above: dy_pool (N,K,P/2,Q/2) + code -> dx (N,C,H,W); the max-pool and
+ * ReLU backward are folded into the kernel's patch loader.  Needs C > 32. */
+int fcd_conv2d_bwd_data_pooled(const fcd_conv_desc* d, const float* dy_pool,
+                               const unsigned char* code, const float* wp_bwd, float* dx,
+                               void* stream);
 /* dw[k][c][r][s] = sum_{n,p,q} dy[n,k,p,q] * x[n,c,p*stride+r-pad,q*stride+s-pad]
  * (plain, unpacked layout).  Needs ws of fcd_conv2d_bwd_weight_ws_bytes(). */
 size_t fcd_conv2d_bwd_weight_ws_bytes(const fcd_conv_desc* d);

@@ -97,6 +97,35 @@ def test_conv2d_fused_relu(case):
         assert (d.norm() / ref.double().norm()).item() < 1e-4, what
 
 
+@pytest.mark.parametrize('case', [(2, 64, 40, 64, 64), (1, 64, 24, 40, 128), (2, 128, 16, 16, 256), (1, 64, 13, 27, 64),
+                                  (2, 40, 8, 8, 48), (1, 64, 33, 70, 96)], ids=lambda c: 'x'.join(map(str, c)))
+def test_conv_relu_maxpool_fused(case):
+    """conv3x3+bias+ReLU+MaxPool2d(2) in one kernel vs the ATen composition, forward and data
+    gradient.  The input is built so that the branchy cases really occur: exact ties inside pooling
+    windows (first maximum must win), windows that are entirely <= 0, odd map sizes."""
+    ops = _ops()
+    N, C, H, W, K = case
+    x = rnd(N, C, H, W, seed=101)
+    x[:, :, : H // 2, : W // 2] = x[:, :, :1, :1]          # constant block => many equal conv outputs (ties)
+    w = rnd(K, C, 3, 3, seed=102, scale=(2.0 / (C * 9)) ** 0.5)
+    b = rnd(K, seed=103, scale=0.1)
+    b[: K // 4] = -50.0                                     # a quarter of the channels: all windows negative
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(F.relu(F.conv2d(xr, w, b, padding=1)), 2)
+    g = rnd(*yr.shape, seed=104)
+    yr.backward(g)
+    xg = x.cuda().requires_grad_(True)
+    wg, bg = w.cuda(), b.cuda()
+    assert ops.conv_relu_pool_supported(xg, wg)
+    y = ops.conv2d_relu_maxpool2(xg, wg, bg)
+    y.backward(g.cuda())
+    assert_close(y, yr, what='pooled y')
+    d = xg.grad.cpu().double() - xr.grad.double()
+    # near-ties (|difference| at rounding level) may pick the other slot: aggregate bound + exact bulk
+    assert (d.norm() / xr.grad.double().norm().clamp_min(1e-30)).item() < 2e-3
+    assert (d.abs() > 1e-4 * xr.grad.abs().max().item()).double().mean().item() < 5e-3
+
+
 @pytest.mark.parametrize('shape', [(2, 16, 5, 7), (1, 64, 12, 16), (3, 32, 1, 1)])
 def test_conv_transpose2x2(shape):
     ops = _ops()
