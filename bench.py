@@ -196,6 +196,16 @@ def main():
                 'avg_launch_ms': ms / max(launches, 1), 'algorithmic_gflop_per_launch': flops / max(launches, 1) / 1e9,
                 'share_of_step_time': ms / (1e3 * dt) if dt > 0 else None,
             }
+            # HBM bytes per launch of the same kernel family from the PMC counters (FETCH_SIZE /
+            # WRITE_SIZE, separate rocprofv3 passes over this very command: tools/pmc_bench.sh);
+            # bench.py cannot run the profiler on itself, so it reports the committed measurement.
+            tpath = os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')
+            if os.path.exists(tpath) and args.batch == 8 and args.bands == 13 and args.size == 256:
+                with open(tpath) as f:
+                    tj = json.load(f)
+                res['roofline']['traffic'] = tj['hbm_bytes_per_launch']
+                res['roofline']['traffic_unit'] = 'HBM bytes per launch (PMC, profiles/r01_hbm_traffic.json)'
+                res['roofline']['algorithmic_bytes_per_launch'] = (fwd['bytes'] + dg['bytes']) / max(launches, 1)
             res['kernel_families'] = {
                 k: {'ms_per_step': v['ms'] / args.steps, 'launches_per_step': v['launches'] / args.steps,
                     'tflops': (v['flops'] / (v['ms'] * 1e-3) / 1e12) if v['ms'] > 0 and v['flops'] > 0 else None,
