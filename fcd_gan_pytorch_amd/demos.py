@@ -128,3 +128,127 @@ def infer_scene(netS, ds, device, batch_size=10, prob_thresh=0.5, gt_map=(1, 2),
             grid.write_center(color, co_h[i], it)
     netS.train(was_training)
     return dict(density=density, color=color, evaluator=acc)
+
+
+def demo_rsss(dataset, device='cuda', n_channels=4, epochs_g=50, epochs_adv=100, init_batch_size=20, batch_size=12,
+              learning_rate=5e-5, perception_weight=0.1, ssim_weight=0, perception_perBand=True, l1_weight=0.02,
+              g_weight=0.5, d_weight=1, r_weight=2, prob_thresh=0.5, gt_map=(1, 2), pre_map=(0, 1), seed=0,
+              netG_state=None, log=None):
+    """Demo_RSSS.py:27-538 on a ``datasets.MultiSceneDataset`` / ``RegionTileDataset`` (tuples
+    ``(x, y, item, ref, region)``): G pre-training on the region-masked reconstruction
+    (skipped when ``netG_state`` is given, Demo_RSSS.py:167-171), netG.eval(), adversarial D/S
+    loop with the reference's LR schedules, per-epoch on-device accuracy over the owned tile
+    centres."""
+    dev = torch.device(device)
+    torch.manual_seed(seed)
+    netD = Module.Discriminator_SRGAN_simple(n_channels=n_channels).to(dev)
+    netS = Module.Segmentor(n_channels=n_channels, bilinear=True).to(dev)
+    netG = Module.Generator(n_channels=n_channels).to(dev)
+    netS.train(); netG.train(); netD.train()
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        crit = Loss.CGeneratorLoss(channel=n_channels, perception_layer=1, perception_perBand=perception_perBand).to(dev)
+    optG = optim.Adam(netG.parameters(), lr=learning_rate, betas=(0.9, 0.99))
+    optS = optim.RMSprop(netS.parameters(), lr=learning_rate)
+    optD = optim.RMSprop(netD.parameters(), lr=learning_rate)
+    hist = {'g': [], 'adv': []}
+    if netG_state is not None:
+        netG.load_state_dict(netG_state)
+        epochs_g = 0
+    for ep in range(epochs_g):                                                   # Demo_RSSS.py:175-236
+        optim.adjust_learning_rate(optG, ep, lr_start=1e-5, lr_max=3e-4, lr_warm_up_epoch=10, lr_sustain_epochs=10)
+        tot = torch.zeros((), device=dev)
+        for x, y, item, r, region in tiles.Prefetcher(_loader(dataset, init_batch_size, True, seed * 1000 + ep), dev):
+            out = steps.rsss_g_pretrain_step(netG, crit, optG, x, y, region, perception_weight, ssim_weight)
+            tot += out['g_loss'].detach() * x.shape[0] / len(dataset)
+        hist['g'].append(float(tot))
+        if log:
+            log('G pre-train epoch %d g_loss %.4f' % (ep + 1, hist['g'][-1]))
+    netG.eval()                                                                   # Demo_RSSS.py:240
+    acc = metrics.Evaluator(2)
+    for ep in range(epochs_adv):                                                  # Demo_RSSS.py:246-396
+        optim.adjust_learning_rate(optS, ep, lr_start=1e-4, lr_max=1e-3, lr_warm_up_epoch=5)
+        optim.adjust_learning_rate(optD, ep, lr_start=5e-6, lr_max=5e-5, lr_min=5e-7, lr_warm_up_epoch=5)
+        acc.reset()
+        sums = torch.zeros(3, device=dev)
+        for x, y, item, r, region in tiles.Prefetcher(_loader(dataset, batch_size, True, seed * 1000 + 500 + ep), dev):
+            out = steps.rsss_adversarial_step(netS, netD, netG, crit, optS, optD, x, y, region,
+                                              perception_weight=perception_weight, ssim_weight=ssim_weight,
+                                              l1_weight=l1_weight, g_weight=g_weight, d_weight=d_weight,
+                                              r_weight=r_weight)
+            w = x.shape[0] / len(dataset)
+            sums += torch.stack([out['d_loss'].detach(), out['s_loss'].detach(), out['g_loss'].detach()]) * w
+            valid = torch.zeros_like(out['cmap'], dtype=torch.bool)
+            for i, it in enumerate(item.tolist()):
+                r0, r1, c0, c1 = dataset.eff_range(it) if hasattr(dataset, 'eff_range') else dataset.grid.eff_range(it)
+                valid[i, :, r0:r1, c0:c1] = True
+            acc.add_batch_map(r, metrics.threshold_map(out['cmap'].detach(), prob_thresh), gt_map, pre_map, valid=valid)
+        hist['adv'].append([float(v) for v in sums] + [float(acc.Pixel_F1_score())])
+        if log:
+            log('adv epoch %d d %.4f s %.4f g %.4f F1 %.4f' % ((ep + 1,) + tuple(hist['adv'][-1])))
+    return dict(netS=netS, netD=netD, netG=netG, history=hist, evaluator=acc)
+
+
+def demo_wsss(changed_ds, unchanged_ds, device='cuda', n_channels=3, epochs_g=50, epochs_adv=50, unc_batch_size=50,
+              batch_size=15, perception_weight=0.5, ssim_weight=0, g_weight=0.2, l1_weight=1.6, d_weight=1,
+              nc_weight=1.5, seed=0, netG_state=None, log=None):
+    """Demo_WSSS.py:27-483 on datasets of (x, y, ...) tuples: G pre-training on UNCHANGED pairs
+    with cmap = 0 (Demo_WSSS.py:152-176), netG.eval(), adversarial loop over (changed, unchanged)
+    pairs re-matched every epoch (``PairingDataset.order_reset``, same seed on every rank)."""
+    from .datasets import PairingDataset
+    dev = torch.device(device)
+    torch.manual_seed(seed)
+    netD = Module.Discriminator_SRGAN_simple(n_channels).to(dev)
+    netS = Module.Segmentor(n_channels=n_channels, bilinear=True).to(dev)
+    netG = Module.Generator(n_channels=n_channels).to(dev)
+    netS.train(); netD.train(); netG.train()
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        crit = Loss.CGeneratorLoss(channel=n_channels, perception_layer=1, perception_perBand=False).to(dev)
+    optG = optim.Adam(netG.parameters(), lr=5e-4, betas=(0.9, 0.99))
+    optS = optim.RMSprop(netS.parameters(), lr=1e-3)
+    optD = optim.RMSprop(netD.parameters(), lr=1e-5)
+    hist = {'g': [], 'adv': []}
+    if netG_state is not None:
+        netG.load_state_dict(netG_state)
+        epochs_g = 0
+    if g_weight == 0:
+        epochs_g = 0
+    for ep in range(epochs_g):
+        optim.adjust_learning_rate(optG, ep, lr_start=1e-5, lr_max=3e-4, lr_warm_up_epoch=10, lr_sustain_epochs=10)
+        tot = torch.zeros((), device=dev)
+        for batch in tiles.Prefetcher(_loader(unchanged_ds, unc_batch_size, True, seed * 1000 + ep), dev):
+            x, y = batch[0], batch[1]
+            optG.zero_grad()
+            y_fake = netG(x)
+            cmap = torch.zeros((x.shape[0], 1, x.shape[2], x.shape[3]), device=dev)
+            gen, ssim, perc = crit(y, y_fake, cmap)
+            g_loss = gen + perception_weight * perc + ssim_weight * ssim
+            g_loss.backward()
+            optG.allreduce_grads()
+            optG.step()
+            tot += g_loss.detach() * x.shape[0] / len(unchanged_ds)
+        hist['g'].append(float(tot))
+        if log:
+            log('G pre-train epoch %d g_loss %.4f' % (ep + 1, hist['g'][-1]))
+    netG.eval()                                                                   # Demo_WSSS.py:206
+    pairs = PairingDataset(changed_ds, unchanged_ds, random_assign=False, seed=seed)
+    for ep in range(epochs_adv):                                                  # Demo_WSSS.py:209-323
+        optim.adjust_learning_rate(optS, ep, lr_start=1e-4, lr_max=1e-3, lr_warm_up_epoch=5)
+        optim.adjust_learning_rate(optD, ep, lr_start=1e-6, lr_max=1e-5, lr_min=1e-8, lr_warm_up_epoch=5)
+        pairs.order_reset(seed=seed * 7919 + ep)
+        sums = torch.zeros(2, device=dev)
+
+        def flat(loader):
+            for cds, ncds in loader:
+                yield (cds[0], cds[1], ncds[0], ncds[1])
+        for x, y, x_nc, y_nc in tiles.Prefetcher(flat(_loader(pairs, batch_size, True, seed * 1000 + 700 + ep)), dev):
+            out = steps.wsss_adversarial_step(netS, netD, netG, crit, optS, optD, x, y, x_nc, y_nc,
+                                              perception_weight=perception_weight, ssim_weight=ssim_weight,
+                                              g_weight=g_weight, l1_weight=l1_weight, d_weight=d_weight,
+                                              nc_weight=nc_weight)
+            sums += torch.stack([out['d_loss'].detach(), out['s_loss'].detach()]) * (x.shape[0] / len(pairs))
+        hist['adv'].append([float(v) for v in sums])
+        if log:
+            log('adv epoch %d d %.4f s %.4f' % ((ep + 1,) + tuple(hist['adv'][-1])))
+    return dict(netS=netS, netD=netD, netG=netG, history=hist)

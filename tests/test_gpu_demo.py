@@ -55,3 +55,40 @@ def test_demo_usss_end_to_end(tmp_path):
     assert cm[1, 1] == np.sum(pred & (ref[0] == 2)) and cm[0, 1] == np.sum(pred & (ref[0] == 1))
     col = tiles.read_tiff(str(tmp_path / 'color.tif'))
     assert set(np.unique(col)).issubset({0.0, 1.0, 2.0, 3.0})
+
+
+def _scene(rng, C, H, W):
+    t1 = rng.standard_normal((C, H, W)).astype(np.float32)
+    t2 = (t1 + 0.1 * rng.standard_normal((C, H, W))).astype(np.float32)
+    r0, c0 = H // 4, W // 3
+    t2[:, r0:r0 + 60, c0:c0 + 70] = rng.standard_normal((C, 60, 70))
+    ref = np.ones((1, H, W), np.uint8); ref[:, r0:r0 + 60, c0:c0 + 70] = 2
+    region = np.zeros((1, H, W), np.uint8); region[:, r0 - 10:r0 + 70, c0 - 10:c0 + 80] = 255
+    return t1, t2, ref, region
+
+
+def test_demo_rsss_and_wsss_run_end_to_end():
+    """Demo_RSSS / Demo_WSSS loop shapes on the HIP path (tiny epochs): multi-scene region tiles,
+    LR schedules, on-device evaluator over owned centres, changed/unchanged pairing."""
+    from fcd_gan_pytorch_amd import datasets, demos
+    rng = np.random.default_rng(5)
+    scenes = []
+    for hw in ((210, 230), (200, 200)):
+        t1, t2, ref, region = _scene(rng, 4, *hw)
+        scenes.append(datasets.RegionTileDataset(t1, t2, region=region, ref=ref, patch_size=(200, 200),
+                                                 overlap_padding=(10, 10)))
+    ds = datasets.MultiSceneDataset(scenes)
+    logs = []
+    out = demos.demo_rsss(ds, n_channels=4, epochs_g=1, epochs_adv=2, init_batch_size=2, batch_size=2, log=logs.append)
+    assert len(logs) == 3 and np.isfinite(out['history']['adv']).all() and np.isfinite(out['history']['g']).all()
+    cm = out['evaluator']._sync()
+    assert cm.sum() == 210 * 230 + 200 * 200          # every scene pixel scored exactly once per epoch
+    # WSSS: "changed" and "unchanged" tile sets of unequal size
+    chg = [(torch.from_numpy(_scene(rng, 3, 176, 176)[0]), torch.from_numpy(_scene(rng, 3, 176, 176)[1])) for _ in range(3)]
+    unc = []
+    for _ in range(2):
+        a = torch.from_numpy(rng.standard_normal((3, 176, 176)).astype(np.float32))
+        unc.append((a, a + 0.05 * torch.randn_like(a)))
+    out = demos.demo_wsss(chg, unc, n_channels=3, epochs_g=1, epochs_adv=1, unc_batch_size=2, batch_size=2,
+                          log=logs.append)
+    assert np.isfinite(out['history']['adv']).all() and len(out['history']['g']) == 1
