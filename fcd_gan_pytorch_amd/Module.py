@@ -53,10 +53,17 @@ class DoubleConv(nn.Module):
         return ops.bn_act(_conv(s[3], x), s[4], ops.ACT_RELU, groups=groups)
 
     def _folded_params(self):
+        s = self.double_conv
+        # key: storage + version of every tensor that enters the fold (load_state_dict / in-place
+        # edits bump the versions; fcd optimizers only run in train() mode, which drops the cache)
+        key = tuple((t.data_ptr(), t._version) for m in (s[0], s[1], s[3], s[4])
+                    for t in (m.weight, m.bias) + ((m.running_mean, m.running_var) if hasattr(m, 'running_var') else ()))
         cache = self.__dict__.get('_fcd_folded')
+        if cache is not None and self.__dict__.get('_fcd_folded_key') != key:
+            cache = None
         if cache is None:
             cache = []
-            s = self.double_conv
+            self.__dict__['_fcd_folded_key'] = key
             with torch.no_grad():
                 for conv, bn in ((s[0], s[1]), (s[3], s[4])):
                     scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)

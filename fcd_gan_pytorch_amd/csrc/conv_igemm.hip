@@ -43,6 +43,7 @@ struct ConvArgs {
   int pad;
   int nchunks;      // ceil(C / CB)
   int tiles_p, tiles_q;
+  int k_tiles, xcd_remap;   // v2 kernel: 1-D grid with the XCD-aware (k-tile fastest) order
 };
 
 template <int R, int S, int RCH, int STRIDE, int DIL, int CB, int MI, int NI, int WM, int WN, int TH,
@@ -284,12 +285,28 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_glds_kernel(ConvArgs a) {
   const int half = lane >> 5, l31 = lane & 31;
   const int wm = wave / WN, wn = wave % WN;
 
-  int bx = blockIdx.x;
+  // XCD-aware tile order.  The dispatcher hands consecutive workgroup ids to the 8 XCDs round
+  // robin (id % 8); each XCD has its own L2.  Remap so that every XCD walks a CONTIGUOUS range
+  // of "virtual" ids, and let the k-tiles of one pixel tile be adjacent virtual ids: the blocks
+  // that read the same input patch (and neighbouring patches sharing halo rows) then run on the
+  // same XCD at about the same time and the patch is fetched from HBM once instead of once per
+  // k-tile.  Placement only affects speed / traffic, never results.
+  int ktile, bx;
+  if (a.xcd_remap) {
+    const unsigned total = gridDim.x, b = blockIdx.x;
+    const unsigned q8 = total >> 3, r8 = total & 7u, xcd = b & 7u;
+    const unsigned v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
+    ktile = (int)(v % (unsigned)a.k_tiles);
+    bx = (int)(v / (unsigned)a.k_tiles);
+  } else {
+    ktile = blockIdx.y;
+    bx = blockIdx.x;
+  }
   const int tq = bx % a.tiles_q;
   bx /= a.tiles_q;
   const int tp = bx % a.tiles_p;
   const int n = bx / a.tiles_p;
-  const int ko0 = blockIdx.y * BM;
+  const int ko0 = ktile * BM;
   const int p0 = tp * TH, q0 = tq * TW;
 
   int xoff[NI];
@@ -571,6 +588,15 @@ extern "C" int fcd_conv_pack_weights(const float* w, float* wp, int K, int C, in
 
 // ---------------------------------------------------------------------------
 // dispatch
+static int xcd_remap_on() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("FCD_CONV_XCD");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v;
+}
+
 static int use_v2() {
   static int v = -1;
   if (v < 0) {
@@ -593,7 +619,10 @@ static int launch_cfg(const ConvArgs& a0, hipStream_t st) {
   if constexpr (kHasV2) {
     if (use_v2()) {
       a.nchunks = cdiv(a.C, CB2);
-      hipLaunchKernelGGL((conv_igemm_glds_kernel<R, S, RCH, STRIDE, DIL, CB2, MI, NI, WM, WN, TH, TW>), grid,
+      a.k_tiles = (int)grid.y;
+      a.xcd_remap = xcd_remap_on();
+      const dim3 grid1 = a.xcd_remap ? dim3(grid.x * grid.y) : grid;
+      hipLaunchKernelGGL((conv_igemm_glds_kernel<R, S, RCH, STRIDE, DIL, CB2, MI, NI, WM, WN, TH, TW>), grid1,
                          dim3(256), 0, st, a);
       return 0;
     }

@@ -169,6 +169,13 @@ def test_inference_path_bn_folded_vs_oracle(size, N):
     with torch.enable_grad():
         unfolded = net(x.to(DEV), y.to(DEV)).detach()
     assert (unfolded - dens).abs().max().item() <= 2e-5
-    # folding is invalidated by train()
+    # folding is invalidated by train() ...
     net.train(); net.eval()
     assert '_fcd_folded' not in net.inc.__dict__
+    # ... and by loading new weights while already in eval mode (version-keyed cache)
+    p.steps.infer_density(net, x.to(DEV), y.to(DEV))
+    sd2 = seeded_state(onets.segmentor_spec(C, 1, True), 78)
+    net.load_state_dict(sd2)
+    dens2, _ = p.steps.infer_density(net, x.to(DEV), y.to(DEV))
+    ref2 = onets.segmentor(onets.clone_state(sd2, requires_grad=False), x, y, train=False, bilinear=True)
+    assert (dens2.cpu() - ref2).abs().max().item() <= 1e-4
