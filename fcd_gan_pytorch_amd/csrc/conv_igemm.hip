@@ -248,11 +248,9 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_kernel(ConvArgs a) {
 // ds_write pass).  Both LDS buffers (filter slab + input patch) are double-buffered:
 // one s_barrier per step instead of two, and the registers freed by the filter staging
 // buy a third resident workgroup per CU.
+// channels per K-step of the v2 kernel (A/B on MI355X: 2 -> -2 %, 6 -> -5 % vs 4)
 #ifndef FCD_CB2
 #define FCD_CB2 4
-#endif
-#ifndef FCD_MFMA_PRIO
-#define FCD_MFMA_PRIO 0
 #endif
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
@@ -420,7 +418,6 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_glds_kernel(ConvArgs a) {
       FCD_GLDS_W((NR == 1) ? nxt : nxt / NR, (NR == 1) ? 0 : nxt % NR, wb ^ 1)
       if (next_patch) FCD_LOAD_X2(chunk + 1)
     }
-    __builtin_amdgcn_s_setprio(FCD_MFMA_PRIO);
     const float* wl = smem + wb * WS_SZ + woff;
     const float* xl = smem + 2 * WS_SZ + xb * XS_SZ + rr * RCH * PWP;
 #pragma unroll
@@ -442,7 +439,6 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_glds_kernel(ConvArgs a) {
         }
       }
     }
-    __builtin_amdgcn_s_setprio(0);
     if (next_patch) FCD_STORE_X2(xb ^ 1)
     __syncthreads();
   }
@@ -456,7 +452,6 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_glds_kernel(ConvArgs a) {
     //            n-tile (same lane), horizontal partner = lane ^ 1
     //  TW == 16: one n-tile holds rows (2t, 2t+1) in lanes (0-15, 16-31) -> vertical partner =
     //            lane ^ 16, horizontal partner = lane ^ 1
-    static_assert(NI == 2 || true, "");
     const int Pp = a.P >> 1, Qp = a.Q >> 1;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
