@@ -257,7 +257,10 @@ typedef __attribute__((address_space(1))) const void gbl_void_t;
 
 template <int R, int S, int RCH, int STRIDE, int DIL, int CB, int MI, int NI, int WM, int WN, int TH,
           int TW>
-__global__ __launch_bounds__(256, 3) void conv_igemm_glds_kernel(ConvArgs a) {
+#ifndef FCD_WPE
+#define FCD_WPE 3
+#endif
+__global__ __launch_bounds__(256, FCD_WPE) void conv_igemm_glds_kernel(ConvArgs a) {
   constexpr int BM = 32 * MI * WM;
   constexpr int BN = 32 * NI * WN;
   static_assert(WM * WN == 4, "4 waves");
