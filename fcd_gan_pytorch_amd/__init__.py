@@ -23,3 +23,13 @@ def install_as_reference_modules():
     sys.modules['Module'] = Module
     sys.modules['Loss'] = Loss
     sys.modules['ssim'] = ssim
+
+
+def set_sync_batchnorm(enabled=True, group=None):
+    """Optional SyncBN: train-mode BatchNorm statistics (and the two backward sums)
+    are all-reduced over ``group`` so that a data-parallel run reproduces the single-device
+    large-batch numerics of the reference.  Off by default (per-replica statistics, standard DDP
+    semantics; the headline throughput is measured with it off)."""
+    from . import _ops
+    _ops.SYNC_BN['enabled'] = bool(enabled)
+    _ops.SYNC_BN['group'] = group

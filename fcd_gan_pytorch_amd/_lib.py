@@ -55,6 +55,12 @@ _SIGS = {
                                P, P, c_int, P, c_float, P, c_size_t, P]),
     'fcd_bn_act_bwd': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_float, c_int, P, P,
                                c_int, P, c_float, P, P, P, P, c_size_t, P]),
+    'fcd_bn_partial_stats': (c_int, [P, P, c_int, c_int, c_int, c_int, P, c_size_t, P]),
+    'fcd_bn_act_fwd_from_stats': (c_int, [P, P, c_int, c_int, c_int, c_int, P, c_double, P, P, P, P, c_float, c_float,
+                                          P, P, c_int, P, c_float, P, c_size_t, P]),
+    'fcd_bn_bwd_partial': (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, c_int, P, c_float, P, c_size_t, P]),
+    'fcd_bn_bwd_from_sums': (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, c_double, P, P, P, P, c_int, P, c_float,
+                                     P, c_size_t, P]),
     'fcd_maxpool2_fwd': (c_int, [P, P, c_int, c_int, c_int, P]),
     'fcd_maxpool2_bwd': (c_int, [P, P, P, c_int, c_int, c_int, P]),
     'fcd_upsample2x_fwd': (c_int, [P, P, c_int, c_int, c_int, P]),

@@ -216,6 +216,17 @@ def conv_transpose2x2(x, weight, bias=None):
 
 
 # ----------------------------------------------------------------- BN + activation
+SYNC_BN = {'enabled': False, 'group': None}     # see fcd_gan_pytorch_amd.set_sync_batchnorm
+
+
+def _sync_world():
+    import torch.distributed as dist
+    if SYNC_BN['enabled'] and dist.is_available() and dist.is_initialized():
+        w = dist.get_world_size(SYNC_BN['group'])
+        return w if w > 1 else 0
+    return 0
+
+
 class _BnAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, slope, running_mean, running_var, training, momentum, eps, groups, act,
@@ -229,28 +240,59 @@ class _BnAct(torch.autograd.Function):
             save_mean = torch.empty(groups * C, dtype=torch.float32, device=x.device)
             save_invstd = torch.empty(groups * C, dtype=torch.float32, device=x.device)
         ws = _ws(lib.fcd_bn_act_ws_bytes(C, groups), x.device)
-        check(lib.fcd_bn_act_fwd(_p(x), _p(y), N, C, H * W, groups, int(has_bn), _p(gamma), _p(beta),
-                                 _p(running_mean), _p(running_var), float(momentum), float(eps), int(training),
-                                 _p(save_mean), _p(save_invstd), act, _p(slope), float(slope_imm), _p(ws),
-                                 ws.numel(), _stream()), 'fcd_bn_act_fwd')
+        world = _sync_world() if (has_bn and training) else 0
+        if world:
+            import torch.distributed as dist
+            sums = torch.empty(groups * C * 2, dtype=torch.float64, device=x.device)
+            check(lib.fcd_bn_partial_stats(_p(x), _p(sums), N, C, H * W, groups, _p(ws), ws.numel(), _stream()),
+                  'fcd_bn_partial_stats')
+            dist.all_reduce(sums, group=SYNC_BN['group'])
+            count = float(N // groups) * H * W * world
+            check(lib.fcd_bn_act_fwd_from_stats(_p(x), _p(y), N, C, H * W, groups, _p(sums), count, _p(gamma), _p(beta),
+                                                _p(running_mean), _p(running_var), float(momentum), float(eps),
+                                                _p(save_mean), _p(save_invstd), act, _p(slope), float(slope_imm),
+                                                _p(ws), ws.numel(), _stream()), 'fcd_bn_act_fwd_from_stats')
+        else:
+            check(lib.fcd_bn_act_fwd(_p(x), _p(y), N, C, H * W, groups, int(has_bn), _p(gamma), _p(beta),
+                                     _p(running_mean), _p(running_var), float(momentum), float(eps), int(training),
+                                     _p(save_mean), _p(save_invstd), act, _p(slope), float(slope_imm), _p(ws),
+                                     ws.numel(), _stream()), 'fcd_bn_act_fwd')
         ctx.save_for_backward(x, gamma, beta, slope, save_mean, save_invstd, running_mean, running_var)
-        ctx.cfg = (bool(training), float(eps), groups, act, float(slope_imm), has_bn)
+        ctx.cfg = (bool(training), float(eps), groups, act, float(slope_imm), has_bn, world)
         return y
 
     @staticmethod
     def backward(ctx, dz):
         x, gamma, beta, slope, save_mean, save_invstd, running_mean, running_var = ctx.saved_tensors
-        training, eps, groups, act, slope_imm, has_bn = ctx.cfg
+        training, eps, groups, act, slope_imm, has_bn, world = ctx.cfg
         dz = _dev(dz, 'bn grad')
         N, C, H, W = x.shape
         dx = torch.empty_like(x)
         dgamma = dbeta = dslope = None
+        ws = _ws(lib.fcd_bn_act_ws_bytes(C, groups), x.device)
+        if world:
+            import torch.distributed as dist
+            part = torch.empty(groups * C * 3, dtype=torch.float64, device=x.device)
+            check(lib.fcd_bn_bwd_partial(_p(dz), _p(x), _p(part), N, C, H * W, groups, _p(gamma), _p(beta),
+                                         _p(save_mean), _p(save_invstd), act, _p(slope), slope_imm, _p(ws), ws.numel(),
+                                         _stream()), 'fcd_bn_bwd_partial')
+            local = part.view(groups, C, 3)
+            dbeta = local[:, :, 0].sum(0).float()          # parameter gradients stay LOCAL sums
+            dgamma = local[:, :, 1].sum(0).float()         # (the DP gradient all-reduce averages them)
+            if slope is not None and ctx.needs_input_grad[3]:
+                dslope = local[:, :, 2].sum().float().view(slope.shape)
+            tot = part.clone()
+            dist.all_reduce(tot, group=SYNC_BN['group'])
+            count = float(N // groups) * H * W * world
+            check(lib.fcd_bn_bwd_from_sums(_p(dz), _p(x), _p(dx), N, C, H * W, groups, _p(tot), count, _p(gamma),
+                                           _p(beta), _p(save_mean), _p(save_invstd), act, _p(slope), slope_imm, _p(ws),
+                                           ws.numel(), _stream()), 'fcd_bn_bwd_from_sums')
+            return dx, dgamma, dbeta, dslope, None, None, None, None, None, None, None, None
         if has_bn and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
             dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
             dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
         if slope is not None and ctx.needs_input_grad[3]:
             dslope = torch.empty(1, dtype=torch.float32, device=x.device)
-        ws = _ws(lib.fcd_bn_act_ws_bytes(C, groups), x.device)
         check(lib.fcd_bn_act_bwd(_p(dz), _p(x), _p(dx), N, C, H * W, groups, int(has_bn), _p(gamma), _p(beta),
                                  _p(running_mean), _p(running_var), eps, int(training), _p(save_mean),
                                  _p(save_invstd), act, _p(slope), slope_imm, _p(dgamma), _p(dbeta), _p(dslope),

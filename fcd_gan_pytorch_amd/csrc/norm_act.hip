@@ -380,3 +380,116 @@ extern "C" int fcd_bn_act_bwd(const float* dz, const float* x, float* dx, int N,
   return FCD_OK;
 }
 
+
+// ---------------------------------------------------------------------------
+// Synchronised BatchNorm (optional): the same kernels split at the point where the
+// per-channel sums exist, so the host can all-reduce them over RCCL between the two halves.
+//   fwd:  fcd_bn_partial_stats -> all-reduce(sum) -> fcd_bn_act_fwd_from_stats
+//   bwd:  fcd_bn_bwd_partial   -> all-reduce(sum) -> fcd_bn_bwd_from_sums
+__global__ void bn_sum_parts_kernel(const double* __restrict__ part, double* __restrict__ out, int GC, int split,
+                                    int nvals) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= GC) return;
+  for (int v = 0; v < nvals; ++v) {
+    double s = 0.0;
+    for (int k = 0; k < split; ++k) s += part[((size_t)i * split + k) * 3 + v];
+    out[(size_t)i * nvals + v] = s;
+  }
+}
+
+__global__ void bn_spread_sums_kernel(const double* __restrict__ in, double* __restrict__ part3, int GC, int nvals) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= GC) return;
+  for (int v = 0; v < 3; ++v) part3[(size_t)i * 3 + v] = v < nvals ? in[(size_t)i * nvals + v] : 0.0;
+}
+
+extern "C" int fcd_bn_partial_stats(const float* x, double* out, int N, int C, int HW, int groups, void* ws,
+                                    size_t ws_bytes, void* stream) {
+  FCD_CHECK_ARG(x && out && N > 0 && C > 0 && HW > 0 && groups > 0 && N % groups == 0, "fcd_bn_partial_stats: bad geometry");
+  if (!ws || ws_bytes < fcd_bn_act_ws_bytes(C, groups)) {
+    fcd_set_error("fcd_bn_partial_stats: workspace too small");
+    return FCD_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  BnWs w = carve(ws, C, groups);
+  const int Ng = N / groups;
+  const int split = pick_split(C, groups, (long long)Ng * HW);
+  FcdProfScope prof(FCD_K_NORM, st, 0.0, 4.0 * N * C * (double)HW);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(C, groups, split), dim3(256), 0, st, x, w.part, C, HW, Ng, split);
+  hipLaunchKernelGGL(bn_sum_parts_kernel, dim3(cdiv(C * groups, 128)), dim3(128), 0, st, (const double*)w.part, out,
+                     C * groups, split, 2);
+  FCD_LAUNCH_CHECK("bn_partial_stats");
+  return FCD_OK;
+}
+
+extern "C" int fcd_bn_act_fwd_from_stats(const float* x, float* y, int N, int C, int HW, int groups,
+                                         const double* sums, double count, const float* gamma, const float* beta,
+                                         float* running_mean, float* running_var, float momentum, float eps,
+                                         float* save_mean, float* save_invstd, int act, const float* slope,
+                                         float slope_imm, void* ws, size_t ws_bytes, void* stream) {
+  FCD_CHECK_ARG(x && y && sums && gamma && beta && save_mean && save_invstd && count > 0 && N % groups == 0,
+                "fcd_bn_act_fwd_from_stats: bad arguments");
+  if (!ws || ws_bytes < fcd_bn_act_ws_bytes(C, groups)) {
+    fcd_set_error("fcd_bn_act_fwd_from_stats: workspace too small");
+    return FCD_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  BnWs w = carve(ws, C, groups);
+  FcdProfScope prof(FCD_K_NORM, st, 0.0, 8.0 * N * C * (double)HW);
+  hipLaunchKernelGGL(bn_spread_sums_kernel, dim3(cdiv(C * groups, 128)), dim3(128), 0, st, sums, w.part, C * groups, 2);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, (const double*)w.part, C, groups, 1,
+                     count, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, w.scale,
+                     w.shift);
+  hipLaunchKernelGGL(bn_act_apply_kernel, plane_grid(N * C, HW), dim3(256), 0, st, x, y, C, HW, N / groups, 1,
+                     (const float*)w.scale, (const float*)w.shift, act, slope, slope_imm);
+  FCD_LAUNCH_CHECK("bn_act_fwd_from_stats");
+  return FCD_OK;
+}
+
+extern "C" int fcd_bn_bwd_partial(const float* dz, const float* x, double* out, int N, int C, int HW, int groups,
+                                  const float* gamma, const float* beta, const float* save_mean,
+                                  const float* save_invstd, int act, const float* slope, float slope_imm, void* ws,
+                                  size_t ws_bytes, void* stream) {
+  FCD_CHECK_ARG(dz && x && out && gamma && beta && save_mean && save_invstd && N % groups == 0,
+                "fcd_bn_bwd_partial: bad arguments");
+  if (!ws || ws_bytes < fcd_bn_act_ws_bytes(C, groups)) {
+    fcd_set_error("fcd_bn_bwd_partial: workspace too small");
+    return FCD_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  BnWs w = carve(ws, C, groups);
+  const int Ng = N / groups;
+  const int split = pick_split(C, groups, (long long)Ng * HW);
+  FcdProfScope prof(FCD_K_NORM, st, 0.0, 8.0 * N * C * (double)HW);
+  hipLaunchKernelGGL(bn_train_prep_kernel, dim3(cdiv(C * groups, 128)), dim3(128), 0, st, C, groups, gamma, beta,
+                     save_mean, save_invstd, w.scale, w.shift);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, groups, split), dim3(256), 0, st, dz, x, w.part, C, HW, Ng, split, 1,
+                     (const float*)w.scale, (const float*)w.shift, save_mean, save_invstd, act, slope, slope_imm);
+  hipLaunchKernelGGL(bn_sum_parts_kernel, dim3(cdiv(C * groups, 128)), dim3(128), 0, st, (const double*)w.part, out,
+                     C * groups, split, 3);
+  FCD_LAUNCH_CHECK("bn_bwd_partial");
+  return FCD_OK;
+}
+
+extern "C" int fcd_bn_bwd_from_sums(const float* dz, const float* x, float* dx, int N, int C, int HW, int groups,
+                                    const double* sums, double count, const float* gamma, const float* beta,
+                                    const float* save_mean, const float* save_invstd, int act, const float* slope,
+                                    float slope_imm, void* ws, size_t ws_bytes, void* stream) {
+  FCD_CHECK_ARG(dz && x && dx && sums && gamma && beta && save_mean && save_invstd && count > 0 && N % groups == 0,
+                "fcd_bn_bwd_from_sums: bad arguments");
+  if (!ws || ws_bytes < fcd_bn_act_ws_bytes(C, groups)) {
+    fcd_set_error("fcd_bn_bwd_from_sums: workspace too small");
+    return FCD_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  BnWs w = carve(ws, C, groups);
+  FcdProfScope prof(FCD_K_NORM, st, 0.0, 12.0 * N * C * (double)HW);
+  hipLaunchKernelGGL(bn_train_prep_kernel, dim3(cdiv(C * groups, 128)), dim3(128), 0, st, C, groups, gamma, beta,
+                     save_mean, save_invstd, w.scale, w.shift);
+  hipLaunchKernelGGL(bn_spread_sums_kernel, dim3(cdiv(C * groups, 128)), dim3(128), 0, st, sums, w.fin, C * groups, 3);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, plane_grid(N * C, HW), dim3(256), 0, st, dz, x, dx, C, HW, N / groups, 1, 1,
+                     (const float*)w.scale, (const float*)w.shift, save_mean, save_invstd, (const double*)w.fin,
+                     1.0 / count, act, slope, slope_imm);
+  FCD_LAUNCH_CHECK("bn_bwd_from_sums");
+  return FCD_OK;
+}

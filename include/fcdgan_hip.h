@@ -121,6 +121,30 @@ int fcd_bn_act_bwd(const float* dz, const float* x, float* dx, int N, int C, int
                    float* dgamma, float* dbeta, float* dslope, void* ws, size_t ws_bytes,
                    void* stream);
 
+/* Synchronised BatchNorm (optional; reproduces the reference's single-device large-batch
+ * statistics under data parallelism): the forward / backward above split where the per-channel
+ * sums exist so the host can all-reduce them (RCCL) in between.  Sums are fp64:
+ *   stats  out[(g*C+c)*2 + {0,1}] = {sum x, sum x^2} of THIS rank's samples
+ *   bwd    out[(g*C+c)*3 + {0,1,2}] = {sum dy', sum dy'*xhat, PReLU-slope term}
+ * `count` = samples per group x HW summed over all ranks. */
+int fcd_bn_partial_stats(const float* x, double* out, int N, int C, int HW, int groups, void* ws,
+                         size_t ws_bytes, void* stream);
+int fcd_bn_act_fwd_from_stats(const float* x, float* y, int N, int C, int HW, int groups,
+                              const double* sums, double count, const float* gamma,
+                              const float* beta, float* running_mean, float* running_var,
+                              float momentum, float eps, float* save_mean, float* save_invstd,
+                              int act, const float* slope, float slope_imm, void* ws,
+                              size_t ws_bytes, void* stream);
+int fcd_bn_bwd_partial(const float* dz, const float* x, double* out, int N, int C, int HW,
+                       int groups, const float* gamma, const float* beta, const float* save_mean,
+                       const float* save_invstd, int act, const float* slope, float slope_imm,
+                       void* ws, size_t ws_bytes, void* stream);
+int fcd_bn_bwd_from_sums(const float* dz, const float* x, float* dx, int N, int C, int HW,
+                         int groups, const double* sums, double count, const float* gamma,
+                         const float* beta, const float* save_mean, const float* save_invstd,
+                         int act, const float* slope, float slope_imm, void* ws, size_t ws_bytes,
+                         void* stream);
+
 /* ---- pooling / resampling --------------------------------------------------
  * nn.MaxPool2d(2) Module.py:43 and VGG pools (Loss.py:25); nn.Upsample(x2,
  * bilinear, align_corners=True) Module.py:60; F.avg_pool2d(k2, padding=s%2)
