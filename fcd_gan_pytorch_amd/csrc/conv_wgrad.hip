@@ -52,6 +52,58 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
   }
 }
 
+// 64x64 tile, float4 on both sides (HW % 4 == 0): 256-B rows in, 256-B channel rows out
+__global__ __launch_bounds__(256) void nchw_to_nhwc_v4_kernel(const float* __restrict__ src,
+                                                              const float* __restrict__ mask,
+                                                              float* __restrict__ dst, int C, int HW, int Cp) {
+  __shared__ float tile[64][65];
+  const int n = blockIdx.z;
+  const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int t = threadIdx.x;
+  const float* s = src + (size_t)n * C * HW;
+  const float* m = mask ? mask + (size_t)n * C * HW : nullptr;
+  float* d = dst + (size_t)n * HW * Cp;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int idx = t + j * 256;          // 64 channel rows x 16 float4
+    const int cr = idx >> 4, p4 = (idx & 15) * 4;
+    const int c = c0 + cr, p = p0 + p4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < C && p < HW) {                // HW % 4 == 0 => the whole float4 is in range
+      v = *reinterpret_cast<const float4*>(s + (size_t)c * HW + p);
+      if (m) {
+        const float4 k = *reinterpret_cast<const float4*>(m + (size_t)c * HW + p);
+        if (!(k.x > 0.f)) v.x = 0.f;
+        if (!(k.y > 0.f)) v.y = 0.f;
+        if (!(k.z > 0.f)) v.z = 0.f;
+        if (!(k.w > 0.f)) v.w = 0.f;
+      }
+    }
+    tile[cr][p4 + 0] = v.x; tile[cr][p4 + 1] = v.y; tile[cr][p4 + 2] = v.z; tile[cr][p4 + 3] = v.w;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int idx = t + j * 256;          // 64 pixel rows x 16 float4 of channels
+    const int pr = idx >> 4, c4 = (idx & 15) * 4;
+    const int p = p0 + pr, c = c0 + c4;
+    if (p < HW && c < Cp) {               // Cp % 64 == 0
+      const float4 v = make_float4(tile[c4 + 0][pr], tile[c4 + 1][pr], tile[c4 + 2][pr], tile[c4 + 3][pr]);
+      *reinterpret_cast<float4*>(d + (size_t)p * Cp + c) = v;
+    }
+  }
+}
+
+static void launch_transpose(const float* src, const float* mask, float* dst, int N, int C, int HW, int Cp,
+                             hipStream_t st) {
+  if ((HW & 3) == 0)
+    hipLaunchKernelGGL(nchw_to_nhwc_v4_kernel, dim3(cdiv(HW, 64), Cp / 64, N), dim3(256), 0, st, src, mask, dst, C, HW,
+                       Cp);
+  else
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(cdiv(HW, 32), Cp / 32, N), dim3(256), 0, st, src, mask, dst, C, HW,
+                       Cp);
+}
+
 struct WgradArgs {
   const float* xt;    // [N][H][W][Cp]
   const float* dyt;   // [N][P][Q][Kp]
@@ -450,11 +502,9 @@ extern "C" int fcd_conv2d_bwd_weight(const fcd_conv_desc* d, const float* x, con
   }
   {
     const int HW = d->H * d->W;
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(cdiv(HW, 32), pl.Cp / 32, d->N), dim3(256), 0, st, x,
-                       (const float*)nullptr, xt, d->C, HW, pl.Cp);
+    launch_transpose(x, nullptr, xt, d->N, d->C, HW, pl.Cp, st);
     const int PQ = d->P * d->Q;
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(cdiv(PQ, 32), pl.Kp / 32, d->N), dim3(256), 0, st, dy, relu_out, dyt, d->K,
-                       PQ, pl.Kp);
+    launch_transpose(dy, relu_out, dyt, d->N, d->K, PQ, pl.Kp, st);
   }
   WgradArgs a;
   memset(&a, 0, sizeof(a));
