@@ -200,7 +200,49 @@ class Generator(nn.Module):
         self.block7 = nn.Sequential(nn.Conv2d(64, 64, kernel_size=3, padding=1), nn.BatchNorm2d(64))
         self.block8 = nn.Conv2d(64, n_channels, kernel_size=9, padding=4)
 
+    def _folded(self):
+        """eval-mode BN folded into the preceding conv (filters cached, keyed by tensor versions)."""
+        pairs = [(blk.conv1, blk.bn1) for blk in (self.block2, self.block3, self.block4, self.block5, self.block6)]
+        pairs += [(blk.conv2, blk.bn2) for blk in (self.block2, self.block3, self.block4, self.block5, self.block6)]
+        pairs.append((self.block7[0], self.block7[1]))
+        key = tuple((t.data_ptr(), t._version) for c, b in pairs
+                    for t in (c.weight, c.bias, b.weight, b.bias, b.running_mean, b.running_var))
+        hit = self.__dict__.get('_fcd_folded')
+        if hit is None or hit[0] != key:
+            out = []
+            with torch.no_grad():
+                for conv, bn in pairs:
+                    scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+                    out.append(((conv.weight * scale.view(-1, 1, 1, 1)).contiguous(),
+                                ((conv.bias - bn.running_mean) * scale + bn.bias).contiguous()))
+            hit = (key, out)
+            self.__dict__['_fcd_folded'] = hit
+        return hit[1]
+
+    def _infer(self, x):
+        """eval + no_grad (the adversarial phases, Demo_RSSS.py:240,319 / Demo_WSSS.py:206,307): 13
+        kernels, no elementwise pass -- BN folded, PReLU and the skip adds in the conv epilogues."""
+        f = self._folded()
+        c1 = self.block1[0]
+        b1 = ops.conv2d_infer(x, c1.weight, c1.bias, 1, 4, ops.ACT_PRELU, slope=self.block1[1].weight)
+        h = b1
+        for i, blk in enumerate((self.block2, self.block3, self.block4, self.block5, self.block6)):
+            r = ops.conv2d_infer(h, f[i][0], f[i][1], 1, 1, ops.ACT_PRELU, slope=blk.prelu.weight)
+            h = ops.conv2d_infer(r, f[5 + i][0], f[5 + i][1], 1, 1, ops.ACT_NONE, residual=h)
+        s = ops.conv2d_infer(h, f[10][0], f[10][1], 1, 1, ops.ACT_NONE, residual=b1)
+        return ops.conv2d_infer(s, self.block8.weight, self.block8.bias, 1, 4)
+
+    def train(self, mode=True):
+        self.__dict__.pop('_fcd_folded', None)
+        return super().train(mode)
+
+    def _apply(self, fn, *a, **k):
+        self.__dict__.pop('_fcd_folded', None)
+        return super()._apply(fn, *a, **k)
+
     def forward(self, x):
+        if not self.training and not torch.is_grad_enabled():
+            return self._infer(x)
         b1 = ops.bn_act(_conv(self.block1[0], x), None, ops.ACT_PRELU, slope=self.block1[1].weight)
         h = b1
         for blk in (self.block2, self.block3, self.block4, self.block5, self.block6):

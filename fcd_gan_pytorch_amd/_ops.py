@@ -122,6 +122,22 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, relu=False):
     return _Conv2d.apply(x, weight, bias, int(stride), int(padding), bool(relu))
 
 
+@torch.no_grad()
+def conv2d_infer(x, weight, bias, stride=1, padding=0, act=ACT_NONE, slope=None, slope_imm=0.0, residual=None):
+    """Inference-only convolution with the general fused epilogue:
+    ``act(conv(x, w) + b) + residual`` in ONE kernel (no autograd graph)."""
+    x = _dev(x, 'conv input')
+    d = _desc(x.shape, weight.shape, int(stride), int(padding))
+    y = torch.empty((d.N, d.K, d.P, d.Q), dtype=torch.float32, device=x.device)
+    wp = packed_weight(weight, 0)
+    res = _dev(residual, 'residual') if residual is not None else None
+    if res is not None and res.shape != y.shape:
+        raise _lib.FcdError('conv2d_infer: residual shape %s != output shape %s' % (tuple(res.shape), tuple(y.shape)))
+    check(lib.fcd_conv2d_fwd_ex(ctypes.byref(d), _p(x), _p(wp), _p(bias), _p(y), act, _p(slope), float(slope_imm),
+                                _p(res), _stream()), 'fcd_conv2d_fwd_ex')
+    return y
+
+
 class _ConvReluPool(torch.autograd.Function):
     """conv3x3 + bias + ReLU + MaxPool2d(2) as one kernel (frozen filters only: the VGG stack).
     Saves just the 1-byte argmax code per pooled element for the backward pass."""

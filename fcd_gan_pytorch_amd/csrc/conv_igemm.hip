@@ -28,6 +28,13 @@ struct ConvArgs {
   const float* mask;  // optional, same shape as x: x is read as x * (mask > 0)  (ReLU backward fused in)
   float* y;
   int relu;           // epilogue: y = max(y, 0)
+  // generalised epilogue (inference fusions): slope activation y = y > 0 ? y : y*slope (PReLU /
+  // LeakyReLU; slope read from device memory when slope_ptr != NULL) and a residual tensor of the
+  // output's shape added AFTER the activation (ResidualBlock / block7 skip adds, Module.py:171,190)
+  int act_slope;
+  const float* slope_ptr;
+  float slope_imm;
+  const float* residual;
   // fused MaxPool2d(2) (v2 kernel only).  Forward: the epilogue writes the 2x2-pooled ReLU
   // output to pool_y and an argmax code byte (bits 0-1: window slot row*2+col, bit 2: max > 0)
   // to pool_code_out INSTEAD of y.  Data gradient: x is the POOLED gradient (N,C,H/2,W/2) and
@@ -234,7 +241,10 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_kernel(ConvArgs a) {
           float v = acc[mi][ni][r];
           if (a.bias) v += a.bias[ko];
           if (a.relu) v = v > 0.f ? v : 0.f;
-          a.y[(((size_t)n * a.K + ko) * a.P + p) * a.Q + q] = v;
+          if (a.act_slope) v = v > 0.f ? v : v * (a.slope_ptr ? a.slope_ptr[0] : a.slope_imm);
+          const size_t yo = (((size_t)n * a.K + ko) * a.P + p) * a.Q + q;
+          if (a.residual) v += a.residual[yo];
+          a.y[yo] = v;
         }
       }
     }
@@ -522,7 +532,10 @@ __global__ __launch_bounds__(256, FCD_WPE) void conv_igemm_glds_kernel(ConvArgs 
           float v = acc[mi][ni][r];
           if (a.bias) v += a.bias[ko];
           if (a.relu) v = v > 0.f ? v : 0.f;
-          a.y[(((size_t)n * a.K + ko) * a.P + p) * a.Q + q] = v;
+          if (a.act_slope) v = v > 0.f ? v : v * (a.slope_ptr ? a.slope_ptr[0] : a.slope_imm);
+          const size_t yo = (((size_t)n * a.K + ko) * a.P + p) * a.Q + q;
+          if (a.residual) v += a.residual[yo];
+          a.y[yo] = v;
         }
       }
     }
@@ -674,14 +687,27 @@ static int check_desc(const fcd_conv_desc* d, const char* who) {
   return FCD_OK;
 }
 
+extern "C" int fcd_conv2d_fwd_ex(const fcd_conv_desc* d, const float* x, const float* wp, const float* bias,
+                                 float* y, int act, const float* slope_ptr, float slope_imm, const float* residual,
+                                 void* stream);
+
 extern "C" int fcd_conv2d_fwd(const fcd_conv_desc* d, const float* x, const float* wp, const float* bias,
                               float* y, int fuse_relu, void* stream) {
+  return fcd_conv2d_fwd_ex(d, x, wp, bias, y, fuse_relu ? FCD_ACT_RELU : FCD_ACT_NONE, nullptr, 0.f, nullptr, stream);
+}
+
+extern "C" int fcd_conv2d_fwd_ex(const fcd_conv_desc* d, const float* x, const float* wp, const float* bias,
+                                 float* y, int act, const float* slope_ptr, float slope_imm, const float* residual,
+                                 void* stream) {
   int rc = check_desc(d, "fcd_conv2d_fwd");
   if (rc) return rc;
   FCD_CHECK_ARG(x && wp && y, "fcd_conv2d_fwd: null pointer");
   ConvArgs a;
   memset(&a, 0, sizeof(a));
-  a.x = x; a.wp = wp; a.bias = bias; a.y = y; a.relu = fuse_relu ? 1 : 0;
+  FCD_CHECK_ARG(act >= FCD_ACT_NONE && act <= FCD_ACT_PRELU, "fcd_conv2d_fwd: bad activation code %d", act);
+  a.x = x; a.wp = wp; a.bias = bias; a.y = y; a.relu = act == FCD_ACT_RELU ? 1 : 0;
+  a.act_slope = (act == FCD_ACT_LEAKY || act == FCD_ACT_PRELU) ? 1 : 0;
+  a.slope_ptr = slope_ptr; a.slope_imm = slope_imm; a.residual = residual;
   a.N = d->N; a.C = d->C; a.H = d->H; a.W = d->W;
   a.K = d->K; a.Kpad = round_up(d->K, 128);
   a.P = d->P; a.Q = d->Q; a.pad = d->pad;

@@ -64,6 +64,13 @@ int fcd_conv_pack_weights(const float* w, float* wp, int K, int C, int R, int S,
  * conv+ReLU pairs of the VGG16 stack, Loss.py:25).  wp: mode-0 packed weights. */
 int fcd_conv2d_fwd(const fcd_conv_desc* d, const float* x, const float* wp, const float* bias,
                    float* y, int fuse_relu, void* stream);
+/* Forward with the general fused epilogue (inference paths):
+ *   y = act(conv(x, w) + bias) + residual
+ * act: FCD_ACT_*; slope from device memory (slope_ptr, the PReLU weight) or slope_imm;
+ * residual: optional tensor of y's shape (ResidualBlock / block7 skip adds, Module.py:171,190). */
+int fcd_conv2d_fwd_ex(const fcd_conv_desc* d, const float* x, const float* wp, const float* bias,
+                      float* y, int act, const float* slope_ptr, float slope_imm,
+                      const float* residual, void* stream);
 /* dx = conv_transpose(dy', w): desc describes the FORWARD conv; wp_bwd: mode-1
  * packed weights.  dx has shape (N,C,H,W).  relu_out (optional, shape of dy): the
  * fused-ReLU forward output; dy' = dy * [relu_out > 0] is formed while staging. */

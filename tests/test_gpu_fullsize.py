@@ -179,3 +179,62 @@ def test_inference_path_bn_folded_vs_oracle(size, N):
     dens2, _ = p.steps.infer_density(net, x.to(DEV), y.to(DEV))
     ref2 = onets.segmentor(onets.clone_state(sd2, requires_grad=False), x, y, train=False, bilinear=True)
     assert (dens2.cpu() - ref2).abs().max().item() <= 1e-4
+
+
+@pytest.mark.parametrize('act', ['none', 'relu', 'prelu', 'leaky'])
+@pytest.mark.parametrize('case', [(2, 64, 40, 64, 3, 1), (2, 13, 33, 64, 9, 4), (1, 64, 24, 13, 9, 4), (2, 24, 20, 16, 3, 1)],
+                         ids=lambda c: 'x'.join(map(str, c)))
+def test_conv2d_infer_epilogue(case, act):
+    """y = act(conv(x) + b) + residual in one kernel vs torch fp64 (all kernel families: glds 3x3,
+    register-staged 9x9, BM=32)."""
+    ops = pkg()._ops
+    N, C, H, K, R, pad = case
+    g0 = torch.Generator(device=DEV).manual_seed(sum(case))
+    x = torch.randn(N, C, H, H, device=DEV, generator=g0)
+    w = torch.randn(K, C, R, R, device=DEV, generator=g0) * (2.0 / (C * R * R)) ** 0.5
+    b = torch.randn(K, device=DEV, generator=g0)
+    res = torch.randn(N, K, H, H, device=DEV, generator=g0)
+    slope = torch.tensor([0.25], device=DEV)
+    code = {'none': ops.ACT_NONE, 'relu': ops.ACT_RELU, 'prelu': ops.ACT_PRELU, 'leaky': ops.ACT_LEAKY}[act]
+    got = ops.conv2d_infer(x, w, b, 1, pad, code, slope=slope if act == 'prelu' else None, slope_imm=0.2, residual=res)
+    ref = torch.nn.functional.conv2d(x.double().cpu(), w.double().cpu(), b.double().cpu(), 1, pad)
+    if act == 'relu':
+        ref = ref.clamp_min(0)
+    elif act == 'prelu':
+        ref = torch.where(ref > 0, ref, ref * 0.25)
+    elif act == 'leaky':
+        ref = torch.where(ref > 0, ref, ref * 0.2)
+    ref = ref + res.double().cpu()
+    assert (got.double().cpu() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    with pytest.raises(Exception):
+        ops.conv2d_infer(x, w, b, 1, pad, code, residual=res[:, :1])
+
+
+@pytest.mark.parametrize('size,N', [(256, 2), (200, 1), (36, 3)])
+def test_generator_inference_path_vs_oracle(size, N):
+    """netG.eval() + no_grad (Demo_RSSS.py:240, Demo_WSSS.py:206): BN folded, PReLU and the skip adds
+    in the conv epilogues -- vs the oracle's eval-mode generator and vs the unfused eval path."""
+    p = pkg()
+    C = 13
+    sd = seeded_state(onets.generator_spec(C), 31)
+    net = p.Module.Generator(C)
+    net.load_state_dict(sd)
+    net.to(DEV).eval()
+    x, _, _ = seeded_tiles(size + 5, N, C, size, size)
+    with torch.no_grad():
+        got = net(x.to(DEV))
+    ref = onets.generator(onets.clone_state(sd, requires_grad=False), x, train=False)
+    scale = ref.abs().max().item()
+    assert (got.cpu() - ref).abs().max().item() <= 1e-4 * max(scale, 1.0)
+    with torch.enable_grad():
+        unfused = net(x.to(DEV)).detach()
+    assert (unfused - got).abs().max().item() <= 2e-5 * max(scale, 1.0)
+    # cache invalidation: new weights while in eval mode
+    sd2 = seeded_state(onets.generator_spec(C), 32)
+    net.load_state_dict(sd2)
+    with torch.no_grad():
+        got2 = net(x.to(DEV))
+    ref2 = onets.generator(onets.clone_state(sd2, requires_grad=False), x, train=False)
+    assert (got2.cpu() - ref2).abs().max().item() <= 1e-4 * max(ref2.abs().max().item(), 1.0)
+    net.train(); net.eval()
+    assert '_fcd_folded' not in net.__dict__
