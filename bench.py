@@ -33,6 +33,17 @@ import torch.distributed as dist
 PEAK_F32_MFMA_TFLOPS = 157.3
 
 
+WORKLOADS = {
+    # name: (BASELINE.json config, default bands, size, tile pairs per GPU, description)
+    'rsss': (2, 13, 256, 8, 'Demo_RSSS adversarial step (S+D+G, masked MSE, MS-SSIM, per-band VGG16 perception, '
+                            'region losses, RMSprop)'),
+    'usss_g': (1, 4, 256, 16, 'Demo_USSS generator-only pre-training step (G fwd/bwd, masked L1 with cmap=0, MS-SSIM, '
+                              'per-band VGG16 perception, Adam)'),
+    'wsss': (4, 3, 512, 4, 'Demo_WSSS adversarial step (S on the changed and the unchanged pair, D, eval-mode G, masked '
+                           'MSE, MS-SSIM, RGB VGG16 perception, RMSprop)'),
+}
+
+
 def build_workload(args, dev, rank):
     import fcd_gan_pytorch_amd as fcd
     from fcd_gan_pytorch_amd.synthetic import synthetic_tiles
@@ -43,18 +54,46 @@ def build_workload(args, dev, rank):
     netG = fcd.Module.Generator(n_channels=C)
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
-        crit = fcd.Loss.CGeneratorLoss(channel=C, perception_layer=1, perception_perBand=True)
+        if args.workload == 'usss_g':
+            crit = fcd.Loss.CNetLoss(channel=C, perception_layer=1, perception_perBand=True)      # Demo_USSS.py:116
+        else:
+            crit = fcd.Loss.CGeneratorLoss(channel=C, perception_layer=1, perception_perBand=args.workload == 'rsss')
     for m in (netD, netS, netG, crit):
         m.to(dev)
-    netS.train(); netD.train(); netG.eval()          # Demo_RSSS.py:146-148,240
+    multi = dist.is_initialized() and dist.get_world_size() > 1
+    x, y, region = (t.to(dev) for t in synthetic_tiles(1234 + rank, N, C, H, W))
+
+    if args.workload == 'usss_g':
+        netG.train()                                      # Demo_USSS.py:127
+        optG = fcd.optim.Adam(netG.parameters(), lr=1e-4, betas=(0.9, 0.99))
+        if multi:
+            dist.broadcast(optG.flat_p, 0)
+            for t in netG.buffers():
+                dist.broadcast(t, 0)
+
+        def step():
+            return fcd.steps.usss_g_pretrain_step(netG, crit, optG, x, y)
+        return step
+
+    netS.train(); netD.train(); netG.eval()          # Demo_RSSS.py:146-148,240 / Demo_WSSS.py:206
     optS = fcd.optim.RMSprop(netS.parameters(), lr=5e-5)
     optD = fcd.optim.RMSprop(netD.parameters(), lr=5e-5)
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if multi:
         dist.broadcast(optS.flat_p, 0)
         dist.broadcast(optD.flat_p, 0)
         for t in list(netG.state_dict().values()) + list(netS.buffers()) + list(netD.buffers()):
             dist.broadcast(t, 0)
-    x, y, region = (t.to(dev) for t in synthetic_tiles(1234 + rank, N, C, H, W))
+    if args.workload == 'wsss':
+        # the unchanged pair: T2 = T1 + small noise, no changed rectangle (WHU_Dataset_WSS pairs a
+        # changed sample with an unchanged one, data_utils.py:570-625)
+        x_nc, _, _ = synthetic_tiles(4321 + rank, N, C, H, W)
+        x_nc = x_nc.to(dev)
+        g = torch.Generator(device=dev).manual_seed(99 + rank)
+        y_nc = x_nc + 0.1 * torch.randn(x_nc.shape, device=dev, generator=g)
+
+        def step():
+            return fcd.steps.wsss_adversarial_step(netS, netD, netG, crit, optS, optD, x, y, x_nc, y_nc)
+        return step
 
     def step():
         return fcd.steps.rsss_adversarial_step(netS, netD, netG, crit, optS, optD, x, y, region)
@@ -116,14 +155,21 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--batch', type=int, default=8, help='tile pairs per GPU per step')
-    ap.add_argument('--bands', type=int, default=13)
-    ap.add_argument('--size', type=int, default=256)
+    ap.add_argument('--workload', default='rsss', choices=sorted(WORKLOADS),
+                    help="'rsss' = the headline (BASELINE.json configs[2]/[3]); 'usss_g' = configs[1] "
+                         "(G-only, 16 x 256x256x4); 'wsss' = configs[4] (512x512x3)")
+    ap.add_argument('--batch', type=int, default=None, help='tile pairs per GPU per step (default: per workload)')
+    ap.add_argument('--bands', type=int, default=None)
+    ap.add_argument('--size', type=int, default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prof', action='store_true', help='do not bracket launches with HIP events')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend: 'nccl' (= RCCL over xGMI); "
                     "'gloo' only for functional tests of the multi-rank path on a single-GPU box")
     args = ap.parse_args()
+    _, d_bands, d_size, d_batch, wl_desc = WORKLOADS[args.workload]
+    args.bands = args.bands or d_bands
+    args.size = args.size or d_size
+    args.batch = args.batch or d_batch
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -176,9 +222,9 @@ def main():
             'value': total_pairs / dt, 'unit': 'tile-pairs/s', 'n_gpus': n_gpus, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'Demo_RSSS adversarial step (S+D+G, masked MSE, MS-SSIM, per-band VGG16 '
-                                   'perception, region losses, RMSprop), %d bands %dx%d, random-init weights'
-                                   % (args.bands, args.size, args.size),
+            'config': {'workload': '%s, %d bands %dx%d, random-init weights'
+                                   % (wl_desc, args.bands, args.size, args.size),
+                       'baseline_config': 'BASELINE.json configs[%d]' % WORKLOADS[args.workload][0],
                        'tile_pairs_per_gpu': args.batch, 'global_batch': args.batch * n_gpus,
                        'parallelism': 'dp%d' % n_gpus, 'bn': 'per-replica statistics'},
             'losses_last_step': losses,
@@ -200,7 +246,7 @@ def main():
             # WRITE_SIZE, separate rocprofv3 passes over this very command: tools/pmc_bench.sh);
             # bench.py cannot run the profiler on itself, so it reports the committed measurement.
             tpath = os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')
-            if os.path.exists(tpath) and args.batch == 8 and args.bands == 13 and args.size == 256:
+            if os.path.exists(tpath) and args.workload == 'rsss' and args.batch == 8 and args.bands == 13 and args.size == 256:
                 with open(tpath) as f:
                     tj = json.load(f)
                 res['roofline']['traffic'] = tj['hbm_bytes_per_launch']
@@ -211,7 +257,7 @@ def main():
                     'tflops': (v['flops'] / (v['ms'] * 1e-3) / 1e12) if v['ms'] > 0 and v['flops'] > 0 else None,
                     'gbps': (v['bytes'] / (v['ms'] * 1e-3) / 1e9) if v['ms'] > 0 and v['bytes'] > 0 else None}
                 for k, v in prof.items() if v['launches'] > 0}
-        if n_gpus == 1 and not args.no_cpu_baseline:
+        if n_gpus == 1 and not args.no_cpu_baseline and args.workload == 'rsss':
             res['cpu_baseline'] = cpu_baseline(args)
         print(json.dumps(res))
     if world > 1:

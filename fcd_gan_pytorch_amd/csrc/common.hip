@@ -47,6 +47,10 @@ hipEvent_t get_event() {
 
 FcdProfScope::FcdProfScope(int family, hipStream_t stream, double flops, double bytes)
     : fam(family), st(stream), on(false) {
+  // Every launching entry point opens one of these scopes first.  hipGetLastError() is per-thread
+  // and sticky: drop whatever an earlier, unrelated HIP user of this thread left behind (e.g. a
+  // benign device probe of the host framework), so that FCD_LAUNCH_CHECK reports OUR launches only.
+  (void)hipGetLastError();
   if (!g_prof_on) return;
   std::lock_guard<std::mutex> lk(g_mu);
   on = true;

@@ -289,7 +289,12 @@ __global__ __launch_bounds__(256, FCD_WPE) void conv_igemm_glds_kernel(ConvArgs 
   constexpr int X_PER_T = (X_ELEMS + 255) / 256;
   constexpr int WS_SZ = KC * BM, XS_SZ = CB * PLANE;
 
-  __shared__ __attribute__((aligned(16))) float smem[2 * WS_SZ + 2 * XS_SZ];
+  // Distinct LDS objects for the filter slabs (written by global_load_lds = LDS DMA, counted by
+  // vmcnt) and the input patches (ds_write), and a step loop unrolled by two so that the slab
+  // being read and the slab being filled are different objects at compile time.
+  __shared__ __attribute__((aligned(16))) float smem_w0[WS_SZ];
+  __shared__ __attribute__((aligned(16))) float smem_w1[WS_SZ];
+  __shared__ __attribute__((aligned(16))) float smem_x[2 * XS_SZ];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -380,13 +385,13 @@ __global__ __launch_bounds__(256, FCD_WPE) void conv_igemm_glds_kernel(ConvArgs 
   const unsigned char* cin_ = pooled_src ? a.pool_code_in + (size_t)n * a.C * in_plane : nullptr;
   const int chunk_elems = CB * in_plane;
 
-#define FCD_GLDS_W(CCHUNK, RR, BUF)                                                                   \
+#define FCD_GLDS_W(CCHUNK, RR, WDST)                                                                  \
   {                                                                                                   \
     const float* wsrc = a.wp + ((size_t)(CCHUNK) * CB * (R * S) + (RR) * (RCH * S)) * a.Kpad;         \
     _Pragma("unroll") for (int j = 0; j < W_PER_WAVE; ++j) {                                          \
       if (W_INSTR % 4 == 0 || wave + 4 * j < W_INSTR)                                                 \
         __builtin_amdgcn_global_load_lds((gbl_void_t*)(wsrc + w_goff[j]),                             \
-                                         (lds_void_t*)(smem + (BUF) * WS_SZ + (wave + 4 * j) * 256), 16, 0, 0); \
+                                         (lds_void_t*)((WDST) + (wave + 4 * j) * 256), 16, 0, 0);     \
     }                                                                                                 \
   }
 #define FCD_LOAD_X2(CCHUNK)                                                                           \
@@ -395,66 +400,73 @@ __global__ __launch_bounds__(256, FCD_WPE) void conv_igemm_glds_kernel(ConvArgs 
     const float* msrc = min_ + (size_t)(CCHUNK) * chunk_elems;                                        \
     const int cleft = a.C - (CCHUNK) * CB;                                                            \
     _Pragma("unroll") for (int i = 0; i < X_PER_T; ++i) {                                             \
-      /* branch-free: out-of-range lanes read element 0 of the chunk and are zeroed by select */     \
+      /* branch-free: out-of-range lanes read element 0 of the chunk; they are zeroed at STORE time  \
+         (any use of the loaded value here would put a vmcnt(0) wait in front of the MFMA block) */   \
       const bool ok = (unsigned)x_cc[i] < (unsigned)cleft;                                            \
       const unsigned off = ok ? (unsigned)x_goff[i] : 0u;                                             \
-      const float v = xsrc[off];                                                                      \
-      xr[i] = ok ? v : 0.f;                                                                           \
+      xr[i] = xsrc[off];                                                                              \
       if (has_mask) mr[i] = msrc[off];                                                                \
       if (pooled_src) mcode[i] = cin_[(size_t)(CCHUNK) * chunk_elems + off];                          \
     }                                                                                                 \
   }
-  /* the ReLU-mask select is applied HERE (after the MFMA block), so neither load is waited for early */ \
-#define FCD_STORE_X2(BUF)                                                                             \
+  /* bounds / ReLU-mask / pool-slot selects are applied HERE (after the MFMA block) */
+#define FCD_STORE_X2(BUF, CCHUNK)                                                                     \
   {                                                                                                   \
+    const int cleft = a.C - (CCHUNK) * CB;                                                            \
     _Pragma("unroll") for (int i = 0; i < X_PER_T; ++i) {                                             \
-      if (X_ELEMS % 256 == 0 || tid + i * 256 < X_ELEMS)                                              \
-        smem[2 * WS_SZ + (BUF) * XS_SZ + x_loff[i]] =                                                 \
-            pooled_src ? (mcode[i] == x_want[i] ? xr[i] : 0.f) : ((!has_mask || mr[i] > 0.f) ? xr[i] : 0.f); \
+      if (X_ELEMS % 256 == 0 || tid + i * 256 < X_ELEMS) {                                            \
+        bool keep = (unsigned)x_cc[i] < (unsigned)cleft;                                              \
+        if (pooled_src) keep = keep && mcode[i] == x_want[i];                                         \
+        else if (has_mask) keep = keep && mr[i] > 0.f;                                                \
+        smem_x[(BUF) * XS_SZ + x_loff[i]] = keep ? xr[i] : 0.f;                                       \
+      }                                                                                               \
     }                                                                                                 \
   }
 
   const int nsteps = a.nchunks * NR;
-  FCD_GLDS_W(0, 0, 0)
+  FCD_GLDS_W(0, 0, smem_w0)
   FCD_LOAD_X2(0)
-  FCD_STORE_X2(0)
+  FCD_STORE_X2(0, 0)
   __syncthreads();
 
-  for (int step = 0; step < nsteps; ++step) {
-    const int nxt = step + 1;
-    const int rr = (NR == 1) ? 0 : step % NR;
-    const int chunk = (NR == 1) ? step : step / NR;
-    const bool have_next = nxt < nsteps;
-    const bool next_patch = have_next && (NR == 1 || nxt % NR == 0);
-    const int wb = step & 1, xb = chunk & 1;
-    if (have_next) {
-      FCD_GLDS_W((NR == 1) ? nxt : nxt / NR, (NR == 1) ? 0 : nxt % NR, wb ^ 1)
-      if (next_patch) FCD_LOAD_X2(chunk + 1)
-    }
-    const float* wl = smem + wb * WS_SZ + woff;
-    const float* xl = smem + 2 * WS_SZ + xb * XS_SZ + rr * RCH * PWP;
-#pragma unroll
-    for (int cc2 = 0; cc2 < CB / 2; ++cc2) {
-#pragma unroll
-      for (int rl = 0; rl < RCH; ++rl) {
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-          float av[MI], bv[NI];
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi) av[mi] = wl[((cc2 * 2) * (RCH * S) + rl * S + s) * BM + mi * 32];
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) bv[ni] = xl[xoff[ni] + (cc2 * 2) * PLANE + rl * PWP + s];
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
-        }
-      }
-    }
-    if (next_patch) FCD_STORE_X2(xb ^ 1)
-    __syncthreads();
+#define FCD_STEP(STEP, WCUR, WNXT)                                                                    \
+  {                                                                                                   \
+    const int step_ = (STEP);                                                                         \
+    const int nxt = step_ + 1;                                                                        \
+    const int rr = (NR == 1) ? 0 : step_ % NR;                                                        \
+    const int chunk = (NR == 1) ? step_ : step_ / NR;                                                 \
+    const bool have_next = nxt < nsteps;                                                              \
+    const bool next_patch = have_next && (NR == 1 || nxt % NR == 0);                                  \
+    const int xb = chunk & 1;                                                                         \
+    if (have_next) {                                                                                  \
+      FCD_GLDS_W((NR == 1) ? nxt : nxt / NR, (NR == 1) ? 0 : nxt % NR, WNXT)                          \
+      if (next_patch) FCD_LOAD_X2(chunk + 1)                                                          \
+    }                                                                                                 \
+    const float* wl = (WCUR) + woff;                                                                  \
+    const float* xl = smem_x + xb * XS_SZ + rr * RCH * PWP;                                           \
+    _Pragma("unroll") for (int cc2 = 0; cc2 < CB / 2; ++cc2) {                                        \
+      _Pragma("unroll") for (int rl = 0; rl < RCH; ++rl) {                                            \
+        _Pragma("unroll") for (int s = 0; s < S; ++s) {                                               \
+          float av[MI], bv[NI];                                                                       \
+          _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                           \
+            av[mi] = wl[((cc2 * 2) * (RCH * S) + rl * S + s) * BM + mi * 32];                         \
+          _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                           \
+            bv[ni] = xl[xoff[ni] + (cc2 * 2) * PLANE + rl * PWP + s];                                 \
+          _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                           \
+            _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                         \
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi], bv[ni], acc[mi][ni], 0, 0, 0); \
+        }                                                                                             \
+      }                                                                                               \
+    }                                                                                                 \
+    if (next_patch) FCD_STORE_X2(xb ^ 1, chunk + 1)                                                   \
+    __syncthreads();                                                                                  \
   }
+
+  for (int step = 0; step < nsteps; step += 2) {
+    FCD_STEP(step, smem_w0, smem_w1)
+    if (step + 1 < nsteps) FCD_STEP(step + 1, smem_w1, smem_w0)
+  }
+#undef FCD_STEP
 #undef FCD_GLDS_W
 #undef FCD_LOAD_X2
 #undef FCD_STORE_X2
