@@ -7,6 +7,14 @@ around the HIP kernels.
 import ctypes
 import os
 import subprocess
+
+# The host framework must be in the process BEFORE libfcdgan_hip.so: the PyTorch-ROCm wheel bundles
+# its own libamdhip64.so.7, and the C library has to bind to that same HIP runtime instance (the
+# streams and device pointers it is handed belong to it).  Loaded first, the wheel's copy satisfies
+# our DT_NEEDED by soname; loaded second, the process would end up with two HIP runtimes and every
+# launch from this library fails with "no ROCm-capable device is detected".
+import torch  # noqa: F401  (import order matters, see above)
+
 from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

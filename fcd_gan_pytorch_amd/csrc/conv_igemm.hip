@@ -18,9 +18,17 @@
 #include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 int fcd_try_dgrad_thin(const fcd_conv_desc* d, const float* dy, const float* relu_out, const float* wp_bwd, float* dx,
                        hipStream_t st);  // conv_thin.hip
 
+// FCD_EXP: diagnostic builds only (results are wrong when set): 1 = no patch loads/stores in the
+// loop, 2 = no filter DMA in the loop, 4 = no barrier in the loop, 8 = operands from registers,
+// 16 = patch loads from a tiny always-cached window, 32 = filter DMA from slabs 0/1 only
+#ifndef FCD_EXP
+#define FCD_EXP 0
+#endif
 struct ConvArgs {
   const float* x;
   const float* wp;
@@ -157,7 +165,7 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_kernel(ConvArgs a) {
   }
 #define FCD_LOAD_X(CCHUNK)                                                                            \
   {                                                                                                   \
-    const float* xsrc = xin + (size_t)(CCHUNK) * chunk_elems;                                         \
+    const float* xsrc = (FCD_EXP & 16) ? a.x + ((CCHUNK) & 1) * 4096 : xin + (size_t)(CCHUNK) * chunk_elems; \
     const float* msrc = min_ + (size_t)(CCHUNK) * chunk_elems;                                        \
     const int cleft = a.C - (CCHUNK) * CB;                                                            \
     _Pragma("unroll") for (int i = 0; i < X_PER_T; ++i) {                                             \
@@ -265,8 +273,19 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_kernel(ConvArgs a) {
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 
+// Filter-slab layout of the global_load_lds kernel ("T layout", written by pack_weights_t_kernel):
+//   wp[q][h][m][FCD_KROW]   q = chunk of 4 input channels, h = lane half of the MFMA (channels 2h, 2h+1
+//   of the chunk), m = GEMM row (output channel, padded to 128), and per row the 18 k-values
+//   j = (c & 1) * 9 + tap this half consumes in one chunk, padded to 20 floats (16-B aligned rows;
+//   stride 80 B => the b128 LDS reads of 8 consecutive lanes touch all 32 banks exactly once).
+// One lane thus fetches its A operands for a whole chunk with 4 ds_read_b128 + 1 ds_read_b64 per
+// m-tile instead of 18 ds_read_b32 with per-k address arithmetic.
+#define FCD_KROW 20
+#define FCD_KH 18
+// SRC: how the loader treats the source tensor -- 0 plain, 1 gated by a ReLU mask (relu_out > 0),
+// 2 pooled gradient routed by the argmax code byte.  Compile-time so the loop carries no mode branches.
 template <int R, int S, int RCH, int STRIDE, int DIL, int CB, int MI, int NI, int WM, int WN, int TH,
-          int TW>
+          int TW, int SRC>
 #ifndef FCD_WPE
 #define FCD_WPE 3
 #endif
@@ -275,19 +294,18 @@ __global__ __launch_bounds__(256, FCD_WPE) void conv_igemm_glds_kernel(ConvArgs 
   constexpr int BN = 32 * NI * WN;
   static_assert(WM * WN == 4, "4 waves");
   static_assert(TH * TW == BN, "pixel tile");
-  static_assert(R % RCH == 0 && CB % 2 == 0, "chunks");
+  static_assert(R == 3 && S == 3 && RCH == 3 && CB == 4, "3x3 taps, 4-channel chunks");
   constexpr int PH = (TH - 1) * STRIDE + R;
   constexpr int PW = (TW - 1) * STRIDE + S;
   constexpr int PWP = PW | 1;
   constexpr int PLANE = PH * PWP;
-  constexpr int KC = CB * RCH * S;
-  constexpr int NR = R / RCH;
-  constexpr int W_INSTR = KC * BM / 256;           // 1 KiB wave-instructions per slab
-  static_assert((KC * BM) % 256 == 0, "slab must be a whole number of wave loads");
+  constexpr int WS_SZ = 2 * BM * FCD_KROW;         // floats per filter slab
+  static_assert(WS_SZ % 256 == 0, "slab must be a whole number of wave loads");
+  constexpr int W_INSTR = WS_SZ / 256;             // 1 KiB wave-instructions per slab
   constexpr int W_PER_WAVE = (W_INSTR + 3) / 4;
   constexpr int X_ELEMS = CB * PH * PW;
   constexpr int X_PER_T = (X_ELEMS + 255) / 256;
-  constexpr int WS_SZ = KC * BM, XS_SZ = CB * PLANE;
+  constexpr int XS_SZ = CB * PLANE;
 
   // Distinct LDS objects for the filter slabs (written by global_load_lds = LDS DMA, counted by
   // vmcnt) and the input patches (ds_write), and a step loop unrolled by two so that the slab
@@ -325,13 +343,15 @@ __global__ __launch_bounds__(256, FCD_WPE) void conv_igemm_glds_kernel(ConvArgs 
   const int ko0 = ktile * BM;
   const int p0 = tp * TH, q0 = tq * TW;
 
-  int xoff[NI];
+  // operand addresses inside the LDS buffers (floats)
+  int xoff[NI], aoff[MI];
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
     const int pidx = wn * (32 * NI) + ni * 32 + l31;
-    xoff[ni] = half * PLANE + (pidx / TW) * STRIDE * PWP + (pidx % TW) * STRIDE;
+    xoff[ni] = half * 2 * PLANE + (pidx / TW) * STRIDE * PWP + (pidx % TW) * STRIDE;
   }
-  const int woff = half * (RCH * S) * BM + wm * (32 * MI) + l31;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) aoff[mi] = (half * BM + wm * (32 * MI) + mi * 32 + l31) * FCD_KROW;
 
   f32x16 acc[MI][NI];
 #pragma unroll
@@ -341,19 +361,21 @@ __global__ __launch_bounds__(256, FCD_WPE) void conv_igemm_glds_kernel(ConvArgs 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-  // loop-invariant addresses
+  // loop-invariant addresses.  Filter DMA: 16-B unit u of the slab image [h][m][KROW] comes from
+  // row (h, ko0 + m) of the chunk's block in global memory.
   int w_goff[W_PER_WAVE];
 #pragma unroll
   for (int j = 0; j < W_PER_WAVE; ++j) {
-    const int f = (wave + 4 * j) * 256 + lane * 4;     // float index inside the slab
-    const int row = f / BM, col = f % BM;
-    const int cc = row / (RCH * S), rem = row % (RCH * S);
-    w_goff[j] = (cc * (R * S) + rem) * a.Kpad + ko0 + col;
+    const int u = (wave + 4 * j) * 64 + lane;
+    const int h = u / (BM * (FCD_KROW / 4)), m = (u / (FCD_KROW / 4)) % BM, part = u % (FCD_KROW / 4);
+    w_goff[j] = (h * a.Kpad + ko0 + m) * FCD_KROW + part * 4;
   }
+  const size_t w_chunk_stride = (size_t)2 * a.Kpad * FCD_KROW;
+
   float xr[X_PER_T], mr[X_PER_T];
   unsigned mcode[X_PER_T], x_want[X_PER_T];   // raw code byte kept as an integer: no conversion => no early wait
-  int x_goff[X_PER_T], x_loff[X_PER_T], x_cc[X_PER_T];
-  const bool pooled_src = a.pool_code_in != nullptr;
+  unsigned x_boff[X_PER_T];                    // byte offset inside a chunk of the source (0 for lanes that load nothing)
+  int x_loff[X_PER_T], x_cc[X_PER_T];
   const int ih0 = p0 * STRIDE - a.pad, iw0 = q0 * STRIDE - a.pad;
 #pragma unroll
   for (int i = 0; i < X_PER_T; ++i) {
@@ -368,45 +390,49 @@ __global__ __launch_bounds__(256, FCD_WPE) void conv_igemm_glds_kernel(ConvArgs 
       iw >>= 1;
     }
     ok = ok && ih < a.H && iw < a.W;
-    x_cc[i] = ok ? cc : -1;
-    x_goff[i] = (cc * a.H + ih) * a.W + iw;
+    int goff = (cc * a.H + ih) * a.W + iw;
     x_loff[i] = cc * PLANE + ph * PWP + pw;
-    if (pooled_src) {   // gradient arrives pooled: index the (Hp, Wp) tensors, remember this element's slot
+    if (SRC == 2) {   // gradient arrives pooled: index the (Hp, Wp) tensors, remember this element's slot
       const int hp = ih >> 1, wq = iw >> 1;
-      if (hp >= a.Hp || wq >= a.Wp) x_cc[i] = -1;            // trailing odd row / column: never pooled
-      x_goff[i] = (cc * a.Hp + hp) * a.Wp + wq;
+      if (hp >= a.Hp || wq >= a.Wp) ok = false;              // trailing odd row / column: never pooled
+      goff = (cc * a.Hp + hp) * a.Wp + wq;
       x_want[i] = (unsigned)((((ih & 1) << 1) | (iw & 1)) | 4);
     }
+    x_cc[i] = ok ? cc : -1;
+    x_boff[i] = ok ? (unsigned)goff * 4u : 0u;
   }
-  const int in_plane = pooled_src ? a.Hp * a.Wp : a.H * a.W;
+  const int in_plane = (SRC == 2) ? a.Hp * a.Wp : a.H * a.W;
   const float* xin = a.x + (size_t)n * a.C * in_plane;
-  const bool has_mask = a.mask != nullptr;
-  const float* min_ = (has_mask ? a.mask : a.x) + (size_t)n * a.C * in_plane;
-  const unsigned char* cin_ = pooled_src ? a.pool_code_in + (size_t)n * a.C * in_plane : nullptr;
+  const float* min_ = ((SRC == 1) ? a.mask : a.x) + (size_t)n * a.C * in_plane;
+  const unsigned char* cin_ = (SRC == 2) ? a.pool_code_in + (size_t)n * a.C * in_plane : nullptr;
   const int chunk_elems = CB * in_plane;
 
-#define FCD_GLDS_W(CCHUNK, RR, WDST)                                                                  \
+#define FCD_GLDS_W(CCHUNK, WDST)                                                                      \
   {                                                                                                   \
-    const float* wsrc = a.wp + ((size_t)(CCHUNK) * CB * (R * S) + (RR) * (RCH * S)) * a.Kpad;         \
+    const float* wsrc = a.wp + (size_t)((FCD_EXP & 32) ? ((CCHUNK) & 1) : (CCHUNK)) * w_chunk_stride; \
     _Pragma("unroll") for (int j = 0; j < W_PER_WAVE; ++j) {                                          \
       if (W_INSTR % 4 == 0 || wave + 4 * j < W_INSTR)                                                 \
         __builtin_amdgcn_global_load_lds((gbl_void_t*)(wsrc + w_goff[j]),                             \
                                          (lds_void_t*)((WDST) + (wave + 4 * j) * 256), 16, 0, 0);     \
     }                                                                                                 \
   }
+  /* Loads only: any USE of a loaded value here would put a vmcnt(0) wait in front of the MFMA       \
+     block.  Lanes that load nothing (halo outside the image, channel tail) read byte 0 of the      \
+     chunk (of the tensor for the tail); they are zeroed at STORE time. */
 #define FCD_LOAD_X2(CCHUNK)                                                                           \
   {                                                                                                   \
-    const float* xsrc = xin + (size_t)(CCHUNK) * chunk_elems;                                         \
-    const float* msrc = min_ + (size_t)(CCHUNK) * chunk_elems;                                        \
     const int cleft = a.C - (CCHUNK) * CB;                                                            \
+    const bool tail = cleft < CB;                                                                     \
+    const char* xsrc = (const char*)(xin + (size_t)(CCHUNK) * chunk_elems);                           \
+    const char* msrc = (const char*)(min_ + (size_t)(CCHUNK) * chunk_elems);                          \
+    const unsigned char* csrc = cin_ + (size_t)(CCHUNK) * chunk_elems;                                \
     _Pragma("unroll") for (int i = 0; i < X_PER_T; ++i) {                                             \
-      /* branch-free: out-of-range lanes read element 0 of the chunk; they are zeroed at STORE time  \
-         (any use of the loaded value here would put a vmcnt(0) wait in front of the MFMA block) */   \
-      const bool ok = (unsigned)x_cc[i] < (unsigned)cleft;                                            \
-      const unsigned off = ok ? (unsigned)x_goff[i] : 0u;                                             \
-      xr[i] = xsrc[off];                                                                              \
-      if (has_mask) mr[i] = msrc[off];                                                                \
-      if (pooled_src) mcode[i] = cin_[(size_t)(CCHUNK) * chunk_elems + off];                          \
+      unsigned off = x_boff[i];                                                                       \
+      if (tail) off = (x_cc[i] < cleft) ? off : 0u;                                                   \
+      if (FCD_EXP & 16) off &= 16383u;                                                                \
+      xr[i] = *(const float*)(xsrc + off);                                                            \
+      if (SRC == 1) mr[i] = *(const float*)(msrc + off);                                              \
+      if (SRC == 2) mcode[i] = csrc[off >> 2];                                                        \
     }                                                                                                 \
   }
   /* bounds / ReLU-mask / pool-slot selects are applied HERE (after the MFMA block) */
@@ -416,50 +442,51 @@ __global__ __launch_bounds__(256, FCD_WPE) void conv_igemm_glds_kernel(ConvArgs 
     _Pragma("unroll") for (int i = 0; i < X_PER_T; ++i) {                                             \
       if (X_ELEMS % 256 == 0 || tid + i * 256 < X_ELEMS) {                                            \
         bool keep = (unsigned)x_cc[i] < (unsigned)cleft;                                              \
-        if (pooled_src) keep = keep && mcode[i] == x_want[i];                                         \
-        else if (has_mask) keep = keep && mr[i] > 0.f;                                                \
+        if (SRC == 2) keep = keep && mcode[i] == x_want[i];                                           \
+        if (SRC == 1) keep = keep && mr[i] > 0.f;                                                     \
         smem_x[(BUF) * XS_SZ + x_loff[i]] = keep ? xr[i] : 0.f;                                       \
       }                                                                                               \
     }                                                                                                 \
   }
 
-  const int nsteps = a.nchunks * NR;
-  FCD_GLDS_W(0, 0, smem_w0)
+  const int nsteps = a.nchunks;
+  FCD_GLDS_W(0, smem_w0)
   FCD_LOAD_X2(0)
   FCD_STORE_X2(0, 0)
   __syncthreads();
 
 #define FCD_STEP(STEP, WCUR, WNXT)                                                                    \
   {                                                                                                   \
-    const int step_ = (STEP);                                                                         \
-    const int nxt = step_ + 1;                                                                        \
-    const int rr = (NR == 1) ? 0 : step_ % NR;                                                        \
-    const int chunk = (NR == 1) ? step_ : step_ / NR;                                                 \
-    const bool have_next = nxt < nsteps;                                                              \
-    const bool next_patch = have_next && (NR == 1 || nxt % NR == 0);                                  \
+    const int chunk = (STEP);                                                                         \
+    const bool have_next = chunk + 1 < nsteps;                                                        \
     const int xb = chunk & 1;                                                                         \
     if (have_next) {                                                                                  \
-      FCD_GLDS_W((NR == 1) ? nxt : nxt / NR, (NR == 1) ? 0 : nxt % NR, WNXT)                          \
-      if (next_patch) FCD_LOAD_X2(chunk + 1)                                                          \
+      if (!(FCD_EXP & 2)) FCD_GLDS_W(chunk + 1, WNXT)                                                 \
+      if (!(FCD_EXP & 1)) FCD_LOAD_X2(chunk + 1)                                                      \
     }                                                                                                 \
-    const float* wl = (WCUR) + woff;                                                                  \
-    const float* xl = smem_x + xb * XS_SZ + rr * RCH * PWP;                                           \
-    _Pragma("unroll") for (int cc2 = 0; cc2 < CB / 2; ++cc2) {                                        \
-      _Pragma("unroll") for (int rl = 0; rl < RCH; ++rl) {                                            \
-        _Pragma("unroll") for (int s = 0; s < S; ++s) {                                               \
-          float av[MI], bv[NI];                                                                       \
-          _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                           \
-            av[mi] = wl[((cc2 * 2) * (RCH * S) + rl * S + s) * BM + mi * 32];                         \
-          _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                           \
-            bv[ni] = xl[xoff[ni] + (cc2 * 2) * PLANE + rl * PWP + s];                                 \
-          _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                           \
-            _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                         \
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi], bv[ni], acc[mi][ni], 0, 0, 0); \
-        }                                                                                             \
+    const float* xl = smem_x + xb * XS_SZ;                                                            \
+    float av[MI][FCD_KROW];                                                                           \
+    _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) {                                               \
+      const float* ap = (WCUR) + aoff[mi];                                                            \
+      _Pragma("unroll") for (int v4 = 0; v4 < 4; ++v4) {                                              \
+        const f32x4 t4 = *(const f32x4*)(ap + 4 * v4);                                                \
+        av[mi][4 * v4] = t4[0]; av[mi][4 * v4 + 1] = t4[1];                                           \
+        av[mi][4 * v4 + 2] = t4[2]; av[mi][4 * v4 + 3] = t4[3];                                       \
       }                                                                                               \
+      const f32x2 t2 = *(const f32x2*)(ap + 16);                                                      \
+      av[mi][16] = t2[0]; av[mi][17] = t2[1];                                                         \
     }                                                                                                 \
-    if (next_patch) FCD_STORE_X2(xb ^ 1, chunk + 1)                                                   \
-    __syncthreads();                                                                                  \
+    _Pragma("unroll") for (int j = 0; j < FCD_KH; ++j) {                                              \
+      float bv[NI];                                                                                   \
+      _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                               \
+        bv[ni] = (FCD_EXP & 8) ? (float)(lane + ni + j)                                               \
+                               : xl[xoff[ni] + (j / 9) * PLANE + ((j % 9) / 3) * PWP + (j % 3)];      \
+      _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                               \
+        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                             \
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][j], bv[ni], acc[mi][ni], 0, 0, 0); \
+    }                                                                                                 \
+    if (!(FCD_EXP & 1)) if (have_next) FCD_STORE_X2(xb ^ 1, chunk + 1)                                \
+    if (!(FCD_EXP & 4)) __syncthreads();                                                              \
   }
 
   for (int step = 0; step < nsteps; step += 2) {
@@ -577,14 +604,45 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
 
 static inline int cb_for(int R, int S) { return (R * S == 1) ? 32 : 8; }
 
+// Which layout a filter is packed in is a pure function of its shape: 3x3 filters whose GEMM has
+// more than 32 rows (output channels forward, input channels for the data gradient) run on the
+// global_load_lds kernel and use the T layout; everything else the register-staged kernel's
+// row layout wp[(c, r, s)][Mpad].
+static inline bool t_layout(int M, int R, int S) { return R == 3 && S == 3 && M > 32; }
+
 static void packed_dims(int K, int C, int R, int S, int mode, int* rows, int* cols) {
   const int cb = cb_for(R, S);
-  if (mode == 0) {
-    *rows = round_up(C, cb) * R * S;
-    *cols = round_up(K, 128);
-  } else {
-    *rows = round_up(K, cb) * R * S;
-    *cols = round_up(C, 128);
+  const int M = mode == 0 ? K : C, Cg = mode == 0 ? C : K;      // GEMM rows / reduction channels
+  if (t_layout(M, R, S)) {
+    *rows = (round_up(Cg, cb) / 4) * 2 * round_up(M, 128);       // (chunk, half, m)
+    *cols = FCD_KROW;
+    return;
+  }
+  *rows = round_up(Cg, cb) * R * S;
+  *cols = round_up(M, 128);
+}
+
+// T layout (see conv_igemm_glds_kernel): wp[q][h][m][KROW], j = (c & 1) * 9 + tap, zero padded.
+__global__ void pack_weights_t_kernel(const float* __restrict__ w, float* __restrict__ wp, int K, int C,
+                                      int64_t total, int Mpad, int mode) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int j = (int)(i % FCD_KROW);
+    const int64_t row = i / FCD_KROW;
+    const int m = (int)(row % Mpad);
+    const int h = (int)((row / Mpad) & 1);
+    const int q = (int)(row / (2 * (int64_t)Mpad));
+    float v = 0.f;
+    if (j < FCD_KH) {
+      const int ch = q * 4 + h * 2 + j / 9, tap = j % 9;
+      const int r = tap / 3, sx = tap % 3;
+      if (mode == 0) {   // GEMM row = output channel k, reduction over (c, r, s)
+        if (ch < C && m < K) v = w[(((int64_t)m * C + ch) * 3 + r) * 3 + sx];
+      } else {           // GEMM row = input channel c, reduction over (k, r', s') with flipped taps
+        if (ch < K && m < C) v = w[(((int64_t)ch * C + m) * 3 + (2 - r)) * 3 + (2 - sx)];
+      }
+    }
+    wp[i] = v;
   }
 }
 
@@ -603,8 +661,12 @@ extern "C" int fcd_conv_pack_weights(const float* w, float* wp, int K, int C, in
   const int64_t total = (int64_t)rows * cols;
   const int grid = (int)std::min<int64_t>(cdiv64(total, 256), 4096);
   FcdProfScope prof(FCD_K_PACK, (hipStream_t)stream, 0.0, 8.0 * total);
-  hipLaunchKernelGGL(pack_weights_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, wp, K, C, R,
-                     S, rows, cols, mode);
+  if (t_layout(mode == 0 ? K : C, R, S))
+    hipLaunchKernelGGL(pack_weights_t_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, wp, K, C, total,
+                       round_up(mode == 0 ? K : C, 128), mode);
+  else
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, wp, K, C, R,
+                       S, rows, cols, mode);
   FCD_LAUNCH_CHECK("pack_weights");
   return FCD_OK;
 }
@@ -620,15 +682,6 @@ static int xcd_remap_on() {
   return v;
 }
 
-static int use_v2() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("FCD_CONV_V2");
-    v = (e && e[0] == '0') ? 0 : 1;
-  }
-  return v;
-}
-
 template <int R, int S, int RCH, int STRIDE, int DIL, int CB, int MI, int NI, int WM, int WN, int TH,
           int TW>
 static int launch_cfg(const ConvArgs& a0, hipStream_t st) {
@@ -637,25 +690,38 @@ static int launch_cfg(const ConvArgs& a0, hipStream_t st) {
   a.tiles_p = cdiv(a.P, TH);
   a.tiles_q = cdiv(a.Q, TW);
   dim3 grid((unsigned)(a.N * a.tiles_p * a.tiles_q), (unsigned)cdiv(a.K, BM));
-  constexpr int CB2 = FCD_CB2;
-  constexpr bool kHasV2 = (R == 3 && S == 3) && ((CB2 * RCH * S * BM) % 256 == 0);
-  if constexpr (kHasV2) {
-    if (use_v2()) {
-      a.nchunks = cdiv(a.C, CB2);
-      a.k_tiles = (int)grid.y;
-      a.xcd_remap = xcd_remap_on();
-      const dim3 grid1 = a.xcd_remap ? dim3(grid.x * grid.y) : grid;
-      hipLaunchKernelGGL((conv_igemm_glds_kernel<R, S, RCH, STRIDE, DIL, CB2, MI, NI, WM, WN, TH, TW>), grid1,
+  if constexpr (R == 3 && S == 3 && BM > 32) {
+    // global_load_lds kernel (T-layout filters: must agree with t_layout() used by the packer)
+    constexpr int CB2 = FCD_CB2;
+    a.nchunks = cdiv(a.C, CB2);
+    a.k_tiles = (int)grid.y;
+    a.xcd_remap = xcd_remap_on();
+    const dim3 grid1 = a.xcd_remap ? dim3(grid.x * grid.y) : grid;
+    const int src = a.pool_code_in ? 2 : (a.mask ? 1 : 0);
+    if (src == 0) {
+      hipLaunchKernelGGL((conv_igemm_glds_kernel<R, S, RCH, STRIDE, DIL, CB2, MI, NI, WM, WN, TH, TW, 0>), grid1,
                          dim3(256), 0, st, a);
       return 0;
     }
-  }
-  {
+    if constexpr (STRIDE == 1) {          // gated sources only occur in data gradients (unit stride)
+      if (src == 1) {
+        hipLaunchKernelGGL((conv_igemm_glds_kernel<R, S, RCH, STRIDE, DIL, CB2, MI, NI, WM, WN, TH, TW, 1>), grid1,
+                           dim3(256), 0, st, a);
+        return 0;
+      }
+      if constexpr (DIL == 1) {
+        hipLaunchKernelGGL((conv_igemm_glds_kernel<R, S, RCH, STRIDE, DIL, CB2, MI, NI, WM, WN, TH, TW, 2>), grid1,
+                           dim3(256), 0, st, a);
+        return 0;
+      }
+    }
+    return -1;
+  } else {
     a.nchunks = cdiv(a.C, CB);
     hipLaunchKernelGGL((conv_igemm_kernel<R, S, RCH, STRIDE, DIL, CB, MI, NI, WM, WN, TH, TW>), grid,
                        dim3(256), 0, st, a);
+    return 0;
   }
-  return 0;
 }
 
 template <int R, int S, int RCH, int STRIDE, int DIL, int CB>
@@ -764,7 +830,6 @@ extern "C" int fcd_conv2d_bwd_data(const fcd_conv_desc* d, const float* dy, cons
 static int pool_supported(const fcd_conv_desc* d, int out_channels, const char* who) {
   FCD_CHECK_ARG(d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1, "%s: only 3x3 / stride 1 / pad 1", who);
   FCD_CHECK_ARG(out_channels > 32, "%s: needs > 32 output channels of the launched GEMM (got %d)", who, out_channels);
-  FCD_CHECK_ARG(use_v2(), "%s: requires the global_load_lds kernel (FCD_CONV_V2=0 set)", who);
   FCD_CHECK_ARG(d->P >= 2 && d->Q >= 2, "%s: map too small to pool", who);
   return FCD_OK;
 }

@@ -34,8 +34,11 @@ def test_argument_validation_without_gpu():
     assert rc == -1 and b'output size' in lib.fcd_last_error_string()
     d = _lib.ConvDesc(1, 4, 8, 8, 8, 5, 5, 1, 2, 8, 8)      # unsupported 5x5
     assert lib.fcd_conv2d_bwd_weight_ws_bytes(ctypes.byref(d)) == 0
-    assert lib.fcd_conv_packed_elems(64, 13, 3, 3, 0) == 16 * 9 * 128
+    # 64 GEMM rows, 3x3: T layout [chunk of 4 channels][half][row padded to 128][20]
+    assert lib.fcd_conv_packed_elems(64, 13, 3, 3, 0) == (16 // 4) * 2 * 128 * 20
+    # data gradient of the same filter: 13 GEMM rows <= 32 -> row layout [(k, r, s)][rows padded to 128]
     assert lib.fcd_conv_packed_elems(64, 13, 3, 3, 1) == 64 * 9 * 128
+    assert lib.fcd_conv_packed_elems(64, 13, 9, 9, 0) == 16 * 81 * 128
     assert lib.fcd_bn_act_ws_bytes(64, 2) > 0
 
 
