@@ -289,7 +289,7 @@ template <int R, int S, int RCH, int STRIDE, int DIL, int CB, int MI, int NI, in
 #ifndef FCD_WPE
 #define FCD_WPE 3
 #endif
-__global__ __launch_bounds__(256, FCD_WPE) void conv_igemm_glds_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, (MI * NI > 4) ? 2 : FCD_WPE) void conv_igemm_glds_kernel(ConvArgs a) {
   constexpr int BM = 32 * MI * WM;
   constexpr int BN = 32 * NI * WN;
   static_assert(WM * WN == 4, "4 waves");
@@ -518,14 +518,16 @@ __global__ __launch_bounds__(256, FCD_WPE) void conv_igemm_glds_kernel(ConvArgs 
           v[ni] = v[ni] > 0.f ? v[ni] : 0.f;
         }
         if (TW >= 32) {
-          if (NI == 2) {
-            const float v01 = __shfl_xor(v[0], 1, 64), v11 = __shfl_xor(v[1], 1, 64);
-            float m = v[0];
+          // the wave's n-tiles are consecutive image rows: pool rows (2t, 2t+1) = n-tiles (2t, 2t+1)
+#pragma unroll
+          for (int np = 0; np + 1 < NI; np += 2) {
+            const float v01 = __shfl_xor(v[np], 1, 64), v11 = __shfl_xor(v[np + 1], 1, 64);
+            float m = v[np];
             int arg = 0;
             if (v01 > m) { m = v01; arg = 1; }
-            if (v[1] > m) { m = v[1]; arg = 2; }
+            if (v[np + 1] > m) { m = v[np + 1]; arg = 2; }
             if (v11 > m) { m = v11; arg = 3; }
-            const int pidx = wn * 64 + l31;
+            const int pidx = wn * (32 * NI) + np * 32 + l31;
             const int pp = (p0 + (pidx / TW)) >> 1, qq = (q0 + (pidx % TW)) >> 1;
             if (!(l31 & 1) && ko < a.K && pp < Pp && qq < Qp) {
               const size_t o = (((size_t)n * a.K + ko) * Pp + pp) * Qp + qq;
@@ -724,10 +726,27 @@ static int launch_cfg(const ConvArgs& a0, hipStream_t st) {
   }
 }
 
+static int big_tiles_on() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("FCD_CONV_BIG");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v;
+}
+
 template <int R, int S, int RCH, int STRIDE, int DIL, int CB>
 static int launch_family(const ConvArgs& a, hipStream_t st) {
   const bool wide = a.Q > 16;  // 4x32 pixel tiles for wide maps, 8x16 otherwise
   if (a.K > 64) {
+    // 128 x 256 tiles (8x32 pixels, each wave 64 x 128): one filter slab feeds twice the MFMAs, at two
+    // workgroups per CU
+    if constexpr (R == 3 && S == 3) {
+      // ... when the launch still fills the 512 resident slots several times over
+      if (wide && a.P >= 8 && big_tiles_on() &&
+          (int64_t)a.N * cdiv(a.P, 8) * cdiv(a.Q, 32) * cdiv(a.K, 128) >= 2048)
+        return launch_cfg<R, S, RCH, STRIDE, DIL, CB, 2, 4, 2, 2, 8, 32>(a, st);
+    }
     return wide ? launch_cfg<R, S, RCH, STRIDE, DIL, CB, 2, 2, 2, 2, 4, 32>(a, st)
                 : launch_cfg<R, S, RCH, STRIDE, DIL, CB, 2, 2, 2, 2, 8, 16>(a, st);
   } else if (a.K > 32) {
