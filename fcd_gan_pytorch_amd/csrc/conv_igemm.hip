@@ -22,6 +22,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 int fcd_try_dgrad_thin(const fcd_conv_desc* d, const float* dy, const float* relu_out, const float* wp_bwd, float* dx,
                        hipStream_t st);  // conv_thin.hip
+int fcd_try_fwd_thin(const fcd_conv_desc* d, const float* x, const float* wp, const float* bias, float* y, int relu,
+                     hipStream_t st);    // conv_thin.hip
 
 // FCD_EXP: diagnostic builds only (results are wrong when set): 1 = no patch loads/stores in the
 // loop, 2 = no filter DMA in the loop, 4 = no barrier in the loop, 8 = operands from registers,
@@ -726,6 +728,15 @@ static int launch_cfg(const ConvArgs& a0, hipStream_t st) {
   }
 }
 
+static int thin_fwd_on() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("FCD_CONV_THINFWD");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v;
+}
+
 static int big_tiles_on() {
   static int v = -1;
   if (v < 0) {
@@ -812,6 +823,11 @@ extern "C" int fcd_conv2d_fwd_ex(const fcd_conv_desc* d, const float* x, const f
   const double bytes = 4.0 * ((double)d->N * d->C * d->H * d->W + (double)d->N * d->K * d->P * d->Q +
                               (double)d->K * d->C * d->R * d->S);
   FcdProfScope prof(FCD_K_CONV_FWD, (hipStream_t)stream, flops, bytes);
+  if (!a.act_slope && !residual && thin_fwd_on() &&
+      fcd_try_fwd_thin(d, x, wp, bias, y, a.relu, (hipStream_t)stream) == 0) {   // <= 4 input channels: VALU kernel
+    FCD_LAUNCH_CHECK("conv2d_fwd(thin)");
+    return FCD_OK;
+  }
   rc = conv_dispatch(a, d->R, d->S, d->stride, 1, (hipStream_t)stream);
   FCD_CHECK_ARG(rc == 0, "fcd_conv2d_fwd: unsupported filter %dx%d stride %d", d->R, d->S, d->stride);
   FCD_LAUNCH_CHECK("conv2d_fwd");

@@ -88,6 +88,212 @@ __global__ __launch_bounds__(256) void conv3x3_dgrad_thin_kernel(const float* __
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Same computation, W % 4 == 0: the 64-wide interior of every halo row is fetched with float4
+// loads (9 per thread and chunk instead of 37 dword loads with index arithmetic), and the loads
+// of chunk i+1 stay in flight while chunk i is consumed from LDS (values are only touched when
+// they are stored to LDS after the compute block).
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+template <int CS>
+__global__ __launch_bounds__(256) void conv3x3_dgrad_thin_v4_kernel(const float* __restrict__ dy,
+                                                                    const float* __restrict__ mask,
+                                                                    const float* __restrict__ wf, float* __restrict__ dx,
+                                                                    int K, int H, int W, int Cpad, int tiles_w) {
+  __shared__ float tile[TH_KC * TH_PH * TH_PWP];
+  const int tid = threadIdx.x;
+  const int n = blockIdx.y;
+  const int th = blockIdx.x / tiles_w, tw = blockIdx.x % tiles_w;
+  const int h0 = th * TH_ROWS, w0 = tw * TH_COLS;
+  const int row = tid >> 4, col = (tid & 15) * 4;
+  const bool has_mask = mask != nullptr;
+  float acc[CS][4];
+#pragma unroll
+  for (int c = 0; c < CS; ++c)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[c][j] = 0.f;
+
+  // interior items: 8 channels x 18 rows x 16 float4 = 2304 = 9 per thread
+  constexpr int NV = TH_KC * TH_PH * (TH_COLS / 4) / 256;
+  static_assert(NV * 256 == TH_KC * TH_PH * (TH_COLS / 4), "interior split");
+  int v_goff[NV], v_loff[NV], v_kk[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int idx = tid + i * 256;
+    const int rowid = idx >> 4, v4 = idx & 15;
+    const int kk = rowid / TH_PH, ph = rowid % TH_PH;
+    const int h = h0 + ph - 1, w = w0 + v4 * 4;
+    const bool ok = h >= 0 && h < H && w < W;
+    v_kk[i] = ok ? kk : (1 << 20);                       // never < remaining channels
+    v_goff[i] = ok ? (kk * H + h) * W + w : 0;
+    v_loff[i] = (kk * TH_PH + ph) * TH_PWP + 1 + v4 * 4;
+  }
+  // halo columns: 8 x 18 rows x 2 = 288 scalars (threads 0..255 one, threads 0..31 a second)
+  int s_goff[2], s_loff[2], s_kk[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = tid + i * 256;
+    const int rowid = idx >> 1, side = idx & 1;
+    const int kk = rowid / TH_PH, ph = rowid % TH_PH;
+    const int h = h0 + ph - 1, w = side ? w0 + TH_COLS : w0 - 1;
+    const bool ok = idx < TH_KC * TH_PH * 2 && h >= 0 && h < H && w >= 0 && w < W;
+    s_kk[i] = ok ? kk : (1 << 20);
+    s_goff[i] = ok ? (kk * H + h) * W + w : 0;
+    s_loff[i] = idx < TH_KC * TH_PH * 2 ? (kk * TH_PH + ph) * TH_PWP + (side ? TH_COLS + 1 : 0) : -1;
+  }
+
+  const size_t img = (size_t)n * K * H * W;
+  const size_t plane_chunk = (size_t)TH_KC * H * W;
+  f32x4_t dv[NV], mv[NV];
+  float ds_[2], ms_[2];
+
+#define THIN_LOAD(K0)                                                                     \
+  {                                                                                       \
+    const float* dsrc = dy + img + (size_t)((K0) / TH_KC) * plane_chunk;                  \
+    const float* msrc = (has_mask ? mask : dy) + img + (size_t)((K0) / TH_KC) * plane_chunk; \
+    const int kleft = K - (K0);                                                           \
+    _Pragma("unroll") for (int i = 0; i < NV; ++i) {                                      \
+      const int off = v_kk[i] < kleft ? v_goff[i] : 0;                                    \
+      dv[i] = *(const f32x4_t*)(dsrc + off);                                              \
+      if (has_mask) mv[i] = *(const f32x4_t*)(msrc + off);                                \
+    }                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                       \
+      const int off = s_kk[i] < kleft ? s_goff[i] : 0;                                    \
+      ds_[i] = dsrc[off];                                                                 \
+      if (has_mask) ms_[i] = msrc[off];                                                   \
+    }                                                                                     \
+  }
+#define THIN_STORE(K0)                                                                    \
+  {                                                                                       \
+    const int kleft = K - (K0);                                                           \
+    _Pragma("unroll") for (int i = 0; i < NV; ++i) {                                      \
+      const bool ok = v_kk[i] < kleft;                                                    \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                       \
+        tile[v_loff[i] + j] = (ok && (!has_mask || mv[i][j] > 0.f)) ? dv[i][j] : 0.f;     \
+    }                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                         \
+      if (s_loff[i] >= 0)                                                                 \
+        tile[s_loff[i]] = (s_kk[i] < kleft && (!has_mask || ms_[i] > 0.f)) ? ds_[i] : 0.f; \
+  }
+
+  THIN_LOAD(0)
+  THIN_STORE(0)
+  __syncthreads();
+  for (int k0 = 0; k0 < K; k0 += TH_KC) {
+    const bool have_next = k0 + TH_KC < K;
+    if (have_next) THIN_LOAD(k0 + TH_KC)
+#pragma unroll 1
+    for (int kk = 0; kk < TH_KC; ++kk) {
+      const float* wk = wf + (size_t)(k0 + kk) * 9 * Cpad;     // wave-uniform -> scalar loads
+      float wv[9][CS];
+#pragma unroll
+      for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+        for (int c = 0; c < CS; ++c) wv[t9][c] = wk[t9 * Cpad + c];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const float* t = tile + (kk * TH_PH + row + r) * TH_PWP + col;
+        float win[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) win[j] = t[j];
+#pragma unroll
+        for (int s2 = 0; s2 < 3; ++s2)
+#pragma unroll
+          for (int c = 0; c < CS; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[c][j] = fmaf(win[j + s2], wv[r * 3 + s2][c], acc[c][j]);
+      }
+    }
+    __syncthreads();
+    if (have_next) THIN_STORE(k0 + TH_KC)
+    __syncthreads();
+  }
+#undef THIN_LOAD
+#undef THIN_STORE
+  const int h = h0 + row;
+  if (h < H && w0 + col < W) {
+#pragma unroll
+    for (int c = 0; c < CS; ++c) {
+      f32x4_t o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = acc[c][j];
+      *(f32x4_t*)(dx + (((size_t)n * CS + c) * H + h) * W + w0 + col) = o;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Forward of a 3x3 / stride-1 / pad-1 convolution with 1..4 INPUT channels and > 32 output
+// channels (VGG conv1_1 on single bands, Loss.py:25,52-58; Segmentor.inc on 3/4-band tiles):
+//   y[n,k,h,w] = act(b[k] + sum_{c,r,s} w[k,c,r,s] * x[n,c,h+r-1,w+s-1])
+// One pass over x, one over y: bound by the HBM write of y.  Every thread keeps the 3x6 input
+// window of its 1x4 pixel strip in registers for all output channels; filter taps are
+// wave-uniform scalar loads from the T-layout pack (conv_igemm.hip):
+//   w(k, c, tap) = wp[((c >> 1) * Mpad + k) * 20 + (c & 1) * 9 + tap].
+template <int CS>
+__global__ __launch_bounds__(256) void conv3x3_fwd_thin_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                               const float* __restrict__ bias, float* __restrict__ y,
+                                                               int K, int Mpad, int H, int W, int tiles_w, int relu) {
+  __shared__ float tile[CS * TH_PH * TH_PWP];
+  const int tid = threadIdx.x;
+  const int n = blockIdx.y;
+  const int th = blockIdx.x / tiles_w, tw = blockIdx.x % tiles_w;
+  const int h0 = th * TH_ROWS, w0 = tw * TH_COLS;
+  const int row = tid >> 4, col = (tid & 15) * 4;
+  for (int i = tid; i < CS * TH_PH * TH_PW; i += 256) {
+    const int c = i / (TH_PH * TH_PW), rem = i % (TH_PH * TH_PW);
+    const int ph = rem / TH_PW, pw = rem % TH_PW;
+    const int h = h0 + ph - 1, w = w0 + pw - 1;
+    float v = 0.f;
+    if (h >= 0 && h < H && w >= 0 && w < W) v = x[(((size_t)n * CS + c) * H + h) * W + w];
+    tile[(c * TH_PH + ph) * TH_PWP + pw] = v;
+  }
+  __syncthreads();
+  float win[CS][3][6];
+#pragma unroll
+  for (int c = 0; c < CS; ++c)
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) win[c][r][j] = tile[(c * TH_PH + row + r) * TH_PWP + col + j];
+  const int h = h0 + row;
+  const bool row_ok = h < H && w0 + col < W;
+  const bool vec_ok = (W & 3) == 0;
+  float* yrow = y + ((size_t)n * K * H + h) * W + w0 + col;
+#pragma unroll 2
+  for (int k = 0; k < K; ++k) {
+    const float b = bias ? bias[k] : 0.f;
+    float a4[4] = {b, b, b, b};
+#pragma unroll
+    for (int c = 0; c < CS; ++c) {
+      const float* wk = wp + ((size_t)(c >> 1) * Mpad + k) * 20 + (c & 1) * 9;      // wave-uniform
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int s2 = 0; s2 < 3; ++s2) {
+          const float wv = wk[r * 3 + s2];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) a4[j] = fmaf(win[c][r][j + s2], wv, a4[j]);
+        }
+    }
+    if (relu) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a4[j] = a4[j] > 0.f ? a4[j] : 0.f;
+    }
+    if (row_ok) {
+      float* o = yrow + (size_t)k * H * W;
+      if (vec_ok) {
+        f32x4_t v = {a4[0], a4[1], a4[2], a4[3]};
+        *(f32x4_t*)o = v;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (w0 + col + j < W) o[j] = a4[j];
+      }
+    }
+  }
+}
+
 // returns 0 when handled, 1 when the shape is not a thin-channel case
 int fcd_try_dgrad_thin(const fcd_conv_desc* d, const float* dy, const float* relu_out, const float* wp_bwd, float* dx,
                        hipStream_t st) {
@@ -95,11 +301,43 @@ int fcd_try_dgrad_thin(const fcd_conv_desc* d, const float* dy, const float* rel
   const int tiles_w = cdiv(d->W, TH_COLS), tiles_h = cdiv(d->H, TH_ROWS);
   const int Cpad = round_up(d->C, 128);
   dim3 grid((unsigned)(tiles_w * tiles_h), (unsigned)d->N);
-  switch (d->C) {
-    case 1: hipLaunchKernelGGL(conv3x3_dgrad_thin_kernel<1>, grid, dim3(256), 0, st, dy, relu_out, wp_bwd, dx, d->K, d->H, d->W, Cpad, tiles_w); break;
-    case 2: hipLaunchKernelGGL(conv3x3_dgrad_thin_kernel<2>, grid, dim3(256), 0, st, dy, relu_out, wp_bwd, dx, d->K, d->H, d->W, Cpad, tiles_w); break;
-    case 3: hipLaunchKernelGGL(conv3x3_dgrad_thin_kernel<3>, grid, dim3(256), 0, st, dy, relu_out, wp_bwd, dx, d->K, d->H, d->W, Cpad, tiles_w); break;
-    default: hipLaunchKernelGGL(conv3x3_dgrad_thin_kernel<4>, grid, dim3(256), 0, st, dy, relu_out, wp_bwd, dx, d->K, d->H, d->W, Cpad, tiles_w); break;
+#define THIN_LAUNCH(KERNEL, CS_)                                                                              \
+  hipLaunchKernelGGL(KERNEL<CS_>, grid, dim3(256), 0, st, dy, relu_out, wp_bwd, dx, d->K, d->H, d->W, Cpad, tiles_w)
+  if ((d->W & 3) == 0 && (d->K % TH_KC) == 0) {     // float4 rows, whole 8-channel chunks
+    switch (d->C) {
+      case 1: THIN_LAUNCH(conv3x3_dgrad_thin_v4_kernel, 1); break;
+      case 2: THIN_LAUNCH(conv3x3_dgrad_thin_v4_kernel, 2); break;
+      case 3: THIN_LAUNCH(conv3x3_dgrad_thin_v4_kernel, 3); break;
+      default: THIN_LAUNCH(conv3x3_dgrad_thin_v4_kernel, 4); break;
+    }
+    return 0;
   }
+  switch (d->C) {
+    case 1: THIN_LAUNCH(conv3x3_dgrad_thin_kernel, 1); break;
+    case 2: THIN_LAUNCH(conv3x3_dgrad_thin_kernel, 2); break;
+    case 3: THIN_LAUNCH(conv3x3_dgrad_thin_kernel, 3); break;
+    default: THIN_LAUNCH(conv3x3_dgrad_thin_kernel, 4); break;
+  }
+#undef THIN_LAUNCH
+  return 0;
+}
+
+// returns 0 when handled, 1 when the shape / epilogue is not covered by the thin forward kernel
+int fcd_try_fwd_thin(const fcd_conv_desc* d, const float* x, const float* wp, const float* bias, float* y, int relu,
+                     hipStream_t st) {
+  if (!(d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1 && d->C >= 1 && d->C <= 4 && d->K > 32)) return 1;
+  const int tiles_w = cdiv(d->W, TH_COLS), tiles_h = cdiv(d->H, TH_ROWS);
+  const int Mpad = round_up(d->K, 128);
+  dim3 grid((unsigned)(tiles_w * tiles_h), (unsigned)d->N);
+#define THIN_LAUNCH(CS_)                                                                                       \
+  hipLaunchKernelGGL(conv3x3_fwd_thin_kernel<CS_>, grid, dim3(256), 0, st, x, wp, bias, y, d->K, Mpad, d->H, d->W, \
+                     tiles_w, relu)
+  switch (d->C) {
+    case 1: THIN_LAUNCH(1); break;
+    case 2: THIN_LAUNCH(2); break;
+    case 3: THIN_LAUNCH(3); break;
+    default: THIN_LAUNCH(4); break;
+  }
+#undef THIN_LAUNCH
   return 0;
 }

@@ -51,6 +51,14 @@ CONV_CASES = [
     (3, 1024, 1, 1, 1, 1, 1, 0),
     (2, 3, 48, 40, 64, 3, 1, 1),
     (2, 512, 6, 5, 512, 3, 1, 1),
+    # thin (<= 4 input channels) VALU kernels: forward (K > 32) and data gradient, float4 rows
+    # (W % 4 == 0, K % 8 == 0) and the generic variants, tile edges in both directions
+    (2, 1, 40, 72, 64, 3, 1, 1),
+    (1, 1, 19, 21, 64, 3, 1, 1),
+    (2, 2, 17, 132, 72, 3, 1, 1),
+    (1, 4, 33, 68, 40, 3, 1, 1),
+    (2, 3, 16, 64, 44, 3, 1, 1),
+    (1, 2, 5, 7, 16, 3, 1, 1),
 ]
 
 
@@ -75,7 +83,7 @@ def test_conv2d_fwd_bwd(case):
 
 
 @pytest.mark.parametrize('case', [(2, 3, 24, 40, 64, 3, 1, 1), (2, 64, 20, 28, 128, 3, 1, 1), (3, 16, 9, 7, 24, 3, 1, 1),
-                                  (2, 8, 16, 16, 40, 3, 2, 1)], ids=lambda c: 'x'.join(map(str, c)))
+                                  (2, 8, 16, 16, 40, 3, 2, 1), (2, 1, 36, 68, 64, 3, 1, 1), (1, 1, 21, 30, 64, 3, 1, 1)], ids=lambda c: 'x'.join(map(str, c)))
 def test_conv2d_fused_relu(case):
     """conv + bias + ReLU in the kernel epilogue; backward re-derives the mask from the output."""
     ops = _ops()
