@@ -352,13 +352,57 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_roll_kernel(WgradArgs a) {
   }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, long long n,
-                                    int splits) {
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (long long)gridDim.x * blockDim.x) {
+// dw = sum over split-K partials (fixed order => deterministic).  float4 streams, four independent
+// loads in flight per partial; n4 = n / 4 vectors, the (n % 4) tail is handled by the last threads.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                           long long n, int splits) {
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  const long long n4 = n >> 2;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  // every partial starts 16-B aligned when n % 4 == 0 and the bases are
+  const bool aligned = (n & 3) == 0 && (((size_t)part | (size_t)dw) & 15) == 0;
+  if (aligned) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+      v4 s = *(const v4*)(part + 4 * i);
+      for (int k = 1; k < splits; ++k) s += *(const v4*)(part + (long long)k * n + 4 * i);
+      *(v4*)(dw + 4 * i) = s;
+    }
+    return;
+  }
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     float s = 0.f;
     for (int k = 0; k < splits; ++k) s += part[(long long)k * n + i];
     dw[i] = s;
+  }
+}
+
+// Many partials, few elements (small filters are split up to 1024 ways): 64 float4 columns per
+// block, the partials dealt round-robin to 4 groups of 64 threads (4 loads in flight each), group
+// sums combined in fixed order through LDS => deterministic.
+__global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                                long long n, int splits) {
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  __shared__ v4 red[4][64];
+  const int tx = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const long long i = (long long)blockIdx.x * 64 + tx;
+  const long long n4 = n >> 2;
+  v4 s = {0.f, 0.f, 0.f, 0.f};
+  if (i < n4) {
+    const float* p = part + 4 * i;
+    int k = g;
+    for (; k + 12 < splits; k += 16) {
+      const v4 a0 = *(const v4*)(p + (long long)k * n), a1 = *(const v4*)(p + (long long)(k + 4) * n),
+               a2 = *(const v4*)(p + (long long)(k + 8) * n), a3 = *(const v4*)(p + (long long)(k + 12) * n);
+      s += a0; s += a1; s += a2; s += a3;
+    }
+    for (; k < splits; k += 4) s += *(const v4*)(p + (long long)k * n);
+  }
+  red[g][tx] = s;
+  __syncthreads();
+  if (g == 0 && i < n4) {
+    v4 t = red[0][tx];
+    t += red[1][tx]; t += red[2][tx]; t += red[3][tx];
+    *(v4*)(dw + 4 * i) = t;
   }
 }
 
@@ -536,8 +580,13 @@ extern "C" int fcd_conv2d_bwd_weight(const fcd_conv_desc* d, const float* x, con
   FCD_LAUNCH_CHECK("conv2d_bwd_weight");
   if (pl.splits > 1) {
     const long long n = a.split_stride;
-    const int grid = (int)std::min<long long>(cdiv64(n, 256), 2048);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, (const float*)part, dw, n, pl.splits);
+    if (pl.splits >= 8 && (n & 3) == 0 && (((size_t)part | (size_t)dw) & 15) == 0) {
+      hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3((unsigned)cdiv64(n >> 2, 64)), dim3(256), 0, st,
+                         (const float*)part, dw, n, pl.splits);
+    } else {
+      const int grid = (int)std::min<long long>(cdiv64(cdiv64(n, 4), 256), 4096);
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, (const float*)part, dw, n, pl.splits);
+    }
     FCD_LAUNCH_CHECK("wgrad_reduce");
   }
   return FCD_OK;
