@@ -57,6 +57,7 @@ _SIGS = {
     'fcd_conv2d_bwd_data_pooled': (c_int, [POINTER(ConvDesc), P, P, P, P, P]),
     'fcd_conv2d_bwd_weight_ws_bytes': (c_size_t, [POINTER(ConvDesc)]),
     'fcd_conv2d_bwd_weight': (c_int, [POINTER(ConvDesc), P, P, P, P, P, c_size_t, P]),
+    'fcd_conv2d_bwd_weight_bias': (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, c_size_t, P]),
     'fcd_channel_sum_ws_bytes': (c_size_t, [c_int]),
     'fcd_channel_sum': (c_int, [P, P, P, c_int, c_int, c_int, P, c_size_t, P]),
     'fcd_bn_act_ws_bytes': (c_size_t, [c_int, c_int]),

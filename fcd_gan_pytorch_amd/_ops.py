@@ -107,12 +107,15 @@ class _Conv2d(torch.autograd.Function):
             wpb = packed_weight(weight, 1)
             check(lib.fcd_conv2d_bwd_data(ctypes.byref(d), _p(dy), _p(yrelu), _p(wpb), _p(dx), _stream()),
                   'fcd_conv2d_bwd_data')
+        want_db = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             dw = torch.empty(weight.shape, dtype=torch.float32, device=dy.device)
+            if want_db:        # channel sums come out of the dy re-layout pass of the weight gradient
+                db = torch.empty((d.K,), dtype=torch.float32, device=dy.device)
             ws = _ws(lib.fcd_conv2d_bwd_weight_ws_bytes(ctypes.byref(d)), dy.device)
-            check(lib.fcd_conv2d_bwd_weight(ctypes.byref(d), _p(x), _p(dy), _p(yrelu), _p(dw), _p(ws), ws.numel(),
-                                            _stream()), 'fcd_conv2d_bwd_weight')
-        if has_bias and ctx.needs_input_grad[2]:
+            check(lib.fcd_conv2d_bwd_weight_bias(ctypes.byref(d), _p(x), _p(dy), _p(yrelu), _p(dw), _p(db), _p(ws),
+                                                 ws.numel(), _stream()), 'fcd_conv2d_bwd_weight_bias')
+        elif want_db:
             db = _channel_sum(dy, yrelu, d.N, d.K, d.P * d.Q)
         return dx, dw, db, None, None, None
 

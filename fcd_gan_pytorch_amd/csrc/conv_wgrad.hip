@@ -53,9 +53,12 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
 }
 
 // 64x64 tile, float4 on both sides (HW % 4 == 0): 256-B rows in, 256-B channel rows out
+// psum (optional): per-block channel sums of the (masked) tile, [n * gridDim.x + blockIdx.x][Cp] floats --
+// the bias gradient falls out of the pass that re-lays dy out for the weight gradient.
 __global__ __launch_bounds__(256) void nchw_to_nhwc_v4_kernel(const float* __restrict__ src,
                                                               const float* __restrict__ mask,
-                                                              float* __restrict__ dst, int C, int HW, int Cp) {
+                                                              float* __restrict__ dst, int C, int HW, int Cp,
+                                                              float* __restrict__ psum) {
   __shared__ float tile[64][65];
   const int n = blockIdx.z;
   const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
@@ -82,6 +85,15 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_v4_kernel(const float* __res
     tile[cr][p4 + 0] = v.x; tile[cr][p4 + 1] = v.y; tile[cr][p4 + 2] = v.z; tile[cr][p4 + 3] = v.w;
   }
   __syncthreads();
+  if (psum != nullptr) {                   // 4 threads per channel row, 16 pixels each, fixed order
+    const int cr = t >> 2, q = t & 3;
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a += tile[cr][q * 16 + i];
+    a += __shfl_xor(a, 1, 64);
+    a += __shfl_xor(a, 2, 64);
+    if (q == 0) psum[((size_t)n * gridDim.x + blockIdx.x) * Cp + c0 + cr] = a;
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int idx = t + j * 256;          // 64 pixel rows x 16 float4 of channels
@@ -94,11 +106,22 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_v4_kernel(const float* __res
   }
 }
 
+// db[c] = sum of the per-block partials (fp64 accumulation, fixed order)
+__global__ __launch_bounds__(256) void channel_psum_fin_kernel(const float* __restrict__ psum, float* __restrict__ out,
+                                                               int C, int Cp, int nblk) {
+  __shared__ double red[16];
+  const int c = blockIdx.x;
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += 256) s += (double)psum[(size_t)b * Cp + c];
+  s = block_sum_d(s, red);
+  if (threadIdx.x == 0 && c < C) out[c] = (float)s;
+}
+
 static void launch_transpose(const float* src, const float* mask, float* dst, int N, int C, int HW, int Cp,
-                             hipStream_t st) {
+                             hipStream_t st, float* psum = nullptr) {
   if ((HW & 3) == 0)
     hipLaunchKernelGGL(nchw_to_nhwc_v4_kernel, dim3(cdiv(HW, 64), Cp / 64, N), dim3(256), 0, st, src, mask, dst, C, HW,
-                       Cp);
+                       Cp, psum);
   else
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(cdiv(HW, 32), Cp / 32, N), dim3(256), 0, st, src, mask, dst, C, HW,
                        Cp);
@@ -463,7 +486,7 @@ extern "C" int fcd_channel_sum(const float* x, const float* relu_out, float* out
 // ---------------------------------------------------------------------------
 struct WgradPlan {
   int TW, RB, tiles_q, total_tiles, tiles_per_split, splits, k_tiles, c_tiles, r_groups, Cp, Kp;
-  size_t xt_bytes, dyt_bytes, part_bytes, zero_bytes;
+  size_t xt_bytes, dyt_bytes, part_bytes, zero_bytes, psum_bytes;
 };
 
 static bool wgrad_plan(const fcd_conv_desc* d, WgradPlan* pl) {
@@ -495,13 +518,17 @@ static bool wgrad_plan(const fcd_conv_desc* d, WgradPlan* pl) {
   pl->dyt_bytes = (size_t)d->N * d->P * d->Q * pl->Kp * sizeof(float);
   pl->part_bytes = pl->splits > 1 ? (size_t)pl->splits * dw_bytes : 0;
   pl->zero_bytes = 1024;
+  // bias gradient: per-block channel partials of the dy re-layout (float4 path), else the
+  // two-stage channel_sum workspace
+  pl->psum_bytes = std::max((size_t)d->N * cdiv(d->P * d->Q, 64) * pl->Kp * sizeof(float),
+                            (size_t)d->K * 64 * sizeof(double));
   return true;
 }
 
 extern "C" size_t fcd_conv2d_bwd_weight_ws_bytes(const fcd_conv_desc* d) {
   WgradPlan pl;
   if (!d || !wgrad_plan(d, &pl)) return 0;
-  return pl.zero_bytes + pl.xt_bytes + pl.dyt_bytes + pl.part_bytes;
+  return pl.zero_bytes + pl.xt_bytes + pl.dyt_bytes + pl.part_bytes + pl.psum_bytes;
 }
 
 static int wgrad_roll() {
@@ -519,8 +546,18 @@ static void launch_wgrad(const WgradArgs& a, const WgradPlan& pl, hipStream_t st
   hipLaunchKernelGGL((conv_wgrad_kernel<R, S, RB, STRIDE, TW>), grid, dim3(256), 0, st, a);
 }
 
+extern "C" int fcd_conv2d_bwd_weight_bias(const fcd_conv_desc* d, const float* x, const float* dy,
+                                          const float* relu_out, float* dw, float* db, void* ws, size_t ws_bytes,
+                                          void* stream);
+
 extern "C" int fcd_conv2d_bwd_weight(const fcd_conv_desc* d, const float* x, const float* dy, const float* relu_out,
                                      float* dw, void* ws, size_t ws_bytes, void* stream) {
+  return fcd_conv2d_bwd_weight_bias(d, x, dy, relu_out, dw, nullptr, ws, ws_bytes, stream);
+}
+
+extern "C" int fcd_conv2d_bwd_weight_bias(const fcd_conv_desc* d, const float* x, const float* dy,
+                                          const float* relu_out, float* dw, float* db, void* ws, size_t ws_bytes,
+                                          void* stream) {
   FCD_CHECK_ARG(d && x && dy && dw, "fcd_conv2d_bwd_weight: null pointer");
   WgradPlan pl;
   FCD_CHECK_ARG(wgrad_plan(d, &pl), "fcd_conv2d_bwd_weight: unsupported filter %dx%d stride %d", d->R, d->S,
@@ -535,7 +572,8 @@ extern "C" int fcd_conv2d_bwd_weight(const fcd_conv_desc* d, const float* x, con
   float* zeros = (float*)wsp; wsp += pl.zero_bytes;
   float* xt = (float*)wsp;    wsp += pl.xt_bytes;
   float* dyt = (float*)wsp;   wsp += pl.dyt_bytes;
-  float* part = (float*)wsp;
+  float* part = (float*)wsp;  wsp += pl.part_bytes;
+  float* psum = (float*)wsp;
   const double flops = 2.0 * d->N * d->K * (double)d->P * d->Q * d->C * d->R * d->S;
   const double bytes = 4.0 * ((double)d->N * d->C * d->H * d->W + (double)d->N * d->K * d->P * d->Q +
                               (double)d->K * d->C * d->R * d->S);
@@ -548,7 +586,19 @@ extern "C" int fcd_conv2d_bwd_weight(const fcd_conv_desc* d, const float* x, con
     const int HW = d->H * d->W;
     launch_transpose(x, nullptr, xt, d->N, d->C, HW, pl.Cp, st);
     const int PQ = d->P * d->Q;
-    launch_transpose(dy, relu_out, dyt, d->N, d->K, PQ, pl.Kp, st);
+    const bool fused_db = db != nullptr && (PQ & 3) == 0;
+    launch_transpose(dy, relu_out, dyt, d->N, d->K, PQ, pl.Kp, st, fused_db ? psum : nullptr);
+    if (fused_db) {
+      hipLaunchKernelGGL(channel_psum_fin_kernel, dim3(d->K), dim3(256), 0, st, (const float*)psum, db, d->K, pl.Kp,
+                         d->N * cdiv(PQ, 64));
+    } else if (db != nullptr) {
+      int nsplit = std::min(std::min<long long>(cdiv(1024, d->K), std::max<long long>(1, (long long)d->N * PQ / 1024)),
+                            (long long)64);
+      hipLaunchKernelGGL(channel_sum_part_kernel, dim3(d->K, nsplit), dim3(256), 0, st, dy, relu_out, (double*)psum,
+                         d->N, d->K, PQ, nsplit);
+      hipLaunchKernelGGL(channel_sum_fin_kernel, dim3(cdiv(d->K, 128)), dim3(128), 0, st, (const double*)psum, db,
+                         d->K, nsplit);
+    }
   }
   WgradArgs a;
   memset(&a, 0, sizeof(a));

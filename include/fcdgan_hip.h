@@ -92,6 +92,11 @@ int fcd_conv2d_bwd_data_pooled(const fcd_conv_desc* d, const float* dy_pool,
 size_t fcd_conv2d_bwd_weight_ws_bytes(const fcd_conv_desc* d);
 int fcd_conv2d_bwd_weight(const fcd_conv_desc* d, const float* x, const float* dy,
                           const float* relu_out, float* dw, void* ws, size_t ws_bytes, void* stream);
+/* Same, plus the bias gradient db[k] = sum_{n,p,q} dy' (NULL: skipped): the channel sums are a
+ * by-product of the pass that re-lays dy out for the weight-gradient kernel, so dy is not read again. */
+int fcd_conv2d_bwd_weight_bias(const fcd_conv_desc* d, const float* x, const float* dy,
+                               const float* relu_out, float* dw, float* db, void* ws, size_t ws_bytes,
+                               void* stream);
 /* out[c] = sum over (n, hw) of x[n,c,hw] (* [relu_out > 0] when given) -- bias gradients. */
 size_t fcd_channel_sum_ws_bytes(int C);
 int fcd_channel_sum(const float* x, const float* relu_out, float* out, int N, int C, int HW,
