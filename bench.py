@@ -252,6 +252,25 @@ def main():
                 res['roofline']['traffic'] = tj['hbm_bytes_per_launch']
                 res['roofline']['traffic_unit'] = 'HBM bytes per launch (PMC, profiles/r01_hbm_traffic.json)'
                 res['roofline']['algorithmic_bytes_per_launch'] = (fwd['bytes'] + dg['bytes']) / max(launches, 1)
+            wf, wd = prof.get('conv_wino_fwd'), prof.get('conv_wino_dgrad')
+            if wf and wd and (wf['launches'] + wd['launches']) > 0:
+                wms, wfl = wf['ms'] + wd['ms'], wf['flops'] + wd['flops']
+                from fcd_gan_pytorch_amd import _lib as _l
+                mt = _l.lib.fcd_conv_wino_set(-1)
+                red = {2: 2.25, 4: 4.0}.get(mt, 1.0)
+                res['winograd'] = {
+                    'what': 'wide 3x3 / stride-1 layers (>= 256 reduction channels) run as Winograd F(%dx%d, 3x3): input '
+                            'transform + batched fp32 MFMA GEMM + output transform; same results within fp32 rounding '
+                            '(<= 2e-5 relative), %.2fx fewer multiplies than the direct convolution' % (mt, mt, red),
+                    'launches_per_step': (wf['launches'] + wd['launches']) / args.steps, 'ms_per_step': wms / args.steps,
+                    'algorithmic_tflops': wfl / (wms * 1e-3) / 1e12,
+                    'executed_mfma_tflops_approx': wfl / red / (wms * 1e-3) / 1e12,
+                    'hbm_gbps_streamed': (wf['bytes'] + wd['bytes']) / (wms * 1e-3) / 1e9,
+                    'share_of_step_time': wms / (1e3 * dt),
+                }
+                res['roofline']['note'] = ('direct MFMA implicit-GEMM launches only; the Winograd launches are reported '
+                                           'under "winograd" (their algorithmic rate exceeds the MFMA peak by construction)')
+                res['conv_all_algorithmic_tflops'] = (flops + wfl) / ((ms + wms) * 1e-3) / 1e12
             res['kernel_families'] = {
                 k: {'ms_per_step': v['ms'] / args.steps, 'launches_per_step': v['launches'] / args.steps,
                     'tflops': (v['flops'] / (v['ms'] * 1e-3) / 1e12) if v['ms'] > 0 and v['flops'] > 0 else None,

@@ -67,6 +67,51 @@ def packed_weight(weight, mode):
     return wp
 
 
+def wino_weight(weight, mode, m):
+    """Winograd-transformed filters (fcd_conv_wino_pack), cached like :func:`packed_weight`."""
+    cache = weight.__dict__.setdefault('_fcd_pack', {})
+    ver = weight._version
+    key = ('wino', mode, m)
+    hit = cache.get(key)
+    if hit is not None and hit[0] == ver and hit[1].device == weight.device:
+        return hit[1]
+    K, C = weight.shape[:2]
+    U = torch.empty(lib.fcd_conv_wino_filter_elems(K, C, mode, m), dtype=torch.float32, device=weight.device)
+    w = weight.detach().contiguous()
+    check(lib.fcd_conv_wino_pack(_p(w), _p(U), K, C, mode, m, _stream()), 'fcd_conv_wino_pack')
+    cache[key] = (ver, U)
+    return U
+
+
+def _fwd_conv(d, x, weight, bias, y, relu, pool_y=None, code=None):
+    """Forward launch: Winograd path when the library plans one for this layer, else direct."""
+    m = lib.fcd_conv_wino_plan(ctypes.byref(d), 0)
+    if m:
+        ws = _ws(lib.fcd_conv_wino_ws_bytes(ctypes.byref(d), 0), x.device)
+        check(lib.fcd_conv2d_fwd_wino(ctypes.byref(d), _p(x), _p(wino_weight(weight, 0, m)), _p(bias), _p(y), int(relu),
+                                      _p(pool_y), _p(code), _p(ws), ws.numel(), _stream()), 'fcd_conv2d_fwd_wino')
+    elif pool_y is not None:
+        check(lib.fcd_conv2d_fwd_relu_pool(ctypes.byref(d), _p(x), _p(packed_weight(weight, 0)), _p(bias), _p(pool_y),
+                                           _p(code), _stream()), 'fcd_conv2d_fwd_relu_pool')
+    else:
+        check(lib.fcd_conv2d_fwd(ctypes.byref(d), _p(x), _p(packed_weight(weight, 0)), _p(bias), _p(y), int(relu),
+                                 _stream()), 'fcd_conv2d_fwd')
+
+
+def _bwd_data_conv(d, dy, weight, dx, yrelu=None, code=None):
+    m = lib.fcd_conv_wino_plan(ctypes.byref(d), 1)
+    if m:
+        ws = _ws(lib.fcd_conv_wino_ws_bytes(ctypes.byref(d), 1), dy.device)
+        check(lib.fcd_conv2d_bwd_data_wino(ctypes.byref(d), _p(dy), _p(yrelu), _p(code), _p(wino_weight(weight, 1, m)),
+                                           _p(dx), _p(ws), ws.numel(), _stream()), 'fcd_conv2d_bwd_data_wino')
+    elif code is not None:
+        check(lib.fcd_conv2d_bwd_data_pooled(ctypes.byref(d), _p(dy), _p(code), _p(packed_weight(weight, 1)), _p(dx),
+                                             _stream()), 'fcd_conv2d_bwd_data_pooled')
+    else:
+        check(lib.fcd_conv2d_bwd_data(ctypes.byref(d), _p(dy), _p(yrelu), _p(packed_weight(weight, 1)), _p(dx),
+                                      _stream()), 'fcd_conv2d_bwd_data')
+
+
 def invalidate_packs(params):
     for p in params:
         p.__dict__.pop('_fcd_pack', None)
@@ -86,10 +131,8 @@ class _Conv2d(torch.autograd.Function):
         _dev(weight, 'conv weight')
         d = _desc(x.shape, weight.shape, stride, pad)
         y = torch.empty((d.N, d.K, d.P, d.Q), dtype=torch.float32, device=x.device)
-        wp = packed_weight(weight, 0)
         b = _dev(bias, 'conv bias') if bias is not None else None
-        check(lib.fcd_conv2d_fwd(ctypes.byref(d), _p(x), _p(wp), _p(b), _p(y), int(relu), _stream()),
-              'fcd_conv2d_fwd')
+        _fwd_conv(d, x, weight, b, y, relu)
         # x is only needed for the weight gradient; the fused-ReLU output doubles as the backward mask
         ctx.save_for_backward(x if weight.requires_grad else None, weight, y if relu else None)
         ctx.geom = (stride, pad, bias is not None, tuple(x.shape))
@@ -104,9 +147,7 @@ class _Conv2d(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(xshape, dtype=torch.float32, device=dy.device)
-            wpb = packed_weight(weight, 1)
-            check(lib.fcd_conv2d_bwd_data(ctypes.byref(d), _p(dy), _p(yrelu), _p(wpb), _p(dx), _stream()),
-                  'fcd_conv2d_bwd_data')
+            _bwd_data_conv(d, dy, weight, dx, yrelu=yrelu)
         want_db = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             dw = torch.empty(weight.shape, dtype=torch.float32, device=dy.device)
@@ -151,9 +192,7 @@ class _ConvReluPool(torch.autograd.Function):
         d = _desc(x.shape, weight.shape, 1, 1)
         yp = torch.empty((d.N, d.K, d.P // 2, d.Q // 2), dtype=torch.float32, device=x.device)
         code = torch.empty(yp.shape, dtype=torch.uint8, device=x.device)
-        wp = packed_weight(weight, 0)
-        check(lib.fcd_conv2d_fwd_relu_pool(ctypes.byref(d), _p(x), _p(wp), _p(bias), _p(yp), _p(code), _stream()),
-              'fcd_conv2d_fwd_relu_pool')
+        _fwd_conv(d, x, weight, bias, None, True, pool_y=yp, code=code)
         ctx.save_for_backward(weight, code)
         ctx.xshape = tuple(x.shape)
         return yp
@@ -166,9 +205,7 @@ class _ConvReluPool(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(ctx.xshape, dtype=torch.float32, device=dyp.device)
-            wpb = packed_weight(weight, 1)
-            check(lib.fcd_conv2d_bwd_data_pooled(ctypes.byref(d), _p(dyp), _p(code), _p(wpb), _p(dx), _stream()),
-                  'fcd_conv2d_bwd_data_pooled')
+            _bwd_data_conv(d, dyp, weight, dx, code=code)
         return dx, None, None
 
 

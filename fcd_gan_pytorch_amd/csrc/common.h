@@ -42,7 +42,9 @@ enum {
   FCD_K_LOSS = 6,       // masked recon, SSIM, reductions
   FCD_K_OPTIM = 7,      // Adam / RMSprop
   FCD_K_MISC = 8,
-  FCD_K_COUNT = 9
+  FCD_K_WINO_FWD = 9,   // Winograd path (input transform + batched MFMA GEMM + output transform), forward
+  FCD_K_WINO_DGRAD = 10,// ... used as data gradient
+  FCD_K_COUNT = 11
 };
 
 struct FcdProfScope {

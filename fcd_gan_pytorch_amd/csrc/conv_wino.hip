@@ -1,0 +1,585 @@
+// Winograd F(m x m, 3 x 3) path for the wide 3x3 / stride-1 / pad-1 layers (>= 256 reduction
+// channels: VGG conv3_2 .. conv5_3, the bottom of the U-Net) -- Module.py:25-31, Loss.py:25.
+//
+//   y = A^T [ sum_c (G g G^T) (.) (B^T d B) ] A            (Lavin & Gray 2016, m = 2 or 4)
+//
+// per (m+2)^2 transform position xi the channel sum is a plain GEMM
+//   M_xi[k][t] = sum_c U_xi[k][c] * V_xi[t][c]             t = image tile index
+// with 2.25x (m = 2) / 4x (m = 4) fewer multiplies than the direct convolution.  Three kernels:
+//   wino_input_kernel   x (or the gated / pooled gradient)  -> V   [xi][chunk of 32 ch][t][32]   HBM-bound
+//   wino_gemm_kernel    batched TN GEMM on v_mfma_f32_32x32x2_f32                                MFMA-bound
+//   wino_output_kernel  M [xi][k][t] -> y (+bias, ReLU, 2x2 max-pool with argmax code)          HBM-bound
+// The transformed filters U [xi][rows][channels padded to 32] are packed once per weight version
+// (fcd_conv_wino_pack): mode 0 forward, mode 1 data gradient (flipped taps, channels swapped).
+// The same arithmetic order is used for every launch => bit-reproducible; fp32 rounding of the
+// m = 4 transforms is ~1e-5 relative (tests/test_gpu_ops.py), m = 2 ~3e-7.
+#include <stdlib.h>
+
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+
+// --------------------------------------------------------------------------------------------
+// transform matrices
+template <int M> struct WinoMat;
+template <> struct WinoMat<2> {
+  static constexpr int A = 4;
+  __host__ __device__ static constexpr float BT(int i, int j) {
+    constexpr float t[4][4] = {{1, 0, -1, 0}, {0, 1, 1, 0}, {0, -1, 1, 0}, {0, 1, 0, -1}};
+    return t[i][j];
+  }
+  __host__ __device__ static constexpr float G(int i, int j) {
+    constexpr float t[4][3] = {{1, 0, 0}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0, 0, 1}};
+    return t[i][j];
+  }
+  __host__ __device__ static constexpr float AT(int i, int j) {
+    constexpr float t[2][4] = {{1, 1, 1, 0}, {0, 1, -1, -1}};
+    return t[i][j];
+  }
+};
+template <> struct WinoMat<4> {
+  static constexpr int A = 6;
+  __host__ __device__ static constexpr float BT(int i, int j) {
+    constexpr float t[6][6] = {{4, 0, -5, 0, 1, 0},  {0, -4, -4, 1, 1, 0}, {0, 4, -4, -1, 1, 0},
+                               {0, -2, -1, 2, 1, 0}, {0, 2, -1, -2, 1, 0}, {0, 4, 0, -5, 0, 1}};
+    return t[i][j];
+  }
+  __host__ __device__ static constexpr float G(int i, int j) {
+    constexpr float t[6][3] = {{1.f / 4, 0, 0},          {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
+                               {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6},  {0, 0, 1}};
+    return t[i][j];
+  }
+  __host__ __device__ static constexpr float AT(int i, int j) {
+    constexpr float t[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
+    return t[i][j];
+  }
+};
+
+// --------------------------------------------------------------------------------------------
+// filter transform: U[xi][row][kc] = (G g G^T)[xi]
+//   mode 0: row = k (output channel), kc = c, g = w[k][c]
+//   mode 1: row = c (input channel),  kc = k, g = w[k][c] with both taps flipped
+template <int MM>
+__global__ void wino_filter_kernel(const float* __restrict__ w, float* __restrict__ U, int K, int C, int rows, int Kc,
+                                   int mode) {
+  constexpr int A = WinoMat<MM>::A;
+  const long long total = (long long)rows * Kc;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int kc = (int)(i % Kc), row = (int)(i / Kc);
+    float g[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        float v = 0.f;
+        if (mode == 0) {
+          if (kc < C) v = w[(((long long)row * C + kc) * 3 + r) * 3 + s];
+        } else {
+          if (kc < K) v = w[(((long long)kc * C + row) * 3 + (2 - r)) * 3 + (2 - s)];
+        }
+        g[r][s] = v;
+      }
+    float t[A][3];
+#pragma unroll
+    for (int a = 0; a < A; ++a)
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+        t[a][s] = WinoMat<MM>::G(a, 0) * g[0][s] + WinoMat<MM>::G(a, 1) * g[1][s] + WinoMat<MM>::G(a, 2) * g[2][s];
+#pragma unroll
+    for (int a = 0; a < A; ++a)
+#pragma unroll
+      for (int b = 0; b < A; ++b) {
+        const float u = t[a][0] * WinoMat<MM>::G(b, 0) + t[a][1] * WinoMat<MM>::G(b, 1) + t[a][2] * WinoMat<MM>::G(b, 2);
+        U[((long long)(a * A + b) * rows + row) * Kc + kc] = u;
+      }
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+// input transform.  One block: image n, tile row ty, TWB consecutive tiles, one 32-channel chunk.
+// The raw (m+2)-row strip is staged in LDS with coalesced row reads (source gating applied here),
+// then every thread transforms (tile, channel) items with the channel fastest across lanes, so
+// that each V row [t][32 ch] is written as one 128-B segment.
+struct WinoInArgs {
+  const float* x;             // SRC 0/1: (N, C, H, W); SRC 2: pooled gradient (N, C, Hp, Wp)
+  const float* mask;          // SRC 1: ReLU output, same shape as x
+  const unsigned char* code;  // SRC 2: argmax code of the pooled tensor
+  float* V;                   // [xi][Q][T][32]
+  int N, C, H, W, Hp, Wp, TH, TW, Q;
+  long long T;
+};
+
+template <int MM, int SRC>
+__global__ __launch_bounds__(256) void wino_input_kernel(WinoInArgs a) {
+  constexpr int A = WinoMat<MM>::A;
+  constexpr int TWB = 64 / MM;            // 32 tiles (m = 2) / 16 tiles (m = 4): 64 output columns
+  constexpr int CW = TWB * MM + 2;        // 66 input columns
+  constexpr int PL = A * CW + 1;          // odd plane pitch: conflict-free across the 32 channel lanes
+  __shared__ float tile[32 * PL];
+  const int tid = threadIdx.x;
+  const int tx0 = blockIdx.x * TWB, ty = blockIdx.y;
+  const int n = blockIdx.z / a.Q, q = blockIdx.z % a.Q;
+  const int ih0 = ty * MM - 1, iw0 = tx0 * MM - 1;
+  const int plane = (SRC == 2) ? a.Hp * a.Wp : a.H * a.W;
+  const size_t img = ((size_t)n * a.C + (size_t)q * 32) * plane;
+  for (int idx = tid; idx < 32 * A * CW; idx += 256) {
+    const int c = idx / (A * CW), rem = idx % (A * CW);
+    const int r = rem / CW, col = rem % CW;
+    const int ih = ih0 + r, iw = iw0 + col;
+    float v = 0.f;
+    if (q * 32 + c < a.C && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) {
+      if (SRC == 2) {
+        const int hp = ih >> 1, wq = iw >> 1;
+        if (hp < a.Hp && wq < a.Wp) {
+          const size_t off = img + (size_t)c * plane + (size_t)hp * a.Wp + wq;
+          const unsigned want = (unsigned)((((ih & 1) << 1) | (iw & 1)) | 4);
+          if ((unsigned)a.code[off] == want) v = a.x[off];
+        }
+      } else {
+        const size_t off = img + (size_t)c * plane + (size_t)ih * a.W + iw;
+        v = a.x[off];
+        if (SRC == 1 && !(a.mask[off] > 0.f)) v = 0.f;
+      }
+    }
+    tile[c * PL + r * CW + col] = v;
+  }
+  __syncthreads();
+  const size_t xi_stride = (size_t)a.Q * a.T * 32;
+#pragma unroll 1
+  for (int it = tid; it < TWB * 32; it += 256) {
+    const int c = it & 31, tl = it >> 5;
+    const int tx = tx0 + tl;
+    if (tx >= a.TW) continue;
+    float d[A][A];
+#pragma unroll
+    for (int i = 0; i < A; ++i)
+#pragma unroll
+      for (int j = 0; j < A; ++j) d[i][j] = tile[c * PL + i * CW + tl * MM + j];
+    float t1[A][A];   // B^T d
+#pragma unroll
+    for (int i = 0; i < A; ++i)
+#pragma unroll
+      for (int j = 0; j < A; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < A; ++k)
+          if (WinoMat<MM>::BT(i, k) != 0.f) s += WinoMat<MM>::BT(i, k) * d[k][j];
+        t1[i][j] = s;
+      }
+    const size_t t = ((size_t)n * a.TH + ty) * a.TW + tx;
+    float* vout = a.V + ((size_t)q * a.T + t) * 32 + c;
+#pragma unroll
+    for (int i = 0; i < A; ++i)
+#pragma unroll
+      for (int j = 0; j < A; ++j) {   // (B^T d) B : column j of B = row j of B^T
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < A; ++k)
+          if (WinoMat<MM>::BT(j, k) != 0.f) s += t1[i][k] * WinoMat<MM>::BT(j, k);
+        vout[(size_t)(i * A + j) * xi_stride] = s;
+      }
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+// batched TN GEMM:  C[b][m][n] = sum_k A[b][m][k] * B[b][k / 32][n][k % 32]
+// 128 x 128 block tile, 4 waves of 64 x 64 (2 x 2 MFMA 32x32x2 tiles), 32-channel chunks.  Both
+// operand slabs arrive by global_load_lds (16 B / lane).  LDS image per operand and chunk:
+// [lane half h][row][4 units of 16 B], unit j of a row stored at j ^ ((row >> 1) & 3) -- the swizzle
+// is applied on the SOURCE address of the lane-linear DMA -- so the four ds_read_b128 with which a
+// lane fetches its 16 operands of the chunk are bank-conflict free without padding.  Two LDS stages
+// as distinct objects, chunk loop unrolled by two (see conv_igemm.hip for why).
+struct WinoGemmArgs {
+  const float* A;
+  const float* B;
+  float* C;
+  int M, N, Kc, m_tiles, n_tiles, xcd_remap;
+};
+
+__global__ __launch_bounds__(256, 2) void wino_gemm_kernel(WinoGemmArgs a) {
+  constexpr int BM = 128, BN = 128;
+  constexpr int PIECES = BM * 8 / 64;      // 16 wave-instructions of 1 KiB per operand and chunk
+  constexpr int PPW = PIECES / 4;          // 4 per wave
+  __shared__ __attribute__((aligned(16))) float sa0[BM * 32];
+  __shared__ __attribute__((aligned(16))) float sa1[BM * 32];
+  __shared__ __attribute__((aligned(16))) float sb0[BN * 32];
+  __shared__ __attribute__((aligned(16))) float sb1[BN * 32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+  unsigned v;
+  {
+    const unsigned total = gridDim.x, b = blockIdx.x;
+    if (a.xcd_remap) {
+      const unsigned q8 = total >> 3, r8 = total & 7u, xcd = b & 7u;
+      v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
+    } else {
+      v = b;
+    }
+  }
+  const int mt = (int)(v % (unsigned)a.m_tiles), nt = (int)(v / (unsigned)a.m_tiles);
+  const int batch = blockIdx.y;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int Q = a.Kc >> 5;
+  const float* Ab = a.A + (size_t)batch * a.M * a.Kc;
+  const float* Bb = a.B + (size_t)batch * Q * a.N * 32;
+
+  int a_goff[PPW], b_goff[PPW];
+#pragma unroll
+  for (int j = 0; j < PPW; ++j) {
+    const int u = (wave + 4 * j) * 64 + lane;
+    const int h = u / (BM * 4), row = (u >> 2) % BM, pj = u & 3;
+    const int jl = pj ^ ((row >> 1) & 3);
+    a_goff[j] = min(m0 + row, a.M - 1) * a.Kc + h * 16 + jl * 4;
+    b_goff[j] = min(n0 + row, a.N - 1) * 32 + h * 16 + jl * 4;
+  }
+  const size_t b_chunk = (size_t)a.N * 32;
+
+  int aoff[2], boff[2], uoff[4];
+  const int sw = (l31 >> 1) & 3;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    aoff[i] = (half * BM + wm * 64 + i * 32 + l31) * 16;
+    boff[i] = (half * BN + wn * 64 + i * 32 + l31) * 16;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) uoff[j] = (j ^ sw) * 4;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#define WG_DMA(QC, SA, SB)                                                                       \
+  {                                                                                              \
+    const float* as_ = Ab + (size_t)(QC) * 32;                                                   \
+    const float* bs_ = Bb + (size_t)(QC) * b_chunk;                                              \
+    _Pragma("unroll") for (int j = 0; j < PPW; ++j)                                              \
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(as_ + a_goff[j]),                           \
+                                       (lds_void_t*)((SA) + (wave + 4 * j) * 256), 16, 0, 0);    \
+    _Pragma("unroll") for (int j = 0; j < PPW; ++j)                                              \
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(bs_ + b_goff[j]),                           \
+                                       (lds_void_t*)((SB) + (wave + 4 * j) * 256), 16, 0, 0);    \
+  }
+#define WG_STEP(QC, SA, SB, SAN, SBN)                                                            \
+  {                                                                                              \
+    if ((QC) + 1 < Q) WG_DMA((QC) + 1, SAN, SBN)                                                 \
+    _Pragma("unroll") for (int j4 = 0; j4 < 4; ++j4) {                                           \
+      f32x4 av[2], bv[2];                                                                        \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                            \
+        av[i] = *(const f32x4*)((SA) + aoff[i] + uoff[j4]);                                      \
+        bv[i] = *(const f32x4*)((SB) + boff[i] + uoff[j4]);                                      \
+      }                                                                                          \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e)                                              \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                            \
+          _Pragma("unroll") for (int j = 0; j < 2; ++j)                                          \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], bv[j][e], acc[i][j], 0, 0, 0); \
+    }                                                                                            \
+    __syncthreads();                                                                             \
+  }
+
+  WG_DMA(0, sa0, sb0)
+  __syncthreads();
+  for (int qc = 0; qc < Q; qc += 2) {
+    WG_STEP(qc, sa0, sb0, sa1, sb1)
+    if (qc + 1 < Q) WG_STEP(qc + 1, sa1, sb1, sa0, sb0)
+  }
+#undef WG_STEP
+#undef WG_DMA
+
+  float* Cb = a.C + (size_t)batch * a.M * a.N;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (m >= a.M) continue;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + l31;
+        if (n < a.N) Cb[(size_t)m * a.N + n] = acc[i][j][r];
+      }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// output transform + epilogue.  Thread = (output channel k, tile t), t fastest.
+struct WinoOutArgs {
+  const float* Mb;      // [xi][K][T]
+  const float* bias;
+  float* y;             // (N, K, P, Q) or NULL when pooling
+  float* pool_y;        // (N, K, P/2, Q/2)
+  unsigned char* code;
+  int K, P, Q, TH, TW, relu;
+  long long T;
+};
+
+template <int MM>
+__global__ __launch_bounds__(256) void wino_output_kernel(WinoOutArgs a) {
+  constexpr int A = WinoMat<MM>::A;
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int k = blockIdx.y;
+  if (t >= a.T) return;
+  const size_t xs = (size_t)a.K * a.T;
+  const float* mp = a.Mb + (size_t)k * a.T + t;
+  float mv[A][A];
+#pragma unroll
+  for (int i = 0; i < A; ++i)
+#pragma unroll
+    for (int j = 0; j < A; ++j) mv[i][j] = mp[(size_t)(i * A + j) * xs];
+  float t1[MM][A];   // A^T M
+#pragma unroll
+  for (int i = 0; i < MM; ++i)
+#pragma unroll
+    for (int j = 0; j < A; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < A; ++q)
+        if (WinoMat<MM>::AT(i, q) != 0.f) s += WinoMat<MM>::AT(i, q) * mv[q][j];
+      t1[i][j] = s;
+    }
+  const float b = a.bias ? a.bias[k] : 0.f;
+  float o[MM][MM];
+#pragma unroll
+  for (int i = 0; i < MM; ++i)
+#pragma unroll
+    for (int j = 0; j < MM; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < A; ++q)
+        if (WinoMat<MM>::AT(j, q) != 0.f) s += t1[i][q] * WinoMat<MM>::AT(j, q);
+      s += b;
+      if (a.relu) s = s > 0.f ? s : 0.f;
+      o[i][j] = s;
+    }
+  const int tx = (int)(t % a.TW);
+  const long long r2 = t / a.TW;
+  const int ty = (int)(r2 % a.TH), n = (int)(r2 / a.TH);
+  const int p0 = ty * MM, q0 = tx * MM;
+  if (a.pool_y != nullptr) {
+    const int Pp = a.P >> 1, Qp = a.Q >> 1;
+#pragma unroll
+    for (int wi = 0; wi < MM / 2; ++wi)
+#pragma unroll
+      for (int wj = 0; wj < MM / 2; ++wj) {
+        const int pp = (p0 >> 1) + wi, qq = (q0 >> 1) + wj;
+        if (pp >= Pp || qq >= Qp) continue;
+        float m = o[2 * wi][2 * wj];
+        int arg = 0;
+        if (o[2 * wi][2 * wj + 1] > m) { m = o[2 * wi][2 * wj + 1]; arg = 1; }
+        if (o[2 * wi + 1][2 * wj] > m) { m = o[2 * wi + 1][2 * wj]; arg = 2; }
+        if (o[2 * wi + 1][2 * wj + 1] > m) { m = o[2 * wi + 1][2 * wj + 1]; arg = 3; }
+        const size_t oo = (((size_t)n * a.K + k) * Pp + pp) * Qp + qq;
+        a.pool_y[oo] = m;
+        a.code[oo] = (unsigned char)(arg | (m > 0.f ? 4 : 0));
+      }
+    return;
+  }
+  float* yo = a.y + (((size_t)n * a.K + k) * a.P + p0) * a.Q + q0;
+  const bool vec = (MM == 4) ? ((a.Q & 3) == 0) : ((a.Q & 1) == 0);
+#pragma unroll
+  for (int i = 0; i < MM; ++i) {
+    if (p0 + i >= a.P) continue;
+    if (vec && q0 + MM <= a.Q) {
+      if (MM == 4) {
+        f32x4 v4 = {o[i][0], o[i][1], o[i][2], o[i][3]};
+        *(f32x4*)(yo + (size_t)i * a.Q) = v4;
+      } else {
+        f32x2 v2 = {o[i][0], o[i][1]};
+        *(f32x2*)(yo + (size_t)i * a.Q) = v2;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < MM; ++j)
+        if (q0 + j < a.Q) yo[(size_t)i * a.Q + j] = o[i][j];
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+// host side
+static int g_wino_mode = -1;   // -1: not initialised (FCD_WINO env, default 4)
+static int wino_env() {
+  if (g_wino_mode < 0) {
+    const char* e = getenv("FCD_WINO");
+    int v = e ? atoi(e) : 4;
+    if (v != 0 && v != 2 && v != 4) v = 4;
+    g_wino_mode = v;
+  }
+  return g_wino_mode;
+}
+
+// 0 = direct kernels only, 2 / 4 = Winograd tile size for the planned layers; returns the previous value.
+// (Filters packed for another tile size stay valid: packs are keyed by m.)
+extern "C" int fcd_conv_wino_set(int m) {
+  const int prev = wino_env();
+  if (m == 0 || m == 2 || m == 4) g_wino_mode = m;
+  return prev;
+}
+
+// mode 0 forward / 1 data gradient.  Returns the output tile size m (2 or 4), or 0 when the layer
+// runs on the direct kernels.  The transform passes stream 22 (m = 4) / 36 (m = 2) bytes per input and
+// per output element, which the 4x / 2.25x smaller GEMM only pays back for wide layers.
+extern "C" int fcd_conv_wino_plan(const fcd_conv_desc* d, int mode) {
+  if (!d || wino_env() == 0) return 0;
+  if (!(d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1)) return 0;
+  const int red = mode == 0 ? d->C : d->K;       // reduction channels of the GEMM
+  const int rows = mode == 0 ? d->K : d->C;      // GEMM rows
+  if (red % 32 != 0 || red < 256 || rows < 128) return 0;
+  if (d->P < 4 || d->Q < 4) return 0;
+  return wino_env();
+}
+
+struct WinoPlan {
+  int m, A2, rows, red, Kc, Q, TH, TW;
+  long long T;
+  size_t v_bytes, m_bytes;
+};
+
+static bool wino_plan(const fcd_conv_desc* d, int mode, WinoPlan* pl) {
+  pl->m = fcd_conv_wino_plan(d, mode);
+  if (!pl->m) return false;
+  const int a = pl->m + 2;
+  pl->A2 = a * a;
+  pl->rows = mode == 0 ? d->K : d->C;
+  pl->red = mode == 0 ? d->C : d->K;
+  pl->Kc = round_up(pl->red, 32);
+  pl->Q = pl->Kc / 32;
+  // forward: tiles over the output (P, Q) = (H, W); data gradient: tiles over dx (H, W) = (P, Q)
+  pl->TH = cdiv(d->H, pl->m);
+  pl->TW = cdiv(d->W, pl->m);
+  pl->T = (long long)d->N * pl->TH * pl->TW;
+  pl->v_bytes = (size_t)pl->A2 * pl->Q * pl->T * 32 * sizeof(float);
+  pl->m_bytes = (size_t)pl->A2 * pl->rows * pl->T * sizeof(float);
+  return true;
+}
+
+extern "C" size_t fcd_conv_wino_ws_bytes(const fcd_conv_desc* d, int mode) {
+  WinoPlan pl;
+  if (!d || !wino_plan(d, mode, &pl)) return 0;
+  return pl.v_bytes + pl.m_bytes + 256;
+}
+
+extern "C" int64_t fcd_conv_wino_filter_elems(int K, int C, int mode, int m) {
+  if (m != 2 && m != 4) return 0;
+  const int rows = mode == 0 ? K : C, red = mode == 0 ? C : K;
+  return (int64_t)(m + 2) * (m + 2) * rows * round_up(red, 32);
+}
+
+extern "C" int fcd_conv_wino_pack(const float* w, float* U, int K, int C, int mode, int m, void* stream) {
+  FCD_CHECK_ARG(w && U && K > 0 && C > 0 && (mode == 0 || mode == 1) && (m == 2 || m == 4),
+                "fcd_conv_wino_pack: bad arguments");
+  const int rows = mode == 0 ? K : C, Kc = round_up(mode == 0 ? C : K, 32);
+  const long long total = (long long)rows * Kc;
+  const int grid = (int)std::min<long long>(cdiv64(total, 256), 4096);
+  FcdProfScope prof(FCD_K_PACK, (hipStream_t)stream, 0.0, 4.0 * total * (9 + (m + 2) * (m + 2)));
+  if (m == 2)
+    hipLaunchKernelGGL(wino_filter_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, U, K, C, rows, Kc, mode);
+  else
+    hipLaunchKernelGGL(wino_filter_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, U, K, C, rows, Kc, mode);
+  FCD_LAUNCH_CHECK("wino_pack");
+  return FCD_OK;
+}
+
+static int wino_xcd() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("FCD_CONV_XCD");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v;
+}
+
+template <int MM>
+static void wino_launch_input(const WinoInArgs& ia, int src, hipStream_t st) {
+  constexpr int TWB = 64 / MM;
+  dim3 grid((unsigned)cdiv(ia.TW, TWB), (unsigned)ia.TH, (unsigned)(ia.N * ia.Q));
+  if (src == 0) hipLaunchKernelGGL((wino_input_kernel<MM, 0>), grid, dim3(256), 0, st, ia);
+  else if (src == 1) hipLaunchKernelGGL((wino_input_kernel<MM, 1>), grid, dim3(256), 0, st, ia);
+  else hipLaunchKernelGGL((wino_input_kernel<MM, 2>), grid, dim3(256), 0, st, ia);
+}
+
+// shared by forward and data gradient: src tensor (in_ch channels, H x W logical extent) -> out tensor
+// (rows channels, H x W)
+static int wino_run(const WinoPlan& pl, int N, int in_ch, int H, int W, const float* src, const float* mask,
+                    const unsigned char* code_in, int Hp, int Wp, const float* U, const float* bias, int relu, float* y,
+                    float* pool_y, unsigned char* code_out, void* ws, hipStream_t st) {
+  float* V = (float*)ws;
+  float* Mb = (float*)((char*)ws + ((pl.v_bytes + 255) & ~(size_t)255));
+  WinoInArgs ia;
+  memset(&ia, 0, sizeof(ia));
+  ia.x = src; ia.mask = mask; ia.code = code_in; ia.V = V;
+  ia.N = N; ia.C = in_ch; ia.H = H; ia.W = W; ia.Hp = Hp; ia.Wp = Wp;
+  ia.TH = pl.TH; ia.TW = pl.TW; ia.Q = pl.Q; ia.T = pl.T;
+  const int srcmode = code_in ? 2 : (mask ? 1 : 0);
+  if (pl.m == 2) wino_launch_input<2>(ia, srcmode, st); else wino_launch_input<4>(ia, srcmode, st);
+
+  WinoGemmArgs ga;
+  memset(&ga, 0, sizeof(ga));
+  ga.A = U; ga.B = V; ga.C = Mb;
+  ga.M = pl.rows; ga.N = (int)pl.T; ga.Kc = pl.Kc;
+  ga.m_tiles = cdiv(pl.rows, 128); ga.n_tiles = cdiv((int)pl.T, 128);
+  ga.xcd_remap = wino_xcd();
+  hipLaunchKernelGGL(wino_gemm_kernel, dim3((unsigned)(ga.m_tiles * ga.n_tiles), (unsigned)pl.A2), dim3(256), 0, st, ga);
+
+  WinoOutArgs oa;
+  memset(&oa, 0, sizeof(oa));
+  oa.Mb = Mb; oa.bias = bias; oa.y = y; oa.pool_y = pool_y; oa.code = code_out;
+  oa.K = pl.rows; oa.P = H; oa.Q = W; oa.TH = pl.TH; oa.TW = pl.TW; oa.relu = relu; oa.T = pl.T;
+  dim3 og((unsigned)cdiv64(pl.T, 256), (unsigned)pl.rows);
+  if (pl.m == 2) hipLaunchKernelGGL(wino_output_kernel<2>, og, dim3(256), 0, st, oa);
+  else hipLaunchKernelGGL(wino_output_kernel<4>, og, dim3(256), 0, st, oa);
+  return 0;
+}
+
+static double conv_flops(const fcd_conv_desc* d) { return 2.0 * d->N * d->K * (double)d->P * d->Q * d->C * 9; }
+// bytes the three passes stream: x in, V out + in, M out + in, y out, transformed filters in
+static double wino_bytes(const WinoPlan& pl) {
+  const double v = (double)pl.v_bytes, m = (double)pl.m_bytes;
+  const int a2 = pl.A2, mm = pl.m * pl.m;
+  return v / a2 * mm + 2.0 * v + 2.0 * m + m / a2 * mm + 4.0 * a2 * pl.rows * pl.Kc;
+}
+
+// y = [relu](conv(x, w) + bias)  or, when pool_y != NULL, pool_y / code = maxpool2(relu(conv + bias))
+extern "C" int fcd_conv2d_fwd_wino(const fcd_conv_desc* d, const float* x, const float* U, const float* bias, float* y,
+                                   int fuse_relu, float* pool_y, unsigned char* code, void* ws, size_t ws_bytes,
+                                   void* stream) {
+  FCD_CHECK_ARG(d && x && U && (y || (pool_y && code)), "fcd_conv2d_fwd_wino: null pointer");
+  WinoPlan pl;
+  FCD_CHECK_ARG(wino_plan(d, 0, &pl), "fcd_conv2d_fwd_wino: layer is not planned for the Winograd path");
+  if (!ws || ws_bytes < fcd_conv_wino_ws_bytes(d, 0)) {
+    fcd_set_error("fcd_conv2d_fwd_wino: workspace %zu < %zu bytes", ws_bytes, fcd_conv_wino_ws_bytes(d, 0));
+    return FCD_ERR_WORKSPACE;
+  }
+  FcdProfScope prof(FCD_K_WINO_FWD, (hipStream_t)stream, conv_flops(d), wino_bytes(pl));
+  wino_run(pl, d->N, d->C, d->H, d->W, x, nullptr, nullptr, 0, 0, U, bias, (fuse_relu || pool_y) ? 1 : 0,
+           pool_y ? nullptr : y, pool_y, code, ws, (hipStream_t)stream);
+  FCD_LAUNCH_CHECK("conv2d_fwd_wino");
+  return FCD_OK;
+}
+
+// dx = conv_transpose(dy') with dy' = dy, dy * [relu_out > 0], or the pooled gradient routed by pool_code
+extern "C" int fcd_conv2d_bwd_data_wino(const fcd_conv_desc* d, const float* dy, const float* relu_out,
+                                        const unsigned char* pool_code, const float* U, float* dx, void* ws,
+                                        size_t ws_bytes, void* stream) {
+  FCD_CHECK_ARG(d && dy && U && dx, "fcd_conv2d_bwd_data_wino: null pointer");
+  WinoPlan pl;
+  FCD_CHECK_ARG(wino_plan(d, 1, &pl), "fcd_conv2d_bwd_data_wino: layer is not planned for the Winograd path");
+  if (!ws || ws_bytes < fcd_conv_wino_ws_bytes(d, 1)) {
+    fcd_set_error("fcd_conv2d_bwd_data_wino: workspace %zu < %zu bytes", ws_bytes, fcd_conv_wino_ws_bytes(d, 1));
+    return FCD_ERR_WORKSPACE;
+  }
+  FcdProfScope prof(FCD_K_WINO_DGRAD, (hipStream_t)stream, conv_flops(d), wino_bytes(pl));
+  wino_run(pl, d->N, d->K, d->P, d->Q, dy, pool_code ? nullptr : relu_out, pool_code, d->P / 2, d->Q / 2, U, nullptr, 0,
+           dx, nullptr, nullptr, ws, (hipStream_t)stream);
+  FCD_LAUNCH_CHECK("conv2d_bwd_data_wino");
+  return FCD_OK;
+}

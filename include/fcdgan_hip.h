@@ -71,6 +71,26 @@ int fcd_conv2d_fwd(const fcd_conv_desc* d, const float* x, const float* wp, cons
 int fcd_conv2d_fwd_ex(const fcd_conv_desc* d, const float* x, const float* wp, const float* bias,
                       float* y, int act, const float* slope_ptr, float slope_imm,
                       const float* residual, void* stream);
+/* ---- Winograd F(m x m, 3 x 3) path for wide 3x3 / stride-1 / pad-1 layers (m = 2 or 4) ------------
+ * fcd_conv_wino_plan(): tile size the library uses for this layer and direction (mode 0 forward,
+ * 1 data gradient), 0 = the layer runs on the direct kernels (then none of the *_wino calls apply).
+ * Filters are transformed once per weight version with fcd_conv_wino_pack (opaque layout,
+ * fcd_conv_wino_filter_elems floats); every call needs fcd_conv_wino_ws_bytes of caller workspace.
+ * Replaces the same nn.Conv2d call sites as fcd_conv2d_fwd / _bwd_data (Module.py:25-31, Loss.py:25). */
+int fcd_conv_wino_plan(const fcd_conv_desc* d, int mode);
+/* tile-size policy: 0 = direct kernels only, 2 or 4 (default, env FCD_WINO); returns the previous value */
+int fcd_conv_wino_set(int m);
+size_t fcd_conv_wino_ws_bytes(const fcd_conv_desc* d, int mode);
+int64_t fcd_conv_wino_filter_elems(int K, int C, int mode, int m);
+int fcd_conv_wino_pack(const float* w, float* U, int K, int C, int mode, int m, void* stream);
+/* y = [relu](conv + bias); with pool_y != NULL instead pool_y / code = maxpool2(relu(conv + bias)) */
+int fcd_conv2d_fwd_wino(const fcd_conv_desc* d, const float* x, const float* U, const float* bias, float* y,
+                        int fuse_relu, float* pool_y, unsigned char* code, void* ws, size_t ws_bytes,
+                        void* stream);
+/* dx from dy, dy * [relu_out > 0] (relu_out != NULL) or the pooled gradient routed by pool_code */
+int fcd_conv2d_bwd_data_wino(const fcd_conv_desc* d, const float* dy, const float* relu_out,
+                             const unsigned char* pool_code, const float* U, float* dx, void* ws,
+                             size_t ws_bytes, void* stream);
 /* dx = conv_transpose(dy', w): desc describes the FORWARD conv; wp_bwd: mode-1
  * packed weights.  dx has shape (N,C,H,W).  relu_out (optional, shape of dy): the
  * fused-ReLU forward output; dy' = dy * [relu_out > 0] is formed while staging. */
@@ -211,7 +231,8 @@ int fcd_rmsprop_step(float* p, const float* g, float* sq, int64_t n, float lr, f
 /* ---- profiling -------------------------------------------------------------
  * When enabled every launch is bracketed by HIP events on its stream; read()
  * synchronises and returns per-family totals: out[f*4+0]=ms, +1=launches,
- * +2=algorithmic FLOPs, +3=algorithmic bytes (f < fcd_prof_families()). */
+ * +2=algorithmic FLOPs (direct-convolution count, also for the Winograd families), +3=bytes
+ * (f < fcd_prof_families()). */
 void fcd_prof_enable(int on);
 int fcd_prof_families(void);
 int fcd_prof_read(double* out, int reset);

@@ -28,7 +28,8 @@ FULL_CONVS = [
     (8, 64, 256, 64, 3, 1, 1),       # G residual convs / U-Net first stage
     (16, 13, 256, 64, 3, 1, 1),      # Siamese inc on 13 bands
     (8, 256, 128, 128, 3, 1, 1),     # decoder up3
-    (8, 2048, 32, 1024, 3, 1, 1),    # decoder up1 (widest K)
+    (8, 2048, 32, 1024, 3, 1, 1),    # decoder up1 (widest K; Winograd path)
+    (26, 512, 32, 512, 3, 1, 1),     # VGG conv4_2 on 26 band images (Winograd path)
     (32, 64, 128, 128, 3, 2, 1),     # discriminator, stride 2
     (8, 13, 256, 64, 9, 1, 4),       # generator head 9x9
     (8, 128, 256, 1, 1, 1, 0),       # OutConv
@@ -49,14 +50,17 @@ def test_conv_adjoint_linearity_determinism(case):
     y.backward(g)
     a, b, c = ddot(y.detach(), g), ddot(x.detach(), x.grad), ddot(w.detach(), w.grad)
     scale = max(abs(a), (y.detach().double().norm() * g.double().norm()).item() * 1e-3)
-    assert abs(a - b) <= 2e-5 * scale, ('fwd vs dgrad', a, b)
-    assert abs(a - c) <= 2e-5 * scale, ('fwd vs wgrad', a, c)
+    # layers planned for the Winograd F(4x4, 3x3) path carry ~1e-5 of transform rounding per element
+    wino = pkg()._lib.lib.fcd_conv_wino_plan(__import__('ctypes').byref(ops._desc(x.shape, w.shape, st, pad)), 0)
+    tol = 1e-4 if wino else 2e-5
+    assert abs(a - b) <= tol * scale, ('fwd vs dgrad', a, b)
+    assert abs(a - c) <= tol * scale, ('fwd vs wgrad', a, c)
     # linearity
     x2 = torch.randn(x.shape, device=DEV, generator=g0)
     with torch.no_grad():
         lhs = ops.conv2d(2.0 * x + x2, w, None, st, pad)
         rhs = 2.0 * y.detach() + ops.conv2d(x2, w, None, st, pad)
-    assert (lhs - rhs).abs().max().item() <= 2e-5 * rhs.abs().max().item()
+    assert (lhs - rhs).abs().max().item() <= (2e-4 if wino else 2e-5) * rhs.abs().max().item()
     # determinism (bitwise)
     dx1, dw1 = x.grad.clone(), w.grad.clone()
     x.grad = None

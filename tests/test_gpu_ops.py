@@ -321,3 +321,86 @@ def test_ssim_level_and_msssim(shape):
         assert abs(v.item() - v_ref.item()) < 1e-5
         assert_close(xg.grad, xr.grad, tol=1e-4, what='ms dX')
         assert_close(yg.grad, yr.grad, tol=1e-4, what='ms dY')
+
+
+WINO_CASES = [
+    # N, C, H, W, K   (3x3 / stride 1 / pad 1, >= 256 reduction channels in at least one direction)
+    (2, 256, 16, 16, 256),
+    (1, 512, 9, 14, 128),      # P, Q not multiples of the tile
+    (3, 256, 33, 21, 384),     # odd sizes, ragged GEMM row / column tiles
+    (2, 320, 8, 12, 160),      # data gradient on the direct kernel (160 reduction channels), forward Winograd
+    (1, 256, 5, 70, 256),      # more than one 64-column strip per tile row
+]
+
+
+@pytest.mark.parametrize('m', [2, 4])
+@pytest.mark.parametrize('case', WINO_CASES, ids=lambda c: 'x'.join(map(str, c)))
+def test_conv_winograd_path(case, m):
+    """Winograd F(m x m, 3 x 3) forward / data gradient (plain, ReLU-gated, pooled-gradient sources;
+    bias / ReLU / max-pool epilogues) vs torch fp64.  fp32 transform rounding: ~3e-7 (m = 2), ~1e-5 (m = 4)."""
+    import ctypes
+    ops = _ops()
+    lib = ops.lib
+    N, C, H, W, K = case
+    tol = 3e-6 if m == 2 else 6e-5
+    flip_tol = 4e-3 if m == 2 else 1e-2     # ReLU / argmax decisions within the forward rounding may fall the other way
+    prev = lib.fcd_conv_wino_set(m)
+    try:
+        d = ops._desc((N, C, H, W), (K, C, 3, 3), 1, 1)
+        assert lib.fcd_conv_wino_plan(ctypes.byref(d), 0) == m
+        x = rnd(N, C, H, W, seed=11)
+        w = rnd(K, C, 3, 3, seed=12, scale=(2.0 / (C * 9)) ** 0.5)
+        b = rnd(K, seed=13, scale=0.1)
+        g = rnd(N, K, H, W, seed=14)
+        xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+        yr = F.conv2d(xr, wr, br, padding=1)
+        yr.backward(g.double())
+        xg, wg, bg = (t.cuda().requires_grad_(True) for t in (x, w, b))
+        y = ops.conv2d(xg, wg, bg, 1, 1)
+        y.backward(g.cuda())
+        assert_close(y, yr.float(), tol=tol, what='y')
+        assert_close(xg.grad, xr.grad.float(), tol=tol, what='dx')
+        assert_close(wg.grad, wr.grad.float(), tol=5e-5, what='dw')
+        # bit-reproducible
+        y2 = ops.conv2d(xg, wg, bg, 1, 1)
+        assert torch.equal(y2, y)
+        # fused ReLU (+ mask-gated data gradient) and fused ReLU + max-pool (+ code-routed data gradient)
+        xr2 = x.double().requires_grad_(True)
+        ypr = F.max_pool2d(F.relu(F.conv2d(xr2, w.double(), b.double(), padding=1)), 2)
+        gp = rnd(*ypr.shape, seed=15)
+        ypr.backward(gp.double())
+        xg2 = x.cuda().requires_grad_(True)
+        yp = ops.conv2d_relu_maxpool2(xg2, w.cuda(), b.cuda())
+        yp.backward(gp.cuda())
+        assert_close(yp, ypr.float(), tol=tol, what='pooled y')
+        dd = xg2.grad.cpu().double() - xr2.grad
+        assert (dd.norm() / xr2.grad.norm()).item() < flip_tol, 'pooled dx'
+        xr3 = x.double().requires_grad_(True)
+        F.relu(F.conv2d(xr3, w.double(), b.double(), padding=1)).backward(g.double())
+        xg3 = x.cuda().requires_grad_(True)
+        ops.conv2d(xg3, w.cuda(), b.cuda(), 1, 1, relu=True).backward(g.cuda())
+        dd = xg3.grad.cpu().double() - xr3.grad
+        assert (dd.norm() / xr3.grad.norm()).item() < flip_tol, 'relu dx'
+    finally:
+        lib.fcd_conv_wino_set(prev)
+
+
+def test_conv_winograd_matches_direct_kernels():
+    """Same layer through the direct MFMA kernel and both Winograd tile sizes."""
+    ops = _ops()
+    lib = ops.lib
+    x = rnd(2, 512, 24, 40, seed=21).cuda()
+    w = rnd(256, 512, 3, 3, seed=22, scale=(2.0 / (512 * 9)) ** 0.5).cuda()
+    b = rnd(256, seed=23, scale=0.1).cuda()
+    outs = {}
+    prev = lib.fcd_conv_wino_set(0)
+    try:
+        for m in (0, 2, 4):
+            lib.fcd_conv_wino_set(m)
+            with torch.no_grad():
+                outs[m] = ops.conv2d(x, w, b, 1, 1)
+    finally:
+        lib.fcd_conv_wino_set(prev)
+    sc = outs[0].abs().max().item()
+    assert (outs[2] - outs[0]).abs().max().item() <= 5e-6 * sc
+    assert (outs[4] - outs[0]).abs().max().item() <= 6e-5 * sc

@@ -75,6 +75,25 @@ def main():
         t_d = timeit(lambda: check(lib.fcd_conv2d_bwd_data(ctypes.byref(d), ops._p(dy), None, ops._p(wpb), ops._p(dx), s)))
         res = '%8.1f %8.1f' % (flops / t_f / 1e9, flops / t_d / 1e9)
         ms = '%6.2f %6.2f' % (t_f, t_d)
+        mw = lib.fcd_conv_wino_plan(ctypes.byref(d), 0) if st == 1 else 0
+        md = lib.fcd_conv_wino_plan(ctypes.byref(d), 1) if st == 1 else 0
+        wino = ''
+        if mw:
+            U = ops.wino_weight(w, 0, mw)
+            wsb = torch.empty(lib.fcd_conv_wino_ws_bytes(ctypes.byref(d), 0), dtype=torch.uint8, device='cuda')
+            t_fw = timeit(lambda: check(lib.fcd_conv2d_fwd_wino(ctypes.byref(d), ops._p(x), ops._p(U), ops._p(b), ops._p(y), 0,
+                                                                None, None, ops._p(wsb), wsb.numel(), s)))
+            wino += '  wino%d fwd %6.2f ms (%5.1f TF-eq)' % (mw, t_fw, flops / t_fw / 1e9)
+            tot['fwd_best'] = tot.get('fwd_best', 0.0) + min(t_fw, t_f) - t_f
+            del wsb
+        if md:
+            U1 = ops.wino_weight(w, 1, md)
+            wsb = torch.empty(lib.fcd_conv_wino_ws_bytes(ctypes.byref(d), 1), dtype=torch.uint8, device='cuda')
+            t_dw = timeit(lambda: check(lib.fcd_conv2d_bwd_data_wino(ctypes.byref(d), ops._p(dy), None, None, ops._p(U1),
+                                                                     ops._p(dx), ops._p(wsb), wsb.numel(), s)))
+            wino += '  dgrad %6.2f ms (%5.1f TF-eq)' % (t_dw, flops / t_dw / 1e9)
+            tot['dgrad_best'] = tot.get('dgrad_best', 0.0) + min(t_dw, t_d) - t_d
+            del wsb
         tot['fwd'] += t_f; tot['dgrad'] += t_d
         if wg:
             nb = lib.fcd_conv2d_bwd_weight_ws_bytes(ctypes.byref(d))
@@ -86,7 +105,7 @@ def main():
             tot['wgrad'] += t_w
         else:
             res += ' %8s' % '-'
-        print('%-26s %5d %10.1f | %s   (%s)' % (tag, N, flops / 1e9, res, ms))
+        print('%-26s %5d %10.1f | %s   (%s)%s' % (tag, N, flops / 1e9, res, ms, wino))
         del x, y, dy, dx
     print('sum ms:', {k: round(v, 2) for k, v in tot.items()})
 
