@@ -1,5 +1,6 @@
-// Winograd F(m x m, 3 x 3) path for the wide 3x3 / stride-1 / pad-1 layers (>= 256 reduction
-// channels: VGG conv3_2 .. conv5_3, the bottom of the U-Net) -- Module.py:25-31, Loss.py:25.
+// Winograd F(m x m, 3 x 3) path for the 3x3 / stride-1 / pad-1 layers whose GEMM has >= 128 rows and
+// >= 64 reduction channels (VGG conv2_1 .. conv5_3, all but the first U-Net stage) -- Module.py:25-31,
+// Loss.py:25.
 //
 //   y = A^T [ sum_c (G g G^T) (.) (B^T d B) ] A            (Lavin & Gray 2016, m = 2 or 4)
 //
@@ -114,23 +115,26 @@ struct WinoInArgs {
   long long T;
 };
 
-template <int MM, int SRC>
+// TRB x TWB tiles per block (16 tiles for m = 4, 32 for m = 2): 1 x 16 strips for wide maps, 2 x 8 / 4 x 4
+// patches for the 32- and 16-pixel maps deep in the nets, so that no thread idles on tiles outside
+// the image.  VEC: W % 4 == 0 -- the interior of every strip row is fetched as float4 (the strip
+// starts one pixel left of a 16-B boundary), the two halo columns as scalars.
+template <int MM, int SRC, int TRB, int TWB, bool VEC>
 __global__ __launch_bounds__(256) void wino_input_kernel(WinoInArgs a) {
   constexpr int A = WinoMat<MM>::A;
-  constexpr int TWB = 64 / MM;            // 32 tiles (m = 2) / 16 tiles (m = 4): 64 output columns
-  constexpr int CW = TWB * MM + 2;        // 66 input columns
-  constexpr int PL = A * CW + 1;          // odd plane pitch: conflict-free across the 32 channel lanes
+  constexpr int RH = TRB * MM + 2;        // input rows of the block's patch
+  constexpr int CW = TWB * MM + 2;        // input columns
+  constexpr int PL = (RH * CW) | 1;       // odd plane pitch: conflict-free across the 32 channel lanes
   __shared__ float tile[32 * PL];
   const int tid = threadIdx.x;
-  const int tx0 = blockIdx.x * TWB, ty = blockIdx.y;
+  const int tx0 = blockIdx.x * TWB, ty0 = blockIdx.y * TRB;
   const int n = blockIdx.z / a.Q, q = blockIdx.z % a.Q;
-  const int ih0 = ty * MM - 1, iw0 = tx0 * MM - 1;
+  const int ih0 = ty0 * MM - 1, iw0 = tx0 * MM - 1;
   const int plane = (SRC == 2) ? a.Hp * a.Wp : a.H * a.W;
   const size_t img = ((size_t)n * a.C + (size_t)q * 32) * plane;
-  for (int idx = tid; idx < 32 * A * CW; idx += 256) {
-    const int c = idx / (A * CW), rem = idx % (A * CW);
-    const int r = rem / CW, col = rem % CW;
-    const int ih = ih0 + r, iw = iw0 + col;
+
+  // one element of the source at (channel c of the chunk, ih, iw), gated by the source mode
+  auto fetch = [&](int c, int ih, int iw) -> float {
     float v = 0.f;
     if (q * 32 + c < a.C && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) {
       if (SRC == 2) {
@@ -146,20 +150,55 @@ __global__ __launch_bounds__(256) void wino_input_kernel(WinoInArgs a) {
         if (SRC == 1 && !(a.mask[off] > 0.f)) v = 0.f;
       }
     }
-    tile[c * PL + r * CW + col] = v;
+    return v;
+  };
+
+  if (VEC && SRC != 2) {
+    constexpr int V4 = (CW - 2) / 4;                    // float4 per strip row
+    for (int idx = tid; idx < 32 * RH * V4; idx += 256) {
+      const int c = idx / (RH * V4), rem = idx % (RH * V4);
+      const int r = rem / V4, v4 = rem % V4;
+      const int ih = ih0 + r, iw = iw0 + 1 + v4 * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (q * 32 + c < a.C && ih >= 0 && ih < a.H && iw < a.W) {     // W % 4 == 0: whole float4 in range
+        const size_t off = img + (size_t)c * plane + (size_t)ih * a.W + iw;
+        v = *(const f32x4*)(a.x + off);
+        if (SRC == 1) {
+          const f32x4 k = *(const f32x4*)(a.mask + off);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (!(k[e] > 0.f)) v[e] = 0.f;
+        }
+      }
+      float* t = tile + c * PL + r * CW + 1 + v4 * 4;
+      t[0] = v[0]; t[1] = v[1]; t[2] = v[2]; t[3] = v[3];
+    }
+    for (int idx = tid; idx < 32 * RH * 2; idx += 256) {
+      const int c = idx / (RH * 2), rem = idx % (RH * 2);
+      const int r = rem >> 1, side = rem & 1;
+      const int col = side ? CW - 1 : 0;
+      tile[c * PL + r * CW + col] = fetch(c, ih0 + r, iw0 + col);
+    }
+  } else {
+    for (int idx = tid; idx < 32 * RH * CW; idx += 256) {
+      const int c = idx / (RH * CW), rem = idx % (RH * CW);
+      const int r = rem / CW, col = rem % CW;
+      tile[c * PL + r * CW + col] = fetch(c, ih0 + r, iw0 + col);
+    }
   }
   __syncthreads();
   const size_t xi_stride = (size_t)a.Q * a.T * 32;
 #pragma unroll 1
-  for (int it = tid; it < TWB * 32; it += 256) {
+  for (int it = tid; it < TRB * TWB * 32; it += 256) {
     const int c = it & 31, tl = it >> 5;
-    const int tx = tx0 + tl;
-    if (tx >= a.TW) continue;
+    const int tr = tl / TWB, tc = tl % TWB;
+    const int tx = tx0 + tc, ty = ty0 + tr;
+    if (tx >= a.TW || ty >= a.TH) continue;
     float d[A][A];
 #pragma unroll
     for (int i = 0; i < A; ++i)
 #pragma unroll
-      for (int j = 0; j < A; ++j) d[i][j] = tile[c * PL + i * CW + tl * MM + j];
+      for (int j = 0; j < A; ++j) d[i][j] = tile[c * PL + (tr * MM + i) * CW + tc * MM + j];
     float t1[A][A];   // B^T d
 #pragma unroll
     for (int i = 0; i < A; ++i)
@@ -365,6 +404,11 @@ __global__ __launch_bounds__(256) void wino_output_kernel(WinoOutArgs a) {
   const int ty = (int)(r2 % a.TH), n = (int)(r2 / a.TH);
   const int p0 = ty * MM, q0 = tx * MM;
   if (a.pool_y != nullptr) {
+    // The four outputs of a pooling window come out of the same transform-domain values through
+    // different coefficient patterns: mathematically equal outputs (constant image regions, zero
+    // padding) differ by transform rounding (<= ~2e-5 relative for m = 4).  Candidates that close to
+    // the maximum count as tied and the FIRST one takes the gradient, as MaxPool2d does on exact ties
+    // (Loss.py:25 -> torchvision vgg16.features[4,9,16,23]); the pooled VALUE is always the maximum.
     const int Pp = a.P >> 1, Qp = a.Q >> 1;
 #pragma unroll
     for (int wi = 0; wi < MM / 2; ++wi)
@@ -372,11 +416,15 @@ __global__ __launch_bounds__(256) void wino_output_kernel(WinoOutArgs a) {
       for (int wj = 0; wj < MM / 2; ++wj) {
         const int pp = (p0 >> 1) + wi, qq = (q0 >> 1) + wj;
         if (pp >= Pp || qq >= Qp) continue;
-        float m = o[2 * wi][2 * wj];
-        int arg = 0;
-        if (o[2 * wi][2 * wj + 1] > m) { m = o[2 * wi][2 * wj + 1]; arg = 1; }
-        if (o[2 * wi + 1][2 * wj] > m) { m = o[2 * wi + 1][2 * wj]; arg = 2; }
-        if (o[2 * wi + 1][2 * wj + 1] > m) { m = o[2 * wi + 1][2 * wj + 1]; arg = 3; }
+        const float c0 = o[2 * wi][2 * wj], c1 = o[2 * wi][2 * wj + 1], c2 = o[2 * wi + 1][2 * wj],
+                    c3 = o[2 * wi + 1][2 * wj + 1];
+        const float m = fmaxf(fmaxf(c0, c1), fmaxf(c2, c3));
+        const float tie = (MM == 4 ? 3e-5f : 2e-6f) * fmaxf(fmaxf(fabsf(c0), fabsf(c1)), fmaxf(fabsf(c2), fabsf(c3)));
+        const float mx = m - tie;
+        int arg = 3;
+        if (c2 >= mx) arg = 2;
+        if (c1 >= mx) arg = 1;
+        if (c0 >= mx) arg = 0;
         const size_t oo = (((size_t)n * a.K + k) * Pp + pp) * Qp + qq;
         a.pool_y[oo] = m;
         a.code[oo] = (unsigned char)(arg | (m > 0.f ? 4 : 0));
@@ -427,13 +475,21 @@ extern "C" int fcd_conv_wino_set(int m) {
 
 // mode 0 forward / 1 data gradient.  Returns the output tile size m (2 or 4), or 0 when the layer
 // runs on the direct kernels.  The transform passes stream 22 (m = 4) / 36 (m = 2) bytes per input and
-// per output element, which the 4x / 2.25x smaller GEMM only pays back for wide layers.
+// per output element, which the 4x / 2.25x smaller GEMM only pays back when the GEMM has >= 128 rows
+// (measured on MI355X: 64 -> 128 channels forward wins, its data gradient with 64 rows does not).
 extern "C" int fcd_conv_wino_plan(const fcd_conv_desc* d, int mode) {
   if (!d || wino_env() == 0) return 0;
   if (!(d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1)) return 0;
   const int red = mode == 0 ? d->C : d->K;       // reduction channels of the GEMM
   const int rows = mode == 0 ? d->K : d->C;      // GEMM rows
-  if (red % 32 != 0 || red < 256 || rows < 128) return 0;
+  static int min_red = -1, min_rows = -1;
+  if (min_red < 0) {
+    const char* e = getenv("FCD_WINO_MINC");
+    min_red = e ? atoi(e) : 64;
+    const char* r = getenv("FCD_WINO_MINROWS");
+    min_rows = r ? atoi(r) : 128;
+  }
+  if (red % 32 != 0 || red < min_red || rows < min_rows) return 0;
   if (d->P < 4 || d->Q < 4) return 0;
   return wino_env();
 }
@@ -498,13 +554,24 @@ static int wino_xcd() {
   return v;
 }
 
+template <int MM, int TRB, int TWB>
+static void wino_launch_input_cfg(const WinoInArgs& ia, int src, hipStream_t st) {
+  dim3 grid((unsigned)cdiv(ia.TW, TWB), (unsigned)cdiv(ia.TH, TRB), (unsigned)(ia.N * ia.Q));
+  const bool vec = (ia.W & 3) == 0 && src != 2;
+#define WINO_IN(SRC_, VEC_) \
+  hipLaunchKernelGGL((wino_input_kernel<MM, SRC_, TRB, TWB, VEC_>), grid, dim3(256), 0, st, ia)
+  if (src == 0) { if (vec) WINO_IN(0, true); else WINO_IN(0, false); }
+  else if (src == 1) { if (vec) WINO_IN(1, true); else WINO_IN(1, false); }
+  else WINO_IN(2, false);
+#undef WINO_IN
+}
+
 template <int MM>
 static void wino_launch_input(const WinoInArgs& ia, int src, hipStream_t st) {
-  constexpr int TWB = 64 / MM;
-  dim3 grid((unsigned)cdiv(ia.TW, TWB), (unsigned)ia.TH, (unsigned)(ia.N * ia.Q));
-  if (src == 0) hipLaunchKernelGGL((wino_input_kernel<MM, 0>), grid, dim3(256), 0, st, ia);
-  else if (src == 1) hipLaunchKernelGGL((wino_input_kernel<MM, 1>), grid, dim3(256), 0, st, ia);
-  else hipLaunchKernelGGL((wino_input_kernel<MM, 2>), grid, dim3(256), 0, st, ia);
+  constexpr int NT = 64 / MM;             // tiles per block: 64 output pixels per patch row at 1 x NT
+  if (ia.TW > NT / 2) wino_launch_input_cfg<MM, 1, NT>(ia, src, st);
+  else if (ia.TW > NT / 4) wino_launch_input_cfg<MM, 2, NT / 2>(ia, src, st);
+  else wino_launch_input_cfg<MM, 4, NT / 4>(ia, src, st);
 }
 
 // shared by forward and data gradient: src tensor (in_ch channels, H x W logical extent) -> out tensor

@@ -21,3 +21,16 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if 'gpu' in it.keywords:
             it.add_marker(skip)
+
+
+@pytest.fixture(params=['direct', 'winograd'])
+def conv_path(request):
+    """Run a gradient-level test once on the direct MFMA kernels only and once with the library's default
+    layer plan (Winograd F(4x4, 3x3) for the 3x3 layers with >= 128 GEMM rows).  The Winograd transforms
+    carry ~1e-5 of fp32 rounding (direct: ~1e-6): forward values stay inside the same bounds, but more
+    ReLU / max-pool decisions within rounding distance of the kink fall the other way, so aggregate
+    gradient bounds are doubled on that path."""
+    from fcd_gan_pytorch_amd import _lib
+    prev = _lib.lib.fcd_conv_wino_set(0 if request.param == 'direct' else 4)
+    yield request.param
+    _lib.lib.fcd_conv_wino_set(prev)

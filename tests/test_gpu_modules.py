@@ -218,7 +218,7 @@ def make_crit(cls, channel, layer, pb):
 
 
 @pytest.mark.parametrize('tag', list(CRIT))
-def test_criteria_vs_reference_fixture(tag):
+def test_criteria_vs_reference_fixture(tag, conv_path):
     z = np.load(os.path.join(G, 'losses.npz'))
     seed, cseed, N, C, H, W, allc = [int(v) for v in z[tag + '/meta']]
     cls, channel, layer, pb = CRIT[tag]
@@ -243,8 +243,9 @@ def test_criteria_vs_reference_fixture(tag):
     # gradient of a whole receptive field, so a few % of the elements may differ visibly while the
     # relative L2 error stays small.  (tools/dbg_replay.py replays each conv op in isolation to
     # tell such flips from kernel errors: every op agrees to rounding.)
-    grad_close(gg.grad, gr.grad, 'd/dgenerated', bad_frac=3e-2)
-    grad_close(cg.grad, cr.grad, 'd/dcmap', bad_frac=3e-2)
+    l2 = 5e-3 if conv_path == 'direct' else 1e-2
+    grad_close(gg.grad, gr.grad, 'd/dgenerated', l2_tol=l2, bad_frac=3e-2)
+    grad_close(cg.grad, cr.grad, 'd/dcmap', l2_tol=l2, bad_frac=3e-2)
 
 
 def test_region_loss_vs_reference_fixture():
@@ -293,7 +294,7 @@ def _update_err(net, before, z, tag, rtol_l2):
 
 
 @pytest.mark.parametrize('literal', [False, True])
-def test_rsss_adversarial_step_vs_reference_fixture(literal):
+def test_rsss_adversarial_step_vs_reference_fixture(literal, conv_path):
     z = np.load(os.path.join(G, 'steps.npz'))
     wseed, tseed, N, C, H, W = [int(v) for v in z['rsss/meta']]
     netG, netS, netD, crit, opts = _load_nets(C, wseed, 'CGeneratorLoss', True, 'rsss')
@@ -306,7 +307,10 @@ def test_rsss_adversarial_step_vs_reference_fixture(literal):
                                      'generator_loss', 'ssim_loss', 'perception_loss')]
         np.testing.assert_allclose(got, z['rsss/it%d/scalars' % it], rtol=2e-3, atol=1e-5)
         ref_cmap = torch.from_numpy(z['rsss/it%d/cmap' % it])
-        tol = 1e-4 if it == 0 else 1e-2     # it 1 sees weights moved by sign-like RMSprop steps
+        # it 1 sees weights moved by sign-like RMSprop steps (first step = +-10 lr whatever |g|): every
+        # gradient element at noise level lands on either side, so the bound measures that amplification,
+        # not the kernels; the Winograd transforms carry ~10x the rounding of the direct kernels
+        tol = 1e-4 if it == 0 else (1e-2 if conv_path == 'direct' else 2e-2)
         assert (r['cmap'].detach().cpu()[:, :, ::4, ::4] - ref_cmap).abs().max().item() <= tol
     _update_err(netS, None, z, 'rsss/S', 2e-3)
     _update_err(netD, None, z, 'rsss/D', 2e-3)
@@ -314,7 +318,7 @@ def test_rsss_adversarial_step_vs_reference_fixture(literal):
 
 
 @pytest.mark.parametrize('literal', [False, True])
-def test_usss_joint_step_vs_reference_fixture(literal):
+def test_usss_joint_step_vs_reference_fixture(literal, conv_path):
     z = np.load(os.path.join(G, 'steps.npz'))
     wseed, tseed, N, C, H, W = [int(v) for v in z['usss/meta']]
     netG, netS, netD, crit, opts = _load_nets(C, wseed, 'CNetLoss', True, 'usss')

@@ -343,7 +343,7 @@ def test_conv_winograd_path(case, m):
     lib = ops.lib
     N, C, H, W, K = case
     tol = 3e-6 if m == 2 else 6e-5
-    flip_tol = 4e-3 if m == 2 else 1e-2     # ReLU / argmax decisions within the forward rounding may fall the other way
+    flip_tol = 4e-3 if m == 2 else 2e-2     # ReLU / argmax decisions within the forward rounding may fall the other way
     prev = lib.fcd_conv_wino_set(m)
     try:
         d = ops._desc((N, C, H, W), (K, C, 3, 3), 1, 1)

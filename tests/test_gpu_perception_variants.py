@@ -20,7 +20,7 @@ def _cmap(seed, N, H, W):
 
 
 @pytest.mark.parametrize('layers,per_band,switch,size', [(5, False, False, 176), (3, True, True, 176), (1, True, False, 200)])
-def test_cnet_loss_variants(layers, per_band, switch, size):
+def test_cnet_loss_variants(layers, per_band, switch, size, conv_path):
     import fcd_gan_pytorch_amd as p
     N, C = 1, 3
     vgg = seeded_state(onets.vgg_spec(), 4242)
@@ -40,4 +40,4 @@ def test_cnet_loss_variants(layers, per_band, switch, size):
     np.testing.assert_allclose([float(v) for v in vals], [float(v) for v in ref], rtol=3e-4, atol=1e-6)
     for got, want, what in ((gg.grad, gr.grad, 'dgen'), (cg.grad, cr.grad, 'dcmap')):
         d = got.cpu().double() - want.double()
-        assert (d.norm() / want.double().norm().clamp_min(1e-30)).item() < 5e-3, what
+        assert (d.norm() / want.double().norm().clamp_min(1e-30)).item() < (5e-3 if conv_path == 'direct' else 1e-2), what

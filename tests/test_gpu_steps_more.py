@@ -48,7 +48,7 @@ def flat_rel(net, sd):
     return (num / den) ** 0.5
 
 
-def test_usss_pretrain_steps_vs_oracle():
+def test_usss_pretrain_steps_vs_oracle(conv_path):
     p = pkg()
     C, N, H = 4, 1, 176
     G, S, crit, (sdG, sdS, sdV) = make(C, 'CNetLoss', True, 500)
@@ -66,7 +66,8 @@ def test_usss_pretrain_steps_vs_oracle():
     np.testing.assert_allclose([float(r['net_loss']), float(r['l1_loss']), float(r['perception_loss'])],
                                [float(ro['net_loss']), float(ro['l1']), float(ro['perc'])], rtol=3e-3)
     assert (r['cmap'].detach().cpu() - ro['cmap'].detach()).abs().max().item() < 1e-3   # after one Adam step of G
-    assert flat_rel(G, n.G) < 2e-3 and flat_rel(S, n.S) < 2e-3
+    wtol = 2e-3 if conv_path == 'direct' else 4e-3
+    assert flat_rel(G, n.G) < wtol and flat_rel(S, n.S) < wtol
 
 
 def test_rsss_g_pretrain_step_vs_oracle():
