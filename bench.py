@@ -231,51 +231,72 @@ def main():
         }
         if prof:
             fwd, dg, wg = prof['conv_igemm_fwd'], prof['conv_igemm_dgrad'], prof['conv_wgrad']
-            ms = fwd['ms'] + dg['ms']
-            flops = fwd['flops'] + dg['flops']
-            launches = fwd['launches'] + dg['launches']
-            ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-            res['roofline'] = {
-                'bound': 'mfma', 'kernel': 'conv_igemm_kernel (fp32 MFMA implicit GEMM; forward + data-gradient launches)',
-                'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS,
-                'traffic': None, 'launches_per_step': launches / args.steps,
-                'avg_launch_ms': ms / max(launches, 1), 'algorithmic_gflop_per_launch': flops / max(launches, 1) / 1e9,
-                'share_of_step_time': ms / (1e3 * dt) if dt > 0 else None,
-            }
-            # HBM bytes per launch of the same kernel family from the PMC counters (FETCH_SIZE /
-            # WRITE_SIZE, separate rocprofv3 passes over this very command: tools/pmc_bench.sh);
-            # bench.py cannot run the profiler on itself, so it reports the committed measurement.
+            zero = dict(ms=0.0, launches=0, flops=0.0, bytes=0.0)
+            wf, wd = prof.get('conv_wino_fwd', zero), prof.get('conv_wino_dgrad', zero)
+            wgemm, wxf = prof.get('wino_gemm', zero), prof.get('wino_transform', zero)
+
+            def mfma_entry(name, ms, flops, launches, what):
+                ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+                return {'bound': 'mfma', 'kernel': name, 'flops_counted': what, 'achieved': ach,
+                        'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS,
+                        'traffic': None, 'launches_per_step': launches / args.steps,
+                        'avg_launch_ms': ms / max(launches, 1), 'gflop_per_launch': flops / max(launches, 1) / 1e9,
+                        'share_of_step_time': ms / (1e3 * dt) if dt > 0 else None}
+            # the MFMA-bound kernels of the step, each priced on the FLOPs its launches really issue:
+            #  * conv_igemm*: direct implicit-GEMM convolution -> algorithmic FLOPs 2 N K P Q C R S
+            #  * wino_gemm: the batched GEMM of the Winograd path -> 2 (m+2)^2 rows Kc T (= the algorithmic conv
+            #    FLOPs of those layers / 4 for F(4x4,3x3), plus tile padding)
+            #  * conv_wgrad: weight gradient (re-layout + reduce passes included in its time)
+            cands = [
+                mfma_entry('conv_igemm_kernel / conv_igemm_glds_kernel (direct fp32 MFMA implicit-GEMM convolution; forward + '
+                           'data-gradient launches)', fwd['ms'] + dg['ms'], fwd['flops'] + dg['flops'],
+                           fwd['launches'] + dg['launches'], 'algorithmic convolution FLOPs'),
+                mfma_entry('wino_gemm_kernel (batched fp32 MFMA GEMM of the Winograd F(4x4,3x3) path; forward + data-gradient '
+                           'launches)', wgemm['ms'], wgemm['flops'], wgemm['launches'], 'executed GEMM FLOPs'),
+                mfma_entry('conv_wgrad_roll_kernel / conv_wgrad_kernel (+ re-layout and split-K reduce)', wg['ms'], wg['flops'],
+                           wg['launches'], 'algorithmic weight-gradient FLOPs'),
+            ]
+            cands.sort(key=lambda e: -(e['share_of_step_time'] or 0.0))
+            res['roofline'] = cands[0]
+            res['roofline']['other_mfma_kernels'] = cands[1:]
+            # HBM bytes per launch of the direct-conv family from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate
+            # rocprofv3 passes over this very command: tools/pmc_bench.sh); bench.py cannot run the profiler on itself,
+            # so it reports the committed measurement of the family it belongs to.
             tpath = os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')
             if os.path.exists(tpath) and args.workload == 'rsss' and args.batch == 8 and args.bands == 13 and args.size == 256:
                 with open(tpath) as f:
                     tj = json.load(f)
-                res['roofline']['traffic'] = tj['hbm_bytes_per_launch']
-                res['roofline']['traffic_unit'] = 'HBM bytes per launch (PMC, profiles/r01_hbm_traffic.json)'
-                res['roofline']['algorithmic_bytes_per_launch'] = (fwd['bytes'] + dg['bytes']) / max(launches, 1)
-            wf, wd = prof.get('conv_wino_fwd'), prof.get('conv_wino_dgrad')
-            if wf and wd and (wf['launches'] + wd['launches']) > 0:
+                for e in cands:
+                    key = 'wino_gemm' if e['kernel'].startswith('wino_gemm') else ('conv_igemm' if e['kernel'].startswith('conv_igemm') else None)
+                    if key and key in tj:
+                        e['traffic'] = tj[key]['hbm_bytes_per_launch']
+                        e['traffic_unit'] = 'HBM bytes per launch (PMC, profiles/r01_hbm_traffic.json)'
+                        e['algorithmic_bytes_per_launch'] = tj[key].get('algorithmic_bytes_per_launch')
+            if wf['launches'] + wd['launches'] > 0:
                 wms, wfl = wf['ms'] + wd['ms'], wf['flops'] + wd['flops']
                 from fcd_gan_pytorch_amd import _lib as _l
                 mt = _l.lib.fcd_conv_wino_set(-1)
-                red = {2: 2.25, 4: 4.0}.get(mt, 1.0)
                 res['winograd'] = {
-                    'what': 'wide 3x3 / stride-1 layers (>= 256 reduction channels) run as Winograd F(%dx%d, 3x3): input '
-                            'transform + batched fp32 MFMA GEMM + output transform; same results within fp32 rounding '
-                            '(<= 2e-5 relative), %.2fx fewer multiplies than the direct convolution' % (mt, mt, red),
-                    'launches_per_step': (wf['launches'] + wd['launches']) / args.steps, 'ms_per_step': wms / args.steps,
-                    'algorithmic_tflops': wfl / (wms * 1e-3) / 1e12,
-                    'executed_mfma_tflops_approx': wfl / red / (wms * 1e-3) / 1e12,
-                    'hbm_gbps_streamed': (wf['bytes'] + wd['bytes']) / (wms * 1e-3) / 1e9,
+                    'what': '3x3 / stride-1 layers with >= 128 GEMM rows and >= 64 reduction channels run as Winograd '
+                            'F(%dx%d, 3x3): input transform + batched fp32 MFMA GEMM + output transform (three kernels per '
+                            'layer call); results equal the direct kernels within fp32 transform rounding (<= 2e-5 relative, '
+                            'tests/test_gpu_ops.py)' % (mt, mt),
+                    'layer_calls_per_step': (wf['launches'] + wd['launches']) / args.steps, 'ms_per_step': wms / args.steps,
+                    'algorithmic_conv_tflops': wfl / (wms * 1e-3) / 1e12,
+                    'gemm_ms_per_step': wgemm['ms'] / args.steps, 'transform_ms_per_step': wxf['ms'] / args.steps,
+                    'transform_gbps': wxf['bytes'] / (wxf['ms'] * 1e-3) / 1e9 if wxf['ms'] > 0 else None,
                     'share_of_step_time': wms / (1e3 * dt),
                 }
-                res['roofline']['note'] = ('direct MFMA implicit-GEMM launches only; the Winograd launches are reported '
-                                           'under "winograd" (their algorithmic rate exceeds the MFMA peak by construction)')
-                res['conv_all_algorithmic_tflops'] = (flops + wfl) / ((ms + wms) * 1e-3) / 1e12
+                dms, dfl = fwd['ms'] + dg['ms'], fwd['flops'] + dg['flops']
+                res['conv_fwd_dgrad_algorithmic_tflops'] = (dfl + wfl) / ((dms + wms) * 1e-3) / 1e12
             res['kernel_families'] = {
                 k: {'ms_per_step': v['ms'] / args.steps, 'launches_per_step': v['launches'] / args.steps,
                     'tflops': (v['flops'] / (v['ms'] * 1e-3) / 1e12) if v['ms'] > 0 and v['flops'] > 0 else None,
                     'gbps': (v['bytes'] / (v['ms'] * 1e-3) / 1e9) if v['ms'] > 0 and v['bytes'] > 0 else None}
                 for k, v in prof.items() if v['launches'] > 0}
+            for k in ('wino_gemm', 'wino_transform'):
+                if k in res['kernel_families']:
+                    res['kernel_families'][k]['nested_in'] = 'conv_wino_fwd + conv_wino_dgrad'
         if n_gpus == 1 and not args.no_cpu_baseline and args.workload == 'rsss':
             res['cpu_baseline'] = cpu_baseline(args)
         print(json.dumps(res))

@@ -44,7 +44,9 @@ enum {
   FCD_K_MISC = 8,
   FCD_K_WINO_FWD = 9,   // Winograd path (input transform + batched MFMA GEMM + output transform), forward
   FCD_K_WINO_DGRAD = 10,// ... used as data gradient
-  FCD_K_COUNT = 11
+  FCD_K_WINO_GEMM = 11, // nested in 9/10: the batched MFMA GEMM alone (FLOPs = executed GEMM FLOPs)
+  FCD_K_WINO_XFORM = 12,// nested in 9/10: input + output transform kernels (bytes streamed)
+  FCD_K_COUNT = 13
 };
 
 struct FcdProfScope {

@@ -31,7 +31,7 @@ std::vector<hipEvent_t> g_free_events;
 double g_ms[FCD_K_COUNT], g_launches[FCD_K_COUNT], g_flops[FCD_K_COUNT], g_bytes[FCD_K_COUNT];
 const char* kNames[FCD_K_COUNT] = {"conv_igemm_fwd", "conv_igemm_dgrad", "conv_wgrad", "pack_weights",
                                    "norm_act",       "pool_resize",      "loss",       "optim",
-                                   "misc", "conv_wino_fwd", "conv_wino_dgrad"};
+                                   "misc", "conv_wino_fwd", "conv_wino_dgrad", "wino_gemm", "wino_transform"};
 
 hipEvent_t get_event() {
   if (!g_free_events.empty()) {

@@ -587,7 +587,11 @@ static int wino_run(const WinoPlan& pl, int N, int in_ch, int H, int W, const fl
   ia.N = N; ia.C = in_ch; ia.H = H; ia.W = W; ia.Hp = Hp; ia.Wp = Wp;
   ia.TH = pl.TH; ia.TW = pl.TW; ia.Q = pl.Q; ia.T = pl.T;
   const int srcmode = code_in ? 2 : (mask ? 1 : 0);
-  if (pl.m == 2) wino_launch_input<2>(ia, srcmode, st); else wino_launch_input<4>(ia, srcmode, st);
+  const double in_elems = (double)N * in_ch * H * W, mm = pl.m * pl.m;
+  {
+    FcdProfScope p1(FCD_K_WINO_XFORM, st, 0.0, 4.0 * in_elems * (srcmode == 1 ? 2.0 : 1.0) + (double)pl.v_bytes);
+    if (pl.m == 2) wino_launch_input<2>(ia, srcmode, st); else wino_launch_input<4>(ia, srcmode, st);
+  }
 
   WinoGemmArgs ga;
   memset(&ga, 0, sizeof(ga));
@@ -595,15 +599,24 @@ static int wino_run(const WinoPlan& pl, int N, int in_ch, int H, int W, const fl
   ga.M = pl.rows; ga.N = (int)pl.T; ga.Kc = pl.Kc;
   ga.m_tiles = cdiv(pl.rows, 128); ga.n_tiles = cdiv((int)pl.T, 128);
   ga.xcd_remap = wino_xcd();
-  hipLaunchKernelGGL(wino_gemm_kernel, dim3((unsigned)(ga.m_tiles * ga.n_tiles), (unsigned)pl.A2), dim3(256), 0, st, ga);
+  {
+    FcdProfScope p2(FCD_K_WINO_GEMM, st, 2.0 * pl.A2 * pl.rows * (double)pl.Kc * (double)pl.T,
+                    (double)pl.v_bytes + (double)pl.m_bytes + 4.0 * pl.A2 * pl.rows * pl.Kc);
+    hipLaunchKernelGGL(wino_gemm_kernel, dim3((unsigned)(ga.m_tiles * ga.n_tiles), (unsigned)pl.A2), dim3(256), 0, st,
+                       ga);
+  }
 
   WinoOutArgs oa;
   memset(&oa, 0, sizeof(oa));
   oa.Mb = Mb; oa.bias = bias; oa.y = y; oa.pool_y = pool_y; oa.code = code_out;
   oa.K = pl.rows; oa.P = H; oa.Q = W; oa.TH = pl.TH; oa.TW = pl.TW; oa.relu = relu; oa.T = pl.T;
   dim3 og((unsigned)cdiv64(pl.T, 256), (unsigned)pl.rows);
-  if (pl.m == 2) hipLaunchKernelGGL(wino_output_kernel<2>, og, dim3(256), 0, st, oa);
-  else hipLaunchKernelGGL(wino_output_kernel<4>, og, dim3(256), 0, st, oa);
+  {
+    FcdProfScope p3(FCD_K_WINO_XFORM, st, 0.0,
+                    (double)pl.m_bytes + (double)pl.m_bytes / pl.A2 * mm * (pool_y ? 0.3125 : 1.0));
+    if (pl.m == 2) hipLaunchKernelGGL(wino_output_kernel<2>, og, dim3(256), 0, st, oa);
+    else hipLaunchKernelGGL(wino_output_kernel<4>, og, dim3(256), 0, st, oa);
+  }
   return 0;
 }
 
