@@ -251,10 +251,11 @@ def main():
                 mfma_entry('conv_igemm_kernel / conv_igemm_glds_kernel (direct fp32 MFMA implicit-GEMM convolution; forward + '
                            'data-gradient launches)', fwd['ms'] + dg['ms'], fwd['flops'] + dg['flops'],
                            fwd['launches'] + dg['launches'], 'algorithmic convolution FLOPs'),
-                mfma_entry('wino_gemm_kernel (batched fp32 MFMA GEMM of the Winograd F(4x4,3x3) path; forward + data-gradient '
-                           'launches)', wgemm['ms'], wgemm['flops'], wgemm['launches'], 'executed GEMM FLOPs'),
-                mfma_entry('conv_wgrad_roll_kernel / conv_wgrad_kernel (+ re-layout and split-K reduce)', wg['ms'], wg['flops'],
-                           wg['launches'], 'algorithmic weight-gradient FLOPs'),
+                mfma_entry('wino_gemm_kernel (batched fp32 MFMA GEMM of the Winograd F(4x4,3x3) path; forward, data-gradient '
+                           'and weight-gradient launches)', wgemm['ms'], wgemm['flops'], wgemm['launches'], 'executed GEMM FLOPs'),
+                mfma_entry('weight gradient: conv_wgrad_roll_kernel / conv_wgrad_kernel (+ re-layout, split-K reduce) and, for the wide '
+                           '3x3 layers, the Winograd F(4x4,3x3) form (its GEMM launches are also part of wino_gemm_kernel above)',
+                           wg['ms'], wg['flops'], wg['launches'], 'algorithmic weight-gradient FLOPs (direct count)'),
             ]
             cands.sort(key=lambda e: -(e['share_of_step_time'] or 0.0))
             res['roofline'] = cands[0]

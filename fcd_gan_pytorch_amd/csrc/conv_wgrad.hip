@@ -525,10 +525,16 @@ static bool wgrad_plan(const fcd_conv_desc* d, WgradPlan* pl) {
   return true;
 }
 
+// conv_wino.hip: Winograd F(4x4, 3x3) weight gradient for the wide 3x3 / stride-1 layers
+size_t fcd_wino_wgrad_ws_bytes(const fcd_conv_desc* d);
+int fcd_wino_wgrad_run(const fcd_conv_desc* d, const float* x, const float* dy, const float* relu_out, float* dw,
+                       float* db, void* ws, hipStream_t st);
+
 extern "C" size_t fcd_conv2d_bwd_weight_ws_bytes(const fcd_conv_desc* d) {
   WgradPlan pl;
   if (!d || !wgrad_plan(d, &pl)) return 0;
-  return pl.zero_bytes + pl.xt_bytes + pl.dyt_bytes + pl.part_bytes + pl.psum_bytes;
+  return std::max(pl.zero_bytes + pl.xt_bytes + pl.dyt_bytes + pl.part_bytes + pl.psum_bytes,
+                  fcd_wino_wgrad_ws_bytes(d));
 }
 
 static int wgrad_roll() {
@@ -578,6 +584,10 @@ extern "C" int fcd_conv2d_bwd_weight_bias(const fcd_conv_desc* d, const float* x
   const double bytes = 4.0 * ((double)d->N * d->C * d->H * d->W + (double)d->N * d->K * d->P * d->Q +
                               (double)d->K * d->C * d->R * d->S);
   FcdProfScope prof(FCD_K_CONV_WGRAD, st, flops, bytes);
+  if (fcd_wino_wgrad_ws_bytes(d) > 0 && fcd_wino_wgrad_run(d, x, dy, relu_out, dw, db, ws, st) == 0) {
+    FCD_LAUNCH_CHECK("conv2d_bwd_weight(winograd)");
+    return FCD_OK;
+  }
   if (hipMemsetAsync(zeros, 0, pl.zero_bytes, st) != hipSuccess) {
     fcd_set_error("fcd_conv2d_bwd_weight: memset failed");
     return FCD_ERR_LAUNCH;

@@ -234,20 +234,25 @@ __global__ __launch_bounds__(256) void wino_input_kernel(WinoInArgs a) {
 // lane fetches its 16 operands of the chunk are bank-conflict free without padding.  Two LDS stages
 // as distinct objects, chunk loop unrolled by two (see conv_igemm.hip for why).
 struct WinoGemmArgs {
-  const float* A;
-  const float* B;
-  float* C;
+  const float* A;   // row m of batch b at A + b * a_batch + m * a_ld, stage q at + q * 32 floats
+  const float* B;   // row n of batch b at B + b * b_batch + n * b_ld, stage q at + q * b_adv floats
+  float* C;         // [split][batch][M][N]
   int M, N, Kc, m_tiles, n_tiles, xcd_remap;
+  long long a_ld, a_batch, b_ld, b_adv, b_batch;
+  int stages_per_split;   // blockIdx.z = split of the reduction: stages [z * sps, min((z + 1) * sps, Kc / 32))
 };
 
+template <int KC>      // reduction elements per pipeline stage
 __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(WinoGemmArgs a) {
   constexpr int BM = 128, BN = 128;
-  constexpr int PIECES = BM * 8 / 64;      // 16 wave-instructions of 1 KiB per operand and chunk
-  constexpr int PPW = PIECES / 4;          // 4 per wave
-  __shared__ __attribute__((aligned(16))) float sa0[BM * 32];
-  __shared__ __attribute__((aligned(16))) float sa1[BM * 32];
-  __shared__ __attribute__((aligned(16))) float sb0[BN * 32];
-  __shared__ __attribute__((aligned(16))) float sb1[BN * 32];
+  constexpr int UH = KC / 8;               // 16-B units per lane half and row
+  constexpr int PIECES = BM * UH * 2 / 64; // wave-instructions of 1 KiB per operand and stage
+  constexpr int PPW = PIECES / 4;
+  constexpr int SWS = UH == 4 ? 1 : 2;     // swizzle = (row >> SWS) & (UH - 1)
+  __shared__ __attribute__((aligned(16))) float sa0[BM * KC];
+  __shared__ __attribute__((aligned(16))) float sa1[BM * KC];
+  __shared__ __attribute__((aligned(16))) float sb0[BN * KC];
+  __shared__ __attribute__((aligned(16))) float sb1[BN * KC];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int wm = wave >> 1, wn = wave & 1;
@@ -264,30 +269,32 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(WinoGemmArgs a) {
   const int mt = (int)(v % (unsigned)a.m_tiles), nt = (int)(v / (unsigned)a.m_tiles);
   const int batch = blockIdx.y;
   const int m0 = mt * BM, n0 = nt * BN;
-  const int Q = a.Kc >> 5;
-  const float* Ab = a.A + (size_t)batch * a.M * a.Kc;
-  const float* Bb = a.B + (size_t)batch * Q * a.N * 32;
+  static_assert(KC == 32, "stage = one 32-float chunk");
+  const int q_all = a.Kc / KC;
+  const int q_beg = (int)blockIdx.z * a.stages_per_split;
+  const int Q = min(a.stages_per_split, q_all - q_beg);      // pipeline stages of this block
+  const float* Ab = a.A + (size_t)batch * a.a_batch + (size_t)q_beg * KC;
+  const float* Bb = a.B + (size_t)batch * a.b_batch + (size_t)q_beg * a.b_adv;
 
   int a_goff[PPW], b_goff[PPW];
 #pragma unroll
   for (int j = 0; j < PPW; ++j) {
     const int u = (wave + 4 * j) * 64 + lane;
-    const int h = u / (BM * 4), row = (u >> 2) % BM, pj = u & 3;
-    const int jl = pj ^ ((row >> 1) & 3);
-    a_goff[j] = min(m0 + row, a.M - 1) * a.Kc + h * 16 + jl * 4;
-    b_goff[j] = min(n0 + row, a.N - 1) * 32 + h * 16 + jl * 4;
+    const int h = u / (BM * UH), row = (u / UH) % BM, pj = u % UH;
+    const int jl = pj ^ ((row >> SWS) & (UH - 1));
+    a_goff[j] = (int)(min(m0 + row, a.M - 1) * a.a_ld) + h * (KC / 2) + jl * 4;
+    b_goff[j] = (int)(min(n0 + row, a.N - 1) * a.b_ld) + h * (KC / 2) + jl * 4;
   }
-  const size_t b_chunk = (size_t)a.N * 32;
 
-  int aoff[2], boff[2], uoff[4];
-  const int sw = (l31 >> 1) & 3;
+  int aoff[2], boff[2], uoff[UH];
+  const int sw = (l31 >> SWS) & (UH - 1);
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    aoff[i] = (half * BM + wm * 64 + i * 32 + l31) * 16;
-    boff[i] = (half * BN + wn * 64 + i * 32 + l31) * 16;
+    aoff[i] = (half * BM + wm * 64 + i * 32 + l31) * (UH * 4);
+    boff[i] = (half * BN + wn * 64 + i * 32 + l31) * (UH * 4);
   }
 #pragma unroll
-  for (int j = 0; j < 4; ++j) uoff[j] = (j ^ sw) * 4;
+  for (int j = 0; j < UH; ++j) uoff[j] = (j ^ sw) * 4;
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -299,8 +306,8 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(WinoGemmArgs a) {
 
 #define WG_DMA(QC, SA, SB)                                                                       \
   {                                                                                              \
-    const float* as_ = Ab + (size_t)(QC) * 32;                                                   \
-    const float* bs_ = Bb + (size_t)(QC) * b_chunk;                                              \
+    const float* as_ = Ab + (size_t)(QC) * KC;                                                   \
+    const float* bs_ = Bb + (size_t)(QC) * a.b_adv;                                              \
     _Pragma("unroll") for (int j = 0; j < PPW; ++j)                                              \
       __builtin_amdgcn_global_load_lds((gbl_void_t*)(as_ + a_goff[j]),                           \
                                        (lds_void_t*)((SA) + (wave + 4 * j) * 256), 16, 0, 0);    \
@@ -311,7 +318,7 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(WinoGemmArgs a) {
 #define WG_STEP(QC, SA, SB, SAN, SBN)                                                            \
   {                                                                                              \
     if ((QC) + 1 < Q) WG_DMA((QC) + 1, SAN, SBN)                                                 \
-    _Pragma("unroll") for (int j4 = 0; j4 < 4; ++j4) {                                           \
+    _Pragma("unroll") for (int j4 = 0; j4 < UH; ++j4) {                                          \
       f32x4 av[2], bv[2];                                                                        \
       _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                            \
         av[i] = *(const f32x4*)((SA) + aoff[i] + uoff[j4]);                                      \
@@ -334,7 +341,7 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(WinoGemmArgs a) {
 #undef WG_STEP
 #undef WG_DMA
 
-  float* Cb = a.C + (size_t)batch * a.M * a.N;
+  float* Cb = a.C + ((size_t)blockIdx.z * gridDim.y + batch) * a.M * a.N;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -599,11 +606,14 @@ static int wino_run(const WinoPlan& pl, int N, int in_ch, int H, int W, const fl
   ga.M = pl.rows; ga.N = (int)pl.T; ga.Kc = pl.Kc;
   ga.m_tiles = cdiv(pl.rows, 128); ga.n_tiles = cdiv((int)pl.T, 128);
   ga.xcd_remap = wino_xcd();
+  ga.a_ld = pl.Kc; ga.a_batch = (long long)pl.rows * pl.Kc;                 // U [xi][rows][Kc]
+  ga.b_ld = 32; ga.b_adv = (long long)pl.T * 32; ga.b_batch = (long long)pl.Q * pl.T * 32;   // V [xi][Q][T][32]
+  ga.stages_per_split = pl.Q;
   {
     FcdProfScope p2(FCD_K_WINO_GEMM, st, 2.0 * pl.A2 * pl.rows * (double)pl.Kc * (double)pl.T,
                     (double)pl.v_bytes + (double)pl.m_bytes + 4.0 * pl.A2 * pl.rows * pl.Kc);
-    hipLaunchKernelGGL(wino_gemm_kernel, dim3((unsigned)(ga.m_tiles * ga.n_tiles), (unsigned)pl.A2), dim3(256), 0, st,
-                       ga);
+    const dim3 gg((unsigned)(ga.m_tiles * ga.n_tiles), (unsigned)pl.A2, 1);
+    hipLaunchKernelGGL(wino_gemm_kernel<32>, gg, dim3(256), 0, st, ga);
   }
 
   WinoOutArgs oa;
@@ -662,4 +672,279 @@ extern "C" int fcd_conv2d_bwd_data_wino(const fcd_conv_desc* d, const float* dy,
            dx, nullptr, nullptr, ws, (hipStream_t)stream);
   FCD_LAUNCH_CHECK("conv2d_bwd_data_wino");
   return FCD_OK;
+}
+
+// =============================================================================================
+// Weight gradient through the same transforms (m = 4):
+//   dU_xi[k][c] = sum_t W_xi[k][t] * V_xi[c][t],  W = A dY_t A^T (6x6 from the 4x4 gradient tile),
+//   V = B^T d_t B as in the forward pass,  dw[k][c] = G^T dU G  (3x3 from 6x6)
+// i.e. 36 GEMMs with the reduction over the image tiles t -- a quarter of the direct weight-gradient
+// multiplies.  Both operands are written tile-contiguous ([xi][channel][Tpad], zero padded to a
+// multiple of 32 tiles), so the transform kernels are pure streaming passes (thread = tile) and the
+// GEMM is the same kernel with a row-major B and, for small filters, a split reduction whose partial
+// dU blocks are summed in fixed order by the final transform.  The bias gradient falls out of the dY
+// pass (per-block channel sums).
+struct WinoWgArgs {
+  const float* src;      // x (N, C, H, W) or dy (N, K, H, W)
+  const float* mask;     // dy only: ReLU output of the layer (NULL: none)
+  float* dst;            // [36][ch][Tpad]
+  float* psum;           // dy only: [gridDim.x][ch] per-block channel sums (NULL: none)
+  int N, CH, H, W, TH, TW;
+  long long T, Tpad;
+};
+
+// V'[xi][c][t]: thread = tile, block = 256 consecutive tiles of one channel
+__global__ __launch_bounds__(256) void wino_wg_input_kernel(WinoWgArgs a) {
+  constexpr int A = 6;
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int c = blockIdx.y;
+  if (t >= a.Tpad) return;
+  float* vout = a.dst + (size_t)c * a.Tpad + t;
+  const size_t xs = (size_t)a.CH * a.Tpad;
+  if (t >= a.T) {
+#pragma unroll
+    for (int i = 0; i < A * A; ++i) vout[(size_t)i * xs] = 0.f;
+    return;
+  }
+  const int tx = (int)(t % a.TW);
+  const long long r2 = t / a.TW;
+  const int ty = (int)(r2 % a.TH), n = (int)(r2 / a.TH);
+  const float* xp = a.src + ((size_t)n * a.CH + c) * a.H * a.W;
+  const int ih0 = ty * 4 - 1, iw0 = tx * 4 - 1;
+  float d[A][A];
+#pragma unroll
+  for (int i = 0; i < A; ++i) {
+    const int ih = ih0 + i;
+    const bool rok = ih >= 0 && ih < a.H;
+#pragma unroll
+    for (int j = 0; j < A; ++j) {
+      const int iw = iw0 + j;
+      d[i][j] = (rok && iw >= 0 && iw < a.W) ? xp[(size_t)ih * a.W + iw] : 0.f;
+    }
+  }
+  float t1[A][A];
+#pragma unroll
+  for (int i = 0; i < A; ++i)
+#pragma unroll
+    for (int j = 0; j < A; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < A; ++k)
+        if (WinoMat<4>::BT(i, k) != 0.f) s += WinoMat<4>::BT(i, k) * d[k][j];
+      t1[i][j] = s;
+    }
+#pragma unroll
+  for (int i = 0; i < A; ++i)
+#pragma unroll
+    for (int j = 0; j < A; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < A; ++k)
+        if (WinoMat<4>::BT(j, k) != 0.f) s += t1[i][k] * WinoMat<4>::BT(j, k);
+      vout[(size_t)(i * A + j) * xs] = s;
+    }
+}
+
+// W[xi][k][t] = A dY A^T, plus per-block channel sums of dY (bias gradient)
+__global__ __launch_bounds__(256) void wino_wg_dy_kernel(WinoWgArgs a) {
+  constexpr int A = 6;
+  __shared__ double red[16];
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int k = blockIdx.y;
+  float dy[4][4];
+  float lsum = 0.f;
+  const bool live = t < a.T;
+  if (live) {
+    const int tx = (int)(t % a.TW);
+    const long long r2 = t / a.TW;
+    const int ty = (int)(r2 % a.TH), n = (int)(r2 / a.TH);
+    const size_t base = ((size_t)n * a.CH + k) * a.H * a.W;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ih = ty * 4 + i;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int iw = tx * 4 + j;
+        float v = 0.f;
+        if (ih < a.H && iw < a.W) {
+          const size_t off = base + (size_t)ih * a.W + iw;
+          v = a.src[off];
+          if (a.mask && !(a.mask[off] > 0.f)) v = 0.f;
+        }
+        dy[i][j] = v;
+        lsum += v;
+      }
+    }
+  }
+  if (a.psum != nullptr) {       // uniform: every thread of the block takes part
+    const double bs = block_sum_d((double)lsum, red);
+    if (threadIdx.x == 0) a.psum[(size_t)blockIdx.x * a.CH + k] = (float)bs;
+  }
+  if (t >= a.Tpad) return;
+  float* wout = a.dst + (size_t)k * a.Tpad + t;
+  const size_t xs = (size_t)a.CH * a.Tpad;
+  if (!live) {
+#pragma unroll
+    for (int i = 0; i < A * A; ++i) wout[(size_t)i * xs] = 0.f;
+    return;
+  }
+  float t1[A][4];   // A dY : A[q][i] = AT(i, q)
+#pragma unroll
+  for (int q = 0; q < A; ++q)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (WinoMat<4>::AT(i, q) != 0.f) s += WinoMat<4>::AT(i, q) * dy[i][j];
+      t1[q][j] = s;
+    }
+#pragma unroll
+  for (int q = 0; q < A; ++q)
+#pragma unroll
+    for (int p2 = 0; p2 < A; ++p2) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (WinoMat<4>::AT(j, p2) != 0.f) s += t1[q][j] * WinoMat<4>::AT(j, p2);
+      wout[(size_t)(q * A + p2) * xs] = s;
+    }
+}
+
+// dw[k][c][3][3] = G^T (sum over splits of dU[split][xi][k][c]) G
+__global__ __launch_bounds__(256) void wino_wg_final_kernel(const float* __restrict__ dU, float* __restrict__ dw, int K,
+                                                            int C, int splits) {
+  constexpr int A = 6;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)K * C) return;
+  const size_t xs = (size_t)K * C, ss = 36 * xs;
+  float u[A][A];
+#pragma unroll
+  for (int q = 0; q < A * A; ++q) {
+    float s = 0.f;
+    for (int sp = 0; sp < splits; ++sp) s += dU[(size_t)sp * ss + (size_t)q * xs + i];
+    u[q / A][q % A] = s;
+  }
+  float t1[3][A];   // G^T u : G^T[r][q] = G(q, r)
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int p2 = 0; p2 < A; ++p2) {
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < A; ++q)
+        if (WinoMat<4>::G(q, r) != 0.f) s += WinoMat<4>::G(q, r) * u[q][p2];
+      t1[r][p2] = s;
+    }
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) {
+      float s = 0.f;
+#pragma unroll
+      for (int p2 = 0; p2 < A; ++p2)
+        if (WinoMat<4>::G(p2, s3) != 0.f) s += t1[r][p2] * WinoMat<4>::G(p2, s3);
+      dw[(size_t)i * 9 + r * 3 + s3] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void wino_psum_fin_kernel(const float* __restrict__ psum, float* __restrict__ out, int C,
+                                                            int nblk) {
+  __shared__ double red[16];
+  const int c = blockIdx.x;
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += 256) s += (double)psum[(size_t)b * C + c];
+  s = block_sum_d(s, red);
+  if (threadIdx.x == 0) out[c] = (float)s;
+}
+
+struct WinoWgPlan {
+  int TH, TW, splits, sps, stages;
+  long long T, Tpad;
+  size_t w_bytes, v_bytes, du_bytes, psum_bytes;
+};
+
+// 0 = direct weight-gradient kernel
+int fcd_wino_wgrad_plan(const fcd_conv_desc* d, WinoWgPlan* pl) {
+  if (wino_env() != 4) return 0;
+  if (!(d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1)) return 0;
+  static int min_k = -1, min_c = -1;
+  if (min_k < 0) {
+    const char* e = getenv("FCD_WINO_WG_MINK");
+    min_k = e ? atoi(e) : 128;
+    const char* f = getenv("FCD_WINO_WG_MINC");
+    min_c = f ? atoi(f) : 128;
+  }
+  if (d->K < min_k || d->C < min_c || d->P < 4 || d->Q < 4) return 0;
+  pl->TH = cdiv(d->H, 4);
+  pl->TW = cdiv(d->W, 4);
+  pl->T = (long long)d->N * pl->TH * pl->TW;
+  pl->Tpad = (pl->T + 31) / 32 * 32;
+  pl->stages = (int)(pl->Tpad / 32);
+  const int blocks = cdiv(d->K, 128) * cdiv(d->C, 128) * 36;
+  int splits = cdiv(1536, blocks);
+  if (splits > pl->stages) splits = pl->stages;
+  if (splits > 64) splits = 64;
+  if (splits < 1) splits = 1;
+  pl->sps = cdiv(pl->stages, splits);
+  pl->splits = cdiv(pl->stages, pl->sps);
+  pl->w_bytes = (size_t)36 * d->K * pl->Tpad * sizeof(float);
+  pl->v_bytes = (size_t)36 * d->C * pl->Tpad * sizeof(float);
+  pl->du_bytes = (size_t)pl->splits * 36 * d->K * d->C * sizeof(float);
+  pl->psum_bytes = (size_t)cdiv64(pl->Tpad, 256) * d->K * sizeof(float);
+  return 4;
+}
+
+size_t fcd_wino_wgrad_ws_bytes(const fcd_conv_desc* d) {
+  WinoWgPlan pl;
+  if (!fcd_wino_wgrad_plan(d, &pl)) return 0;
+  return pl.w_bytes + pl.v_bytes + pl.du_bytes + pl.psum_bytes + 1024;
+}
+
+// called by fcd_conv2d_bwd_weight_bias (conv_wgrad.hip) when the plan says so; ws holds fcd_wino_wgrad_ws_bytes
+int fcd_wino_wgrad_run(const fcd_conv_desc* d, const float* x, const float* dy, const float* relu_out, float* dw,
+                       float* db, void* ws, hipStream_t st) {
+  WinoWgPlan pl;
+  if (!fcd_wino_wgrad_plan(d, &pl)) return 1;
+  char* wsp = (char*)ws;
+  float* Wb = (float*)wsp; wsp += (pl.w_bytes + 255) & ~(size_t)255;
+  float* Vb = (float*)wsp; wsp += (pl.v_bytes + 255) & ~(size_t)255;
+  float* dU = (float*)wsp; wsp += (pl.du_bytes + 255) & ~(size_t)255;
+  float* psum = (float*)wsp;
+  const unsigned tb = (unsigned)cdiv64(pl.Tpad, 256);
+  {
+    FcdProfScope p1(FCD_K_WINO_XFORM, st, 0.0,
+                    4.0 * ((double)d->N * d->C * d->H * d->W + (double)d->N * d->K * d->P * d->Q) + (double)pl.w_bytes +
+                        (double)pl.v_bytes);
+    WinoWgArgs ia;
+    memset(&ia, 0, sizeof(ia));
+    ia.src = x; ia.dst = Vb; ia.N = d->N; ia.CH = d->C; ia.H = d->H; ia.W = d->W;
+    ia.TH = pl.TH; ia.TW = pl.TW; ia.T = pl.T; ia.Tpad = pl.Tpad;
+    hipLaunchKernelGGL(wino_wg_input_kernel, dim3(tb, (unsigned)d->C), dim3(256), 0, st, ia);
+    WinoWgArgs ya = ia;
+    ya.src = dy; ya.mask = relu_out; ya.dst = Wb; ya.CH = d->K; ya.psum = db ? psum : nullptr;
+    hipLaunchKernelGGL(wino_wg_dy_kernel, dim3(tb, (unsigned)d->K), dim3(256), 0, st, ya);
+    if (db) hipLaunchKernelGGL(wino_psum_fin_kernel, dim3((unsigned)d->K), dim3(256), 0, st, (const float*)psum, db, d->K, (int)tb);
+  }
+  WinoGemmArgs ga;
+  memset(&ga, 0, sizeof(ga));
+  ga.A = Wb; ga.B = Vb; ga.C = dU;
+  ga.M = d->K; ga.N = d->C; ga.Kc = (int)pl.Tpad;
+  ga.m_tiles = cdiv(d->K, 128); ga.n_tiles = cdiv(d->C, 128);
+  ga.xcd_remap = 0;
+  ga.a_ld = pl.Tpad; ga.a_batch = (long long)d->K * pl.Tpad;
+  ga.b_ld = pl.Tpad; ga.b_adv = 32; ga.b_batch = (long long)d->C * pl.Tpad;
+  ga.stages_per_split = pl.sps;
+  {
+    FcdProfScope p2(FCD_K_WINO_GEMM, st, 2.0 * 36 * d->K * (double)d->C * (double)pl.Tpad,
+                    (double)pl.w_bytes + (double)pl.v_bytes + (double)pl.du_bytes);
+    hipLaunchKernelGGL(wino_gemm_kernel<32>, dim3((unsigned)(ga.m_tiles * ga.n_tiles), 36, (unsigned)pl.splits), dim3(256),
+                       0, st, ga);
+  }
+  {
+    FcdProfScope p3(FCD_K_WINO_XFORM, st, 0.0, (double)pl.du_bytes + 4.0 * 9 * d->K * d->C);
+    hipLaunchKernelGGL(wino_wg_final_kernel, dim3((unsigned)cdiv64((long long)d->K * d->C, 256)), dim3(256), 0, st,
+                       (const float*)dU, dw, d->K, d->C, pl.splits);
+  }
+  return 0;
 }
