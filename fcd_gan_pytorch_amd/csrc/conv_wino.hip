@@ -242,20 +242,23 @@ struct WinoGemmArgs {
   int stages_per_split;   // blockIdx.z = split of the reduction: stages [z * sps, min((z + 1) * sps, Kc / 32))
 };
 
-template <int KC>      // reduction elements per pipeline stage
-__global__ __launch_bounds__(256, 2) void wino_gemm_kernel(WinoGemmArgs a) {
-  constexpr int BM = 128, BN = 128;
+template <int WM, int WN>      // waves along M / N, each 64 x 64: block tile (64 WM) x (64 WN)
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void wino_gemm_kernel(WinoGemmArgs a) {
+  constexpr int KC = 32;                   // reduction elements per pipeline stage
+  constexpr int NW = WM * WN;
+  constexpr int BM = 64 * WM, BN = 64 * WN;
   constexpr int UH = KC / 8;               // 16-B units per lane half and row
-  constexpr int PIECES = BM * UH * 2 / 64; // wave-instructions of 1 KiB per operand and stage
-  constexpr int PPW = PIECES / 4;
-  constexpr int SWS = UH == 4 ? 1 : 2;     // swizzle = (row >> SWS) & (UH - 1)
+  constexpr int PPW_A = BM * UH * 2 / 64 / NW;   // 1 KiB wave-instructions per wave, operand and stage
+  constexpr int PPW_B = BN * UH * 2 / 64 / NW;
+  static_assert(PPW_A * NW * 64 == BM * UH * 2 && PPW_B * NW * 64 == BN * UH * 2, "DMA split");
+  constexpr int SWS = 1;                   // swizzle = (row >> 1) & 3
   __shared__ __attribute__((aligned(16))) float sa0[BM * KC];
   __shared__ __attribute__((aligned(16))) float sa1[BM * KC];
   __shared__ __attribute__((aligned(16))) float sb0[BN * KC];
   __shared__ __attribute__((aligned(16))) float sb1[BN * KC];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   unsigned v;
   {
     const unsigned total = gridDim.x, b = blockIdx.x;
@@ -269,21 +272,27 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(WinoGemmArgs a) {
   const int mt = (int)(v % (unsigned)a.m_tiles), nt = (int)(v / (unsigned)a.m_tiles);
   const int batch = blockIdx.y;
   const int m0 = mt * BM, n0 = nt * BN;
-  static_assert(KC == 32, "stage = one 32-float chunk");
   const int q_all = a.Kc / KC;
   const int q_beg = (int)blockIdx.z * a.stages_per_split;
   const int Q = min(a.stages_per_split, q_all - q_beg);      // pipeline stages of this block
-  const float* Ab = a.A + (size_t)batch * a.a_batch + (size_t)q_beg * KC;
-  const float* Bb = a.B + (size_t)batch * a.b_batch + (size_t)q_beg * a.b_adv;
+  // 64-bit part of the addresses in the (scalar) bases, the per-lane offsets stay 32-bit
+  const float* Ab = a.A + (size_t)batch * a.a_batch + (size_t)q_beg * KC + (size_t)m0 * a.a_ld;
+  const float* Bb = a.B + (size_t)batch * a.b_batch + (size_t)q_beg * a.b_adv + (size_t)n0 * a.b_ld;
 
-  int a_goff[PPW], b_goff[PPW];
+  int a_goff[PPW_A], b_goff[PPW_B];
 #pragma unroll
-  for (int j = 0; j < PPW; ++j) {
-    const int u = (wave + 4 * j) * 64 + lane;
+  for (int j = 0; j < PPW_A; ++j) {
+    const int u = (wave + NW * j) * 64 + lane;
     const int h = u / (BM * UH), row = (u / UH) % BM, pj = u % UH;
     const int jl = pj ^ ((row >> SWS) & (UH - 1));
-    a_goff[j] = (int)(min(m0 + row, a.M - 1) * a.a_ld) + h * (KC / 2) + jl * 4;
-    b_goff[j] = (int)(min(n0 + row, a.N - 1) * a.b_ld) + h * (KC / 2) + jl * 4;
+    a_goff[j] = (int)(min(row, a.M - 1 - m0) * a.a_ld) + h * (KC / 2) + jl * 4;
+  }
+#pragma unroll
+  for (int j = 0; j < PPW_B; ++j) {
+    const int u = (wave + NW * j) * 64 + lane;
+    const int h = u / (BN * UH), row = (u / UH) % BN, pj = u % UH;
+    const int jl = pj ^ ((row >> SWS) & (UH - 1));
+    b_goff[j] = (int)(min(row, a.N - 1 - n0) * a.b_ld) + h * (KC / 2) + jl * 4;
   }
 
   int aoff[2], boff[2], uoff[UH];
@@ -308,12 +317,12 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(WinoGemmArgs a) {
   {                                                                                              \
     const float* as_ = Ab + (size_t)(QC) * KC;                                                   \
     const float* bs_ = Bb + (size_t)(QC) * a.b_adv;                                              \
-    _Pragma("unroll") for (int j = 0; j < PPW; ++j)                                              \
+    _Pragma("unroll") for (int j = 0; j < PPW_A; ++j)                                            \
       __builtin_amdgcn_global_load_lds((gbl_void_t*)(as_ + a_goff[j]),                           \
-                                       (lds_void_t*)((SA) + (wave + 4 * j) * 256), 16, 0, 0);    \
-    _Pragma("unroll") for (int j = 0; j < PPW; ++j)                                              \
+                                       (lds_void_t*)((SA) + (wave + NW * j) * 256), 16, 0, 0);   \
+    _Pragma("unroll") for (int j = 0; j < PPW_B; ++j)                                            \
       __builtin_amdgcn_global_load_lds((gbl_void_t*)(bs_ + b_goff[j]),                           \
-                                       (lds_void_t*)((SB) + (wave + 4 * j) * 256), 16, 0, 0);    \
+                                       (lds_void_t*)((SB) + (wave + NW * j) * 256), 16, 0, 0);   \
   }
 #define WG_STEP(QC, SA, SB, SAN, SBN)                                                            \
   {                                                                                              \
@@ -354,6 +363,34 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(WinoGemmArgs a) {
         if (n < a.N) Cb[(size_t)m * a.N + n] = acc[i][j][r];
       }
     }
+}
+
+static int wino_gemm_cfg() {     // FCD_WINO_TILE: 0 = 128x128 (4 waves), 1 = 256x128 (8 waves), 2 = 256x256 (16 waves)
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("FCD_WINO_TILE");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
+
+static void wino_gemm_launch(WinoGemmArgs ga, int batches, int splits, hipStream_t st) {
+  int cfg = wino_gemm_cfg();
+  if (cfg == 2 && (ga.M < 256 || ga.N < 256)) cfg = 1;
+  if (cfg == 1 && ga.M < 256) cfg = 0;
+  if (cfg == 2) {
+    ga.m_tiles = cdiv(ga.M, 256); ga.n_tiles = cdiv(ga.N, 256);
+    hipLaunchKernelGGL((wino_gemm_kernel<4, 4>), dim3((unsigned)(ga.m_tiles * ga.n_tiles), (unsigned)batches, (unsigned)splits),
+                       dim3(1024), 0, st, ga);
+  } else if (cfg == 1) {
+    ga.m_tiles = cdiv(ga.M, 256); ga.n_tiles = cdiv(ga.N, 128);
+    hipLaunchKernelGGL((wino_gemm_kernel<4, 2>), dim3((unsigned)(ga.m_tiles * ga.n_tiles), (unsigned)batches, (unsigned)splits),
+                       dim3(512), 0, st, ga);
+  } else {
+    ga.m_tiles = cdiv(ga.M, 128); ga.n_tiles = cdiv(ga.N, 128);
+    hipLaunchKernelGGL((wino_gemm_kernel<2, 2>), dim3((unsigned)(ga.m_tiles * ga.n_tiles), (unsigned)batches, (unsigned)splits),
+                       dim3(256), 0, st, ga);
+  }
 }
 
 // --------------------------------------------------------------------------------------------
@@ -612,8 +649,7 @@ static int wino_run(const WinoPlan& pl, int N, int in_ch, int H, int W, const fl
   {
     FcdProfScope p2(FCD_K_WINO_GEMM, st, 2.0 * pl.A2 * pl.rows * (double)pl.Kc * (double)pl.T,
                     (double)pl.v_bytes + (double)pl.m_bytes + 4.0 * pl.A2 * pl.rows * pl.Kc);
-    const dim3 gg((unsigned)(ga.m_tiles * ga.n_tiles), (unsigned)pl.A2, 1);
-    hipLaunchKernelGGL(wino_gemm_kernel<32>, gg, dim3(256), 0, st, ga);
+    wino_gemm_launch(ga, pl.A2, 1, st);
   }
 
   WinoOutArgs oa;
@@ -938,8 +974,7 @@ int fcd_wino_wgrad_run(const fcd_conv_desc* d, const float* x, const float* dy, 
   {
     FcdProfScope p2(FCD_K_WINO_GEMM, st, 2.0 * 36 * d->K * (double)d->C * (double)pl.Tpad,
                     (double)pl.w_bytes + (double)pl.v_bytes + (double)pl.du_bytes);
-    hipLaunchKernelGGL(wino_gemm_kernel<32>, dim3((unsigned)(ga.m_tiles * ga.n_tiles), 36, (unsigned)pl.splits), dim3(256),
-                       0, st, ga);
+    wino_gemm_launch(ga, 36, pl.splits, st);
   }
   {
     FcdProfScope p3(FCD_K_WINO_XFORM, st, 0.0, (double)pl.du_bytes + 4.0 * 9 * d->K * d->C);
