@@ -153,7 +153,43 @@ __global__ __launch_bounds__(256) void wino_input_kernel(WinoInArgs a) {
     return v;
   };
 
-  if (VEC && SRC != 2) {
+  if (VEC && SRC == 2) {
+    // pooled gradient: 4 strip columns = 2 pooled elements (one 8-B load + 2 code bytes), each routed to
+    // the slot its argmax code names
+    constexpr int V4 = (CW - 2) / 4;
+    for (int idx = tid; idx < 32 * RH * V4; idx += 256) {
+      const int c = idx / (RH * V4), rem = idx % (RH * V4);
+      const int r = rem / V4, v4 = rem % V4;
+      const int ih = ih0 + r, iw = iw0 + 1 + v4 * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      const int hp = ih >> 1, wq = iw >> 1;
+      if (q * 32 + c < a.C && ih >= 0 && ih < a.H && iw < a.W && hp < a.Hp && wq + 1 < a.Wp + 1) {
+        const size_t off = img + (size_t)c * plane + (size_t)hp * a.Wp + wq;
+        const unsigned rowbit = (unsigned)((ih & 1) << 1) | 4u;
+        if (wq + 1 < a.Wp) {
+          const f32x2 g2 = *(const f32x2*)(a.x + off);
+          const unsigned c0 = a.code[off], c1 = a.code[off + 1];
+          v[0] = c0 == rowbit ? g2[0] : 0.f;
+          v[1] = c0 == (rowbit | 1u) ? g2[0] : 0.f;
+          v[2] = c1 == rowbit ? g2[1] : 0.f;
+          v[3] = c1 == (rowbit | 1u) ? g2[1] : 0.f;
+        } else if (wq < a.Wp) {
+          const float g0 = a.x[off];
+          const unsigned c0 = a.code[off];
+          v[0] = c0 == rowbit ? g0 : 0.f;
+          v[1] = c0 == (rowbit | 1u) ? g0 : 0.f;
+        }
+      }
+      float* t = tile + c * PL + r * CW + 1 + v4 * 4;
+      t[0] = v[0]; t[1] = v[1]; t[2] = v[2]; t[3] = v[3];
+    }
+    for (int idx = tid; idx < 32 * RH * 2; idx += 256) {
+      const int c = idx / (RH * 2), rem = idx % (RH * 2);
+      const int r = rem >> 1, side = rem & 1;
+      const int col = side ? CW - 1 : 0;
+      tile[c * PL + r * CW + col] = fetch(c, ih0 + r, iw0 + col);
+    }
+  } else if (VEC) {
     constexpr int V4 = (CW - 2) / 4;                    // float4 per strip row
     for (int idx = tid; idx < 32 * RH * V4; idx += 256) {
       const int c = idx / (RH * V4), rem = idx % (RH * V4);
@@ -601,12 +637,13 @@ static int wino_xcd() {
 template <int MM, int TRB, int TWB>
 static void wino_launch_input_cfg(const WinoInArgs& ia, int src, hipStream_t st) {
   dim3 grid((unsigned)cdiv(ia.TW, TWB), (unsigned)cdiv(ia.TH, TRB), (unsigned)(ia.N * ia.Q));
-  const bool vec = (ia.W & 3) == 0 && src != 2;
+  // float4 strip rows: W % 4 == 0; the pooled source additionally needs 8-B aligned pooled rows
+  const bool vec = (ia.W & 3) == 0 && (src != 2 || (ia.Wp & 1) == 0);
 #define WINO_IN(SRC_, VEC_) \
   hipLaunchKernelGGL((wino_input_kernel<MM, SRC_, TRB, TWB, VEC_>), grid, dim3(256), 0, st, ia)
   if (src == 0) { if (vec) WINO_IN(0, true); else WINO_IN(0, false); }
   else if (src == 1) { if (vec) WINO_IN(1, true); else WINO_IN(1, false); }
-  else WINO_IN(2, false);
+  else { if (vec) WINO_IN(2, true); else WINO_IN(2, false); }
 #undef WINO_IN
 }
 
