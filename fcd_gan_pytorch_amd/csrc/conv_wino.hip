@@ -269,6 +269,9 @@ __global__ __launch_bounds__(256) void wino_input_kernel(WinoInArgs a) {
 // is applied on the SOURCE address of the lane-linear DMA -- so the four ds_read_b128 with which a
 // lane fetches its 16 operands of the chunk are bank-conflict free without padding.  Two LDS stages
 // as distinct objects, chunk loop unrolled by two (see conv_igemm.hip for why).
+#ifndef FCD_GEXP
+#define FCD_GEXP 0   // diagnostic builds only (wrong results): 1 no DMA in the loop, 2 operands from registers, 4 no barrier
+#endif
 struct WinoGemmArgs {
   const float* A;   // row m of batch b at A + b * a_batch + m * a_ld, stage q at + q * 32 floats
   const float* B;   // row n of batch b at B + b * b_batch + n * b_ld, stage q at + q * b_adv floats
@@ -362,19 +365,19 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void wino_gem
   }
 #define WG_STEP(QC, SA, SB, SAN, SBN)                                                            \
   {                                                                                              \
-    if ((QC) + 1 < Q) WG_DMA((QC) + 1, SAN, SBN)                                                 \
+    if (!(FCD_GEXP & 1)) if ((QC) + 1 < Q) WG_DMA((QC) + 1, SAN, SBN)                            \
     _Pragma("unroll") for (int j4 = 0; j4 < UH; ++j4) {                                          \
       f32x4 av[2], bv[2];                                                                        \
       _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                            \
-        av[i] = *(const f32x4*)((SA) + aoff[i] + uoff[j4]);                                      \
-        bv[i] = *(const f32x4*)((SB) + boff[i] + uoff[j4]);                                      \
+        av[i] = (FCD_GEXP & 2) ? f32x4{(float)lane, 1.f, 2.f, (float)j4} : *(const f32x4*)((SA) + aoff[i] + uoff[j4]); \
+        bv[i] = (FCD_GEXP & 2) ? f32x4{(float)i, 1.f, (float)lane, 3.f} : *(const f32x4*)((SB) + boff[i] + uoff[j4]); \
       }                                                                                          \
       _Pragma("unroll") for (int e = 0; e < 4; ++e)                                              \
         _Pragma("unroll") for (int i = 0; i < 2; ++i)                                            \
           _Pragma("unroll") for (int j = 0; j < 2; ++j)                                          \
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], bv[j][e], acc[i][j], 0, 0, 0); \
     }                                                                                            \
-    __syncthreads();                                                                             \
+    if (!(FCD_GEXP & 4)) __syncthreads();                                                        \
   }
 
   WG_DMA(0, sa0, sb0)
@@ -884,41 +887,49 @@ __global__ __launch_bounds__(256) void wino_wg_dy_kernel(WinoWgArgs a) {
     }
 }
 
-// dw[k][c][3][3] = G^T (sum over splits of dU[split][xi][k][c]) G
+// dw[k][c][3][3] = G^T (sum over splits of dU[split][xi][k][c]) G.  Thread = one (k, c) filter; the nine
+// taps of the block's 256 filters are staged in LDS so that dw is written as 2304 consecutive floats.
 __global__ __launch_bounds__(256) void wino_wg_final_kernel(const float* __restrict__ dU, float* __restrict__ dw, int K,
                                                             int C, int splits) {
   constexpr int A = 6;
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (long long)K * C) return;
-  const size_t xs = (size_t)K * C, ss = 36 * xs;
-  float u[A][A];
+  __shared__ float st9[256 * 9];
+  const long long total = (long long)K * C;
+  const long long i0 = (long long)blockIdx.x * 256;
+  const long long i = i0 + threadIdx.x;
+  if (i < total) {
+    const size_t xs = (size_t)K * C, ss = 36 * xs;
+    float u[A][A];
 #pragma unroll
-  for (int q = 0; q < A * A; ++q) {
-    float s = 0.f;
-    for (int sp = 0; sp < splits; ++sp) s += dU[(size_t)sp * ss + (size_t)q * xs + i];
-    u[q / A][q % A] = s;
+    for (int q = 0; q < A * A; ++q) {
+      float s = 0.f;
+      for (int sp = 0; sp < splits; ++sp) s += dU[(size_t)sp * ss + (size_t)q * xs + i];
+      u[q / A][q % A] = s;
+    }
+    float t1[3][A];   // G^T u : G^T[r][q] = G(q, r)
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int p2 = 0; p2 < A; ++p2) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < A; ++q)
+          if (WinoMat<4>::G(q, r) != 0.f) s += WinoMat<4>::G(q, r) * u[q][p2];
+        t1[r][p2] = s;
+      }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int s3 = 0; s3 < 3; ++s3) {
+        float s = 0.f;
+#pragma unroll
+        for (int p2 = 0; p2 < A; ++p2)
+          if (WinoMat<4>::G(p2, s3) != 0.f) s += t1[r][p2] * WinoMat<4>::G(p2, s3);
+        st9[threadIdx.x * 9 + r * 3 + s3] = s;
+      }
   }
-  float t1[3][A];   // G^T u : G^T[r][q] = G(q, r)
-#pragma unroll
-  for (int r = 0; r < 3; ++r)
-#pragma unroll
-    for (int p2 = 0; p2 < A; ++p2) {
-      float s = 0.f;
-#pragma unroll
-      for (int q = 0; q < A; ++q)
-        if (WinoMat<4>::G(q, r) != 0.f) s += WinoMat<4>::G(q, r) * u[q][p2];
-      t1[r][p2] = s;
-    }
-#pragma unroll
-  for (int r = 0; r < 3; ++r)
-#pragma unroll
-    for (int s3 = 0; s3 < 3; ++s3) {
-      float s = 0.f;
-#pragma unroll
-      for (int p2 = 0; p2 < A; ++p2)
-        if (WinoMat<4>::G(p2, s3) != 0.f) s += t1[r][p2] * WinoMat<4>::G(p2, s3);
-      dw[(size_t)i * 9 + r * 3 + s3] = s;
-    }
+  __syncthreads();
+  const long long nout = (total - i0 < 256 ? total - i0 : 256) * 9;
+  for (int j = threadIdx.x; j < nout; j += 256) dw[i0 * 9 + j] = st9[j];
 }
 
 __global__ __launch_bounds__(256) void wino_psum_fin_kernel(const float* __restrict__ psum, float* __restrict__ out, int C,
