@@ -9,7 +9,7 @@ dur = collections.defaultdict(list)
 for r in csv.DictReader(open(d + '/pmc_kernel_trace.csv')):
     dur[r['Kernel_Name'][:70]].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
 for k, cs in ctr.items():
-    if 'conv' not in k and 'bn_' not in k and 'ssim' not in k:
+    if "conv" not in k and "bn_" not in k and "ssim" not in k and "wino" not in k:
         continue
     n = max(len(v) for v in cs.values())
     us = sum(dur[k]) / max(len(dur[k]), 1)
