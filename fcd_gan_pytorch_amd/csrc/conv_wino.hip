@@ -420,7 +420,11 @@ static void wino_gemm_launch(WinoGemmArgs ga, int batches, int splits, hipStream
   int cfg = wino_gemm_cfg();
   if (cfg == 2 && (ga.M < 256 || ga.N < 256)) cfg = 1;
   if (cfg == 1 && ga.M < 256) cfg = 0;
-  if (cfg == 2) {
+  if (ga.M <= 64) {        // 64-row GEMMs: 64 x 256 tiles, no wasted MFMA rows
+    ga.m_tiles = 1; ga.n_tiles = cdiv(ga.N, 256);
+    hipLaunchKernelGGL((wino_gemm_kernel<1, 4>), dim3((unsigned)(ga.m_tiles * ga.n_tiles), (unsigned)batches, (unsigned)splits),
+                       dim3(256), 0, st, ga);
+  } else if (cfg == 2) {
     ga.m_tiles = cdiv(ga.M, 256); ga.n_tiles = cdiv(ga.N, 256);
     hipLaunchKernelGGL((wino_gemm_kernel<4, 4>), dim3((unsigned)(ga.m_tiles * ga.n_tiles), (unsigned)batches, (unsigned)splits),
                        dim3(1024), 0, st, ga);
@@ -561,8 +565,10 @@ extern "C" int fcd_conv_wino_set(int m) {
 
 // mode 0 forward / 1 data gradient.  Returns the output tile size m (2 or 4), or 0 when the layer
 // runs on the direct kernels.  The transform passes stream 22 (m = 4) / 36 (m = 2) bytes per input and
-// per output element, which the 4x / 2.25x smaller GEMM only pays back when the GEMM has >= 128 rows
-// (measured on MI355X: 64 -> 128 channels forward wins, its data gradient with 64 rows does not).
+// per output element, which the 4x / 2.25x smaller GEMM only pays back from 128 GEMM rows and 64 reduction
+// channels upwards -- measured per layer on MI355X with tools/bench_conv.py.  64-row layers (64 x 256 GEMM
+// tiles, FCD_WINO_MINROWS=64) are a wash: 64 -> 64 at 208 x 256 x 256 runs 8.3 / 8.4 ms vs 8.2 / 7.8 direct, the
+// ReLU-gated 128 -> 64 data gradient 4.4 vs 4.2.
 extern "C" int fcd_conv_wino_plan(const fcd_conv_desc* d, int mode) {
   if (!d || wino_env() == 0) return 0;
   if (!(d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1)) return 0;
