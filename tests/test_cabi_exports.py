@@ -40,6 +40,25 @@ def test_argument_validation_without_gpu():
     assert lib.fcd_conv_packed_elems(64, 13, 3, 3, 1) == 64 * 9 * 128
     assert lib.fcd_conv_packed_elems(64, 13, 9, 9, 0) == 16 * 81 * 128
     assert lib.fcd_bn_act_ws_bytes(64, 2) > 0
+    # Winograd layer plan (pure host logic): wide 3x3 / stride-1 layers only
+    prev = lib.fcd_conv_wino_set(4)
+    try:
+        wide = _lib.ConvDesc(2, 256, 32, 32, 512, 3, 3, 1, 1, 32, 32)
+        assert lib.fcd_conv_wino_plan(ctypes.byref(wide), 0) == 4 and lib.fcd_conv_wino_plan(ctypes.byref(wide), 1) == 4
+        T = 2 * 8 * 8
+        assert lib.fcd_conv_wino_ws_bytes(ctypes.byref(wide), 0) == 36 * (256 // 32) * T * 32 * 4 + 36 * 512 * T * 4 + 256
+        assert lib.fcd_conv_wino_filter_elems(512, 256, 0, 4) == 36 * 512 * 256
+        assert lib.fcd_conv_wino_filter_elems(512, 256, 1, 2) == 16 * 256 * 512
+        for d in (_lib.ConvDesc(2, 64, 32, 32, 64, 3, 3, 1, 1, 32, 32),        # 64 GEMM rows
+                  _lib.ConvDesc(2, 256, 32, 32, 512, 3, 3, 2, 1, 16, 16),      # stride 2
+                  _lib.ConvDesc(2, 256, 32, 32, 512, 1, 1, 1, 0, 32, 32),      # 1x1
+                  _lib.ConvDesc(2, 13, 32, 32, 256, 3, 3, 1, 1, 32, 32)):      # 13 reduction channels
+            assert lib.fcd_conv_wino_plan(ctypes.byref(d), 0) == 0
+            assert lib.fcd_conv_wino_ws_bytes(ctypes.byref(d), 0) == 0
+        assert lib.fcd_conv_wino_set(0) == 4 and lib.fcd_conv_wino_plan(ctypes.byref(wide), 0) == 0
+        assert lib.fcd_conv_wino_set(2) == 0 and lib.fcd_conv_wino_plan(ctypes.byref(wide), 0) == 2
+    finally:
+        lib.fcd_conv_wino_set(prev)
 
 
 def test_product_rejects_cpu_tensors():
