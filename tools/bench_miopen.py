@@ -1,4 +1,5 @@
-"""How fast is the stock library path (PyTorch-ROCm -> MIOpen) on the dominant layer shapes?  (reference point only)"""
+"""How fast is the stock library path (PyTorch-ROCm -> MIOpen) on the dominant layer shapes?  (reference point only;
+MIOpen's kernel search takes ~10 minutes per shape on a fresh box -- run it with a generous timeout, one shape at a time)"""
 import sys, time, torch
 import torch.nn.functional as F
 torch.backends.cudnn.benchmark = True
