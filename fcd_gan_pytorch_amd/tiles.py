@@ -19,6 +19,8 @@ import struct
 import threading
 import queue
 
+import os
+
 import numpy as np
 import torch
 
@@ -266,6 +268,79 @@ class PairTileDataset(torch.utils.data.Dataset):
             r[:, wy:wy + wh, wx:wx + ww] = self.ref[:, ry:ry + rh, rx:rx + rw]
         return (torch.from_numpy(cx).float(), torch.from_numpy(cy).float(), torch.tensor(item),
                 torch.from_numpy(r).float())
+
+
+# ------------------------------------------------------------------------ dataset statistics
+def _valid(x):
+    """Valid-pixel mask of a patch: pixels whose band sum is non-zero (nodata / zero padding excluded,
+    CommonFunc.py:446) -- taken from the FIRST scene for both scenes, as the reference does."""
+    return torch.sum(x, dim=0) != 0
+
+
+def dataset_mean(dataset):
+    """Per-band mean of both scenes over the valid pixels of all patches (CommonFunc.Dataset_mean,
+    CommonFunc.py:436-465): per-patch means weighted by the patch's valid-pixel count."""
+    npix, mx, my = [], [], []
+    for i in range(len(dataset)):
+        item = dataset[i]
+        x, y = item[0], item[1]
+        idx = _valid(x)
+        npix.append(torch.sum(idx))
+        mx.append(torch.mean(x[:, idx], 1))
+        my.append(torch.mean(y[:, idx], 1))
+    mx = torch.cat(mx).reshape(len(mx), -1)
+    my = torch.cat(my).reshape(len(my), -1)
+    npix = torch.tensor(npix).reshape(-1, 1)
+    w = npix.repeat(1, mx.size()[1]) / torch.sum(npix)
+    return torch.sum(mx * w, dim=0), torch.sum(my * w, dim=0)
+
+
+def dataset_std(dataset, mean_x, mean_y):
+    """Per-band standard deviation around the given means (CommonFunc.Dataset_std, CommonFunc.py:467-500):
+    per-patch mean squared deviations weighted by n_i / (N - 1)."""
+    npix, vx, vy = [], [], []
+    mean_x = mean_x.reshape(-1, 1)
+    mean_y = mean_y.reshape(-1, 1)
+    for i in range(len(dataset)):
+        item = dataset[i]
+        x, y = item[0], item[1]
+        idx = _valid(x)
+        n = torch.sum(idx)
+        npix.append(n)
+        vx.append(torch.mean(torch.square(x[:, idx] - mean_x.repeat(1, n)), 1))
+        vy.append(torch.mean(torch.square(y[:, idx] - mean_y.repeat(1, n)), 1))
+    vx = torch.cat(vx).reshape(len(vx), -1)
+    vy = torch.cat(vy).reshape(len(vy), -1)
+    npix = torch.tensor(npix).reshape(-1, 1)
+    w = npix.repeat(1, vx.size()[1]) / (torch.sum(npix) - 1)
+    return torch.sqrt(torch.sum(vx * w, dim=0)), torch.sqrt(torch.sum(vy * w, dim=0))
+
+
+def _write_stats(path, mean, std):
+    with open(path, 'w') as f:
+        f.write('mean:' + ''.join(' {}'.format(v) for v in mean) + '\n')
+        f.write('std:' + ''.join(' {}'.format(v) for v in std) + '\n')
+
+
+def _read_stats(path):
+    with open(path) as f:
+        lines = f.readlines()
+    return [float(v) for v in lines[0].split()[1:]], [float(v) for v in lines[1].split()[1:]]
+
+
+def dataset_meanstd(txt_x, txt_y, dataset):
+    """``(meanX, stdX, meanY, stdY)`` as lists of floats, cached in two text files in the reference's
+    format (``mean: v v ...`` / ``std: v v ...``; CommonFunc.Dataset_meanstd, CommonFunc.py:373-434):
+    computed and written when either file is missing, read back otherwise."""
+    if not (os.path.exists(txt_x) and os.path.exists(txt_y)):
+        mx, my = dataset_mean(dataset)
+        sx, sy = dataset_std(dataset, mx, my)
+        _write_stats(txt_x, mx, sx)
+        _write_stats(txt_y, my, sy)
+        return mx.numpy().tolist(), sx.numpy().tolist(), my.numpy().tolist(), sy.numpy().tolist()
+    mx, sx = _read_stats(txt_x)
+    my, sy = _read_stats(txt_y)
+    return mx, sx, my, sy
 
 
 def normalize_(x, mean, std):

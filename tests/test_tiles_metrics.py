@@ -125,3 +125,33 @@ def test_prefetcher_yields_batches_in_order_on_cpu():
     out = list(tiles.Prefetcher(data, 'cpu'))
     assert [int(b[1]) for b in out] == list(range(5))
     assert all(torch.equal(o[0], d[0]) for o, d in zip(out, data))
+
+
+@pytest.mark.parametrize('tag', ['s1', 's2'])
+def test_dataset_statistics_match_reference(tag, tmp_path):
+    """Dataset_mean / Dataset_std / Dataset_meanstd (valid-pixel mask from the first scene,
+    count-weighted per-patch moments, text-file cache) vs the reference run over the same scenes
+    (tests/golden/gen_golden_stats.py)."""
+    from fcd_gan_pytorch_amd import tiles
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'stats.npz'))
+    nb, ys, xs, pw, ph, ox, oy = [int(v) for v in z[tag + '/meta']]
+    ds = tiles.PairTileDataset(z[tag + '/x'], z[tag + '/y'], None, (pw, ph), (ox, oy))
+    mx, my = tiles.dataset_mean(ds)
+    sx, sy = tiles.dataset_std(ds, mx, my)
+    ref = z[tag + '/mean_std']
+    np.testing.assert_allclose(np.stack([mx.numpy(), sx.numpy(), my.numpy(), sy.numpy()]), ref, rtol=1e-6)
+    t1, t2 = str(tmp_path / 'x.txt'), str(tmp_path / 'y.txt')
+    first = tiles.dataset_meanstd(t1, t2, ds)
+    np.testing.assert_allclose(np.array(first), z[tag + '/first'], rtol=1e-6)
+    # same text format as the reference (two lines, "mean:" / "std:" + space separated values)
+    for path, key in ((t1, '/txt1'), (t2, '/txt2')):
+        mine, theirs = open(path).read().split(), bytes(z[tag + key]).decode().split()
+        assert [w for w in mine if w.endswith(':')] == [w for w in theirs if w.endswith(':')] == ['mean:', 'std:']
+        np.testing.assert_allclose([float(w) for w in mine if not w.endswith(':')],
+                                   [float(w) for w in theirs if not w.endswith(':')], rtol=1e-6)
+    again = tiles.dataset_meanstd(t1, t2, ds)           # second call reads the cache
+    np.testing.assert_allclose(np.array(again), np.array(first), rtol=1e-7)
+    np.testing.assert_allclose(np.array(again), z[tag + '/again'], rtol=1e-6)
+    # the reference's own cache files are read back identically
+    open(t1, 'wb').write(bytes(z[tag + '/txt1'])); open(t2, 'wb').write(bytes(z[tag + '/txt2']))
+    np.testing.assert_allclose(np.array(tiles.dataset_meanstd(t1, t2, ds)), z[tag + '/again'], rtol=0, atol=0)
