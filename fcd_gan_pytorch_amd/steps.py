@@ -39,6 +39,15 @@ def _frozen(net):
             p.requires_grad_(f)
 
 
+def _weighted(weight, term, literal):
+    """``weight * term``; outside literal mode a zero weight (every demo sets ssim_weight = 0: the MS-SSIM
+    value is logged, its gradient multiplied by 0 -- Demo_RSSS.py:46) drops the term's graph instead of
+    back-propagating zeros through it."""
+    if not literal and isinstance(weight, (int, float)) and weight == 0 and torch.is_tensor(term):
+        term = term.detach()
+    return weight * term
+
+
 def _bcast_keep(cmask, C):
     return 1 - cmask            # (N,1,H,W) broadcasts over the C bands (reference uses .repeat)
 
@@ -92,7 +101,7 @@ def rsss_adversarial_step(netS, netD, netG, crit, optS, optD, x, y, region, perc
         with torch.no_grad():
             y_fake = netG(x)
     generator_loss, ssim_loss, perception_loss = crit(y, y_fake, cmap)
-    g_loss = generator_loss + perception_weight * perception_loss + ssim_weight * ssim_loss
+    g_loss = generator_loss + perception_weight * perception_loss + _weighted(ssim_weight, ssim_loss, literal)
     l1_loss = region_loss(cmap, region, 'l1')
     s_d_loss = c_out.mean()
     r_loss = region_loss(cmap, 1 - region, 'mse')
@@ -147,7 +156,7 @@ def wsss_adversarial_step(netS, netD, netG, crit, optS, optD, x, y, x_nc, y_nc, 
         generator_loss, ssim_loss, perception_loss = crit(y, y_fake, cmap)
     else:
         generator_loss = ssim_loss = perception_loss = torch.zeros((), device=x.device)
-    g_loss = generator_loss + perception_weight * perception_loss + ssim_weight * ssim_loss
+    g_loss = generator_loss + perception_weight * perception_loss + _weighted(ssim_weight, ssim_loss, literal)
     l1_loss = torch.mean(abs(cmap))
     s_d_loss = c_out.mean()
     s_loss = d_weight * s_d_loss + l1_weight * l1_loss + g_weight * g_loss + nc_weight * nc_loss
