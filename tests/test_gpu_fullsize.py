@@ -242,3 +242,42 @@ def test_generator_inference_path_vs_oracle(size, N):
     assert (got2.cpu() - ref2).abs().max().item() <= 1e-4 * max(ref2.abs().max().item(), 1.0)
     net.train(); net.eval()
     assert '_fcd_folded' not in net.__dict__
+
+
+@pytest.mark.parametrize('literal', [False, True])
+def test_rsss_step_full_size_vs_oracle(literal):
+    """One Demo_RSSS adversarial iteration at the headline tile size (13 bands, 256 x 256, 2 tile pairs;
+    the library's default layer plan, i.e. Winograd F(4x4,3x3) on the wide layers) against the CPU oracle
+    step: every logged loss, the change-density map (1e-4, north_star) and the thresholded map."""
+    import warnings
+    from oracle import steps as osteps
+    p = pkg()
+    C, N, H = 13, 2, 256
+    sdG = seeded_state(onets.generator_spec(C), 11)
+    sdS = seeded_state(onets.segmentor_spec(C, 1, True), 12)
+    sdD = seeded_state(onets.discriminator_spec(C), 13)
+    sdV = seeded_state(onets.vgg_spec(), 4242)
+    netG, netS, netD = p.Module.Generator(C), p.Module.Segmentor(C, 1, True), p.Module.Discriminator_SRGAN_simple(C)
+    netG.load_state_dict(sdG); netS.load_state_dict(sdS); netD.load_state_dict(sdD)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        crit = p.Loss.CGeneratorLoss(channel=C, perception_layer=1, perception_perBand=True)
+    crit.loss_perception.net.load_state_dict(sdV)
+    for m in (netG, netS, netD, crit):
+        m.to(DEV)
+    netS.train(); netD.train(); netG.eval()
+    oS, oD = p.optim.RMSprop(netS.parameters(), lr=5e-5), p.optim.RMSprop(netD.parameters(), lr=5e-5)
+    x, y, region = seeded_tiles(21, N, C, H, H)
+    r = p.steps.rsss_adversarial_step(netS, netD, netG, crit, oS, oD, x.to(DEV), y.to(DEV), region.to(DEV),
+                                      literal=literal)
+    n = osteps.Nets(sdG, sdS, sdD, sdV).make_optimizers('rsss')
+    ro = osteps.rsss_adversarial_step(n, x, y, region)
+    got = [float(r[k]) for k in ('d_loss', 's_loss', 's_d_loss', 'g_loss', 'l1_loss', 'r_loss', 'generator_loss',
+                                 'ssim_loss', 'perception_loss')]
+    ref = [float(ro[k]) for k in ('d_loss', 's_loss', 's_d_loss', 'g_loss', 'l1_loss', 'r_loss', 'gen', 'ssim', 'perc')]
+    np.testing.assert_allclose(got, ref, rtol=5e-4, atol=1e-6)
+    cm, cmo = r['cmap'].detach().cpu(), ro['cmap'].detach()
+    err = (cm - cmo).abs().max().item()
+    assert err <= 1e-4, 'density map L_inf %.2e' % err
+    safe = (cmo - 0.5).abs() > 2e-4
+    assert torch.equal((cm > 0.5)[safe], (cmo > 0.5)[safe])
