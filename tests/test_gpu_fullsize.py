@@ -244,7 +244,7 @@ def test_generator_inference_path_vs_oracle(size, N):
     assert '_fcd_folded' not in net.__dict__
 
 
-@pytest.mark.parametrize('literal', [False, True])
+@pytest.mark.parametrize('literal', [False])      # literal mode is covered at the fixture sizes (test_gpu_modules.py)
 def test_rsss_step_full_size_vs_oracle(literal):
     """One Demo_RSSS adversarial iteration at the headline tile size (13 bands, 256 x 256, 2 tile pairs;
     the library's default layer plan, i.e. Winograd F(4x4,3x3) on the wide layers) against the CPU oracle
