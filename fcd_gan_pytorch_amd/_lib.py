@@ -52,6 +52,9 @@ _SIGS = {
     'fcd_conv_pack_weights': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'fcd_conv2d_fwd': (c_int, [POINTER(ConvDesc), P, P, P, P, c_int, P]),
     'fcd_conv2d_fwd_ex': (c_int, [POINTER(ConvDesc), P, P, P, P, c_int, P, c_float, P, P]),
+    'fcd_conv2d_relu_bits_bytes': (c_size_t, [POINTER(ConvDesc)]),
+    'fcd_conv2d_fwd_relu_bits': (c_int, [POINTER(ConvDesc), P, P, P, P, P, P]),
+    'fcd_conv2d_bwd_data_bits': (c_int, [POINTER(ConvDesc), P, P, P, P, P]),
     'fcd_conv_wino_plan': (c_int, [POINTER(ConvDesc), c_int]),
     'fcd_conv_wino_set': (c_int, [c_int]),
     'fcd_conv_wino_ws_bytes': (c_size_t, [POINTER(ConvDesc), c_int]),

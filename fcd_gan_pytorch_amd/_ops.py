@@ -132,22 +132,34 @@ class _Conv2d(torch.autograd.Function):
         d = _desc(x.shape, weight.shape, stride, pad)
         y = torch.empty((d.N, d.K, d.P, d.Q), dtype=torch.float32, device=x.device)
         b = _dev(bias, 'conv bias') if bias is not None else None
-        _fwd_conv(d, x, weight, b, y, relu)
+        bits = None
+        if relu and not weight.requires_grad:
+            nb = lib.fcd_conv2d_relu_bits_bytes(ctypes.byref(d))
+            if nb:      # thin-channel frozen layer: the backward mask is kept as 4 bits per strip, not as y
+                bits = torch.empty(nb, dtype=torch.uint8, device=x.device)
+                check(lib.fcd_conv2d_fwd_relu_bits(ctypes.byref(d), _p(x), _p(packed_weight(weight, 0)), _p(b), _p(y),
+                                                   _p(bits), _stream()), 'fcd_conv2d_fwd_relu_bits')
+        if bits is None:
+            _fwd_conv(d, x, weight, b, y, relu)
         # x is only needed for the weight gradient; the fused-ReLU output doubles as the backward mask
-        ctx.save_for_backward(x if weight.requires_grad else None, weight, y if relu else None)
+        ctx.save_for_backward(x if weight.requires_grad else None, weight, (y if relu and bits is None else None), bits)
         ctx.geom = (stride, pad, bias is not None, tuple(x.shape))
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight, yrelu = ctx.saved_tensors
+        x, weight, yrelu, bits = ctx.saved_tensors
         stride, pad, has_bias, xshape = ctx.geom
         dy = _dev(dy, 'conv grad')
         d = _desc(xshape, weight.shape, stride, pad)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(xshape, dtype=torch.float32, device=dy.device)
-            _bwd_data_conv(d, dy, weight, dx, yrelu=yrelu)
+            if bits is not None:
+                check(lib.fcd_conv2d_bwd_data_bits(ctypes.byref(d), _p(dy), _p(bits), _p(packed_weight(weight, 1)), _p(dx),
+                                                   _stream()), 'fcd_conv2d_bwd_data_bits')
+            else:
+                _bwd_data_conv(d, dy, weight, dx, yrelu=yrelu)
         want_db = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             dw = torch.empty(weight.shape, dtype=torch.float32, device=dy.device)

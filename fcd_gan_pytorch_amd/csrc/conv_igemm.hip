@@ -21,9 +21,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 int fcd_try_dgrad_thin(const fcd_conv_desc* d, const float* dy, const float* relu_out, const float* wp_bwd, float* dx,
-                       hipStream_t st);  // conv_thin.hip
+                       hipStream_t st, int mask_is_bits);  // conv_thin.hip
 int fcd_try_fwd_thin(const fcd_conv_desc* d, const float* x, const float* wp, const float* bias, float* y, int relu,
-                     hipStream_t st);    // conv_thin.hip
+                     hipStream_t st, unsigned char* bits);    // conv_thin.hip
 
 // FCD_EXP: diagnostic builds only (results are wrong when set): 1 = no patch loads/stores in the
 // loop, 2 = no filter DMA in the loop, 4 = no barrier in the loop, 8 = operands from registers,
@@ -824,7 +824,7 @@ extern "C" int fcd_conv2d_fwd_ex(const fcd_conv_desc* d, const float* x, const f
                               (double)d->K * d->C * d->R * d->S);
   FcdProfScope prof(FCD_K_CONV_FWD, (hipStream_t)stream, flops, bytes);
   if (!a.act_slope && !residual && thin_fwd_on() &&
-      fcd_try_fwd_thin(d, x, wp, bias, y, a.relu, (hipStream_t)stream) == 0) {   // <= 4 input channels: VALU kernel
+      fcd_try_fwd_thin(d, x, wp, bias, y, a.relu, (hipStream_t)stream, nullptr) == 0) {   // <= 4 input channels: VALU kernel
     FCD_LAUNCH_CHECK("conv2d_fwd(thin)");
     return FCD_OK;
   }
@@ -850,13 +850,54 @@ extern "C" int fcd_conv2d_bwd_data(const fcd_conv_desc* d, const float* dy, cons
   const double bytes = 4.0 * ((double)d->N * d->C * d->H * d->W + (double)d->N * d->K * d->P * d->Q +
                               (double)d->K * d->C * d->R * d->S);
   FcdProfScope prof(FCD_K_CONV_DGRAD, (hipStream_t)stream, flops, bytes);
-  if (fcd_try_dgrad_thin(d, dy, relu_out, wp_bwd, dx, (hipStream_t)stream) == 0) {   // <= 4 input channels: VALU kernel
+  if (fcd_try_dgrad_thin(d, dy, relu_out, wp_bwd, dx, (hipStream_t)stream, 0) == 0) {   // <= 4 input channels: VALU kernel
     FCD_LAUNCH_CHECK("conv2d_bwd_data(thin)");
     return FCD_OK;
   }
   rc = conv_dispatch(a, d->R, d->S, 1, d->stride, (hipStream_t)stream);
   FCD_CHECK_ARG(rc == 0, "fcd_conv2d_bwd_data: unsupported filter %dx%d stride %d", d->R, d->S, d->stride);
   FCD_LAUNCH_CHECK("conv2d_bwd_data");
+  return FCD_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Thin-channel layers (<= 4 input channels, e.g. VGG conv1_1 on single bands): fused-ReLU forward that also
+// writes the ReLU mask as 4 bits per 1 x 4 pixel strip, and the data gradient that consumes it -- the fp32
+// activation then need not be kept (or re-read) for the backward pass.
+extern "C" size_t fcd_conv2d_relu_bits_bytes(const fcd_conv_desc* d) {
+  if (!d || !(d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1 && d->C >= 1 && d->C <= 4 && d->K > 32 &&
+              (d->W & 3) == 0 && (d->K % 8) == 0))
+    return 0;
+  return (size_t)d->N * d->K * d->H * (d->W >> 2);
+}
+
+extern "C" int fcd_conv2d_fwd_relu_bits(const fcd_conv_desc* d, const float* x, const float* wp, const float* bias,
+                                        float* y, unsigned char* bits, void* stream) {
+  int rc = check_desc(d, "fcd_conv2d_fwd_relu_bits");
+  if (rc) return rc;
+  FCD_CHECK_ARG(x && wp && y && bits, "fcd_conv2d_fwd_relu_bits: null pointer");
+  FCD_CHECK_ARG(fcd_conv2d_relu_bits_bytes(d) > 0, "fcd_conv2d_fwd_relu_bits: layer has no bit-mask path");
+  const double flops = 2.0 * d->N * d->K * (double)d->P * d->Q * d->C * 9;
+  FcdProfScope prof(FCD_K_CONV_FWD, (hipStream_t)stream, flops,
+                    4.0 * ((double)d->N * d->C * d->H * d->W + 1.0625 * d->N * d->K * (double)d->P * d->Q));
+  FCD_CHECK_ARG(fcd_try_fwd_thin(d, x, wp, bias, y, 1, (hipStream_t)stream, bits) == 0,
+                "fcd_conv2d_fwd_relu_bits: unsupported shape");
+  FCD_LAUNCH_CHECK("conv2d_fwd_relu_bits");
+  return FCD_OK;
+}
+
+extern "C" int fcd_conv2d_bwd_data_bits(const fcd_conv_desc* d, const float* dy, const unsigned char* bits,
+                                        const float* wp_bwd, float* dx, void* stream) {
+  int rc = check_desc(d, "fcd_conv2d_bwd_data_bits");
+  if (rc) return rc;
+  FCD_CHECK_ARG(dy && bits && wp_bwd && dx, "fcd_conv2d_bwd_data_bits: null pointer");
+  FCD_CHECK_ARG(fcd_conv2d_relu_bits_bytes(d) > 0, "fcd_conv2d_bwd_data_bits: layer has no bit-mask path");
+  const double flops = 2.0 * d->N * d->K * (double)d->P * d->Q * d->C * 9;
+  FcdProfScope prof(FCD_K_CONV_DGRAD, (hipStream_t)stream, flops,
+                    4.0 * ((double)d->N * d->C * d->H * d->W + 1.0625 * d->N * d->K * (double)d->P * d->Q));
+  FCD_CHECK_ARG(fcd_try_dgrad_thin(d, dy, (const float*)bits, wp_bwd, dx, (hipStream_t)stream, 1) == 0,
+                "fcd_conv2d_bwd_data_bits: unsupported shape");
+  FCD_LAUNCH_CHECK("conv2d_bwd_data_bits");
   return FCD_OK;
 }
 

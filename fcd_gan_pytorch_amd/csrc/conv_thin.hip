@@ -95,7 +95,9 @@ __global__ __launch_bounds__(256) void conv3x3_dgrad_thin_kernel(const float* __
 // they are stored to LDS after the compute block).
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
-template <int CS>
+// BITS: the ReLU mask arrives as one byte per 1 x 4 pixel strip (bit j = [relu_out > 0] of pixel 4 s + j, written
+// by conv3x3_fwd_thin_kernel) instead of the fp32 activation: 1/16 of the mask traffic.
+template <int CS, bool BITS>
 __global__ __launch_bounds__(256) void conv3x3_dgrad_thin_v4_kernel(const float* __restrict__ dy,
                                                                     const float* __restrict__ mask,
                                                                     const float* __restrict__ wf, float* __restrict__ dx,
@@ -145,7 +147,9 @@ __global__ __launch_bounds__(256) void conv3x3_dgrad_thin_v4_kernel(const float*
   const size_t img = (size_t)n * K * H * W;
   const size_t plane_chunk = (size_t)TH_KC * H * W;
   f32x4_t dv[NV], mv[NV];
+  unsigned mb[NV];                 // BITS: mask byte of the strip
   float ds_[2], ms_[2];
+  const unsigned char* mbits = (const unsigned char*)mask;
 
 #define THIN_LOAD(K0)                                                                     \
   {                                                                                       \
@@ -155,12 +159,16 @@ __global__ __launch_bounds__(256) void conv3x3_dgrad_thin_v4_kernel(const float*
     _Pragma("unroll") for (int i = 0; i < NV; ++i) {                                      \
       const int off = v_kk[i] < kleft ? v_goff[i] : 0;                                    \
       dv[i] = *(const f32x4_t*)(dsrc + off);                                              \
-      if (has_mask) mv[i] = *(const f32x4_t*)(msrc + off);                                \
+      if (BITS) mb[i] = mbits[(img + (size_t)((K0) / TH_KC) * plane_chunk + off) >> 2];   \
+      else if (has_mask) mv[i] = *(const f32x4_t*)(msrc + off);                           \
     }                                                                                     \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                       \
       const int off = s_kk[i] < kleft ? s_goff[i] : 0;                                    \
       ds_[i] = dsrc[off];                                                                 \
-      if (has_mask) ms_[i] = msrc[off];                                                   \
+      if (BITS) {                                                                         \
+        const size_t e = img + (size_t)((K0) / TH_KC) * plane_chunk + off;                \
+        ms_[i] = ((mbits[e >> 2] >> (e & 3)) & 1u) ? 1.f : 0.f;                           \
+      } else if (has_mask) ms_[i] = msrc[off];                                            \
     }                                                                                     \
   }
 #define THIN_STORE(K0)                                                                    \
@@ -169,7 +177,7 @@ __global__ __launch_bounds__(256) void conv3x3_dgrad_thin_v4_kernel(const float*
     _Pragma("unroll") for (int i = 0; i < NV; ++i) {                                      \
       const bool ok = v_kk[i] < kleft;                                                    \
       _Pragma("unroll") for (int j = 0; j < 4; ++j)                                       \
-        tile[v_loff[i] + j] = (ok && (!has_mask || mv[i][j] > 0.f)) ? dv[i][j] : 0.f;     \
+        tile[v_loff[i] + j] = (ok && (BITS ? ((mb[i] >> j) & 1u) != 0u : (!has_mask || mv[i][j] > 0.f))) ? dv[i][j] : 0.f; \
     }                                                                                     \
     _Pragma("unroll") for (int i = 0; i < 2; ++i)                                         \
       if (s_loff[i] >= 0)                                                                 \
@@ -233,7 +241,8 @@ __global__ __launch_bounds__(256) void conv3x3_dgrad_thin_v4_kernel(const float*
 template <int CS>
 __global__ __launch_bounds__(256) void conv3x3_fwd_thin_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                                const float* __restrict__ bias, float* __restrict__ y,
-                                                               int K, int Mpad, int H, int W, int tiles_w, int relu) {
+                                                               int K, int Mpad, int H, int W, int tiles_w, int relu,
+                                                               unsigned char* __restrict__ bits) {
   __shared__ float tile[CS * TH_PH * TH_PWP];
   const int tid = threadIdx.x;
   const int n = blockIdx.y;
@@ -282,6 +291,9 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_thin_kernel(const float* __re
     }
     if (row_ok) {
       float* o = yrow + (size_t)k * H * W;
+      if (bits != nullptr)        // W % 4 == 0: element index / 4 = strip index
+        bits[(((size_t)n * K + k) * H + h) * (W >> 2) + ((w0 + col) >> 2)] =
+            (unsigned char)((a4[0] > 0.f) | ((a4[1] > 0.f) << 1) | ((a4[2] > 0.f) << 2) | ((a4[3] > 0.f) << 3));
       if (vec_ok) {
         f32x4_t v = {a4[0], a4[1], a4[2], a4[3]};
         *(f32x4_t*)o = v;
@@ -296,7 +308,7 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_thin_kernel(const float* __re
 
 // returns 0 when handled, 1 when the shape is not a thin-channel case
 int fcd_try_dgrad_thin(const fcd_conv_desc* d, const float* dy, const float* relu_out, const float* wp_bwd, float* dx,
-                       hipStream_t st) {
+                       hipStream_t st, int mask_is_bits) {
   if (!(d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1 && d->C >= 1 && d->C <= 4)) return 1;
   const int tiles_w = cdiv(d->W, TH_COLS), tiles_h = cdiv(d->H, TH_ROWS);
   const int Cpad = round_up(d->C, 128);
@@ -304,14 +316,18 @@ int fcd_try_dgrad_thin(const fcd_conv_desc* d, const float* dy, const float* rel
 #define THIN_LAUNCH(KERNEL, CS_)                                                                              \
   hipLaunchKernelGGL(KERNEL<CS_>, grid, dim3(256), 0, st, dy, relu_out, wp_bwd, dx, d->K, d->H, d->W, Cpad, tiles_w)
   if ((d->W & 3) == 0 && (d->K % TH_KC) == 0) {     // float4 rows, whole 8-channel chunks
+#define THIN_V4(CS_, B_) \
+  hipLaunchKernelGGL((conv3x3_dgrad_thin_v4_kernel<CS_, B_>), grid, dim3(256), 0, st, dy, relu_out, wp_bwd, dx, d->K, d->H, d->W, Cpad, tiles_w)
     switch (d->C) {
-      case 1: THIN_LAUNCH(conv3x3_dgrad_thin_v4_kernel, 1); break;
-      case 2: THIN_LAUNCH(conv3x3_dgrad_thin_v4_kernel, 2); break;
-      case 3: THIN_LAUNCH(conv3x3_dgrad_thin_v4_kernel, 3); break;
-      default: THIN_LAUNCH(conv3x3_dgrad_thin_v4_kernel, 4); break;
+      case 1: if (mask_is_bits) THIN_V4(1, true); else THIN_V4(1, false); break;
+      case 2: if (mask_is_bits) THIN_V4(2, true); else THIN_V4(2, false); break;
+      case 3: if (mask_is_bits) THIN_V4(3, true); else THIN_V4(3, false); break;
+      default: if (mask_is_bits) THIN_V4(4, true); else THIN_V4(4, false); break;
     }
+#undef THIN_V4
     return 0;
   }
+  if (mask_is_bits) return 1;      // bit masks only exist for the float4 configuration
   switch (d->C) {
     case 1: THIN_LAUNCH(conv3x3_dgrad_thin_kernel, 1); break;
     case 2: THIN_LAUNCH(conv3x3_dgrad_thin_kernel, 2); break;
@@ -323,15 +339,18 @@ int fcd_try_dgrad_thin(const fcd_conv_desc* d, const float* dy, const float* rel
 }
 
 // returns 0 when handled, 1 when the shape / epilogue is not covered by the thin forward kernel
+// bits != NULL: additionally write the ReLU bit mask (needs W % 4 == 0 and K % 8 == 0, the configuration the
+// float4 data-gradient kernel consumes)
 int fcd_try_fwd_thin(const fcd_conv_desc* d, const float* x, const float* wp, const float* bias, float* y, int relu,
-                     hipStream_t st) {
+                     hipStream_t st, unsigned char* bits) {
+  if (bits && ((d->W & 3) != 0 || (d->K % TH_KC) != 0)) return 1;
   if (!(d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1 && d->C >= 1 && d->C <= 4 && d->K > 32)) return 1;
   const int tiles_w = cdiv(d->W, TH_COLS), tiles_h = cdiv(d->H, TH_ROWS);
   const int Mpad = round_up(d->K, 128);
   dim3 grid((unsigned)(tiles_w * tiles_h), (unsigned)d->N);
 #define THIN_LAUNCH(CS_)                                                                                       \
   hipLaunchKernelGGL(conv3x3_fwd_thin_kernel<CS_>, grid, dim3(256), 0, st, x, wp, bias, y, d->K, Mpad, d->H, d->W, \
-                     tiles_w, relu)
+                     tiles_w, relu, bits)
   switch (d->C) {
     case 1: THIN_LAUNCH(1); break;
     case 2: THIN_LAUNCH(2); break;

@@ -71,6 +71,15 @@ int fcd_conv2d_fwd(const fcd_conv_desc* d, const float* x, const float* wp, cons
 int fcd_conv2d_fwd_ex(const fcd_conv_desc* d, const float* x, const float* wp, const float* bias,
                       float* y, int act, const float* slope_ptr, float slope_imm,
                       const float* residual, void* stream);
+/* Thin-channel 3x3 layers (<= 4 input channels, > 32 output channels, W % 4 == 0, K % 8 == 0; VGG conv1_1 on
+ * single bands, Loss.py:52-58): fused-ReLU forward that also writes the ReLU mask as 4 bits per 1 x 4 pixel
+ * strip (fcd_conv2d_relu_bits_bytes() bytes; 0 = the layer has no such path), and the data gradient that
+ * consumes the bits instead of the fp32 activation. */
+size_t fcd_conv2d_relu_bits_bytes(const fcd_conv_desc* d);
+int fcd_conv2d_fwd_relu_bits(const fcd_conv_desc* d, const float* x, const float* wp, const float* bias,
+                             float* y, unsigned char* bits, void* stream);
+int fcd_conv2d_bwd_data_bits(const fcd_conv_desc* d, const float* dy, const unsigned char* bits,
+                             const float* wp_bwd, float* dx, void* stream);
 /* ---- Winograd F(m x m, 3 x 3) path for wide 3x3 / stride-1 / pad-1 layers (m = 2 or 4) ------------
  * fcd_conv_wino_plan(): tile size the library uses for this layer and direction (mode 0 forward,
  * 1 data gradient), 0 = the layer runs on the direct kernels (then none of the *_wino calls apply).

@@ -404,3 +404,31 @@ def test_conv_winograd_matches_direct_kernels():
     sc = outs[0].abs().max().item()
     assert (outs[2] - outs[0]).abs().max().item() <= 5e-6 * sc
     assert (outs[4] - outs[0]).abs().max().item() <= 6e-5 * sc
+
+
+@pytest.mark.parametrize('case', [(2, 1, 36, 68, 64), (1, 3, 17, 132, 72), (3, 4, 16, 64, 40), (2, 1, 21, 30, 64)],
+                         ids=lambda c: 'x'.join(map(str, c)))
+def test_thin_conv_relu_bitmask_path(case):
+    """Frozen thin-channel layer (VGG conv1_1 on single bands): conv + bias + ReLU whose backward mask is kept as
+    4 bits per 1 x 4 strip (`fcd_conv2d_fwd_relu_bits` / `_bwd_data_bits`; W % 4 == 0 and K % 8 == 0, else the
+    fp32-mask path) vs the ATen composition."""
+    import ctypes
+    ops = _ops()
+    N, C, H, W, K = case
+    x = rnd(N, C, H, W, seed=201)
+    w = rnd(K, C, 3, 3, seed=202, scale=(2.0 / (C * 9)) ** 0.5)
+    b = rnd(K, seed=203, scale=0.1)
+    g = rnd(N, K, H, W, seed=204)
+    xr = x.clone().requires_grad_(True)
+    yr = F.relu(F.conv2d(xr, w, b, padding=1))
+    yr.backward(g)
+    xg = x.cuda().requires_grad_(True)
+    d = ops._desc(x.shape, w.shape, 1, 1)
+    expect_bits = W % 4 == 0 and K % 8 == 0
+    assert (ops.lib.fcd_conv2d_relu_bits_bytes(ctypes.byref(d)) > 0) == expect_bits
+    y = ops.conv2d(xg, w.cuda(), b.cuda(), 1, 1, relu=True)          # frozen filter => bit-mask path when available
+    y.backward(g.cuda())
+    assert_close(y, yr, what='y')
+    dd = xg.grad.cpu().double() - xr.grad.double()
+    assert (dd.norm() / xr.grad.double().norm()).item() < 1e-4, 'dx'       # kink flips only
+    assert (dd.abs() > 1e-4 * xr.grad.abs().max().item()).double().mean().item() < 2e-3
