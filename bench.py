@@ -55,9 +55,9 @@ def build_workload(args, dev, rank):
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
         if args.workload == 'usss_g':
-            crit = fcd.Loss.CNetLoss(channel=C, perception_layer=1, perception_perBand=True)      # Demo_USSS.py:116
+            crit = fcd.Loss.CNetLoss(channel=C, perception_layer=1, perception_perBand=True, allow_seeded=True)      # Demo_USSS.py:116
         else:
-            crit = fcd.Loss.CGeneratorLoss(channel=C, perception_layer=1, perception_perBand=args.workload == 'rsss')
+            crit = fcd.Loss.CGeneratorLoss(channel=C, perception_layer=1, perception_perBand=args.workload == 'rsss', allow_seeded=True)
     for m in (netD, netS, netG, crit):
         m.to(dev)
     multi = dist.is_initialized() and dist.get_world_size() > 1
@@ -100,6 +100,84 @@ def build_workload(args, dev, rank):
     return step
 
 
+def write_layer_tables(path, detail, psteps, args):
+    """Per-layer tables of the profiled pass (one row per distinct launch geometry): avg launch time, achieved
+    TFLOP/s (or GB/s) against the fp32 MFMA peak, and for the Winograd GEMM the workgroup count / chip fill."""
+    import re
+    from collections import OrderedDict
+    groups = OrderedDict()
+    for e in detail:
+        g = groups.setdefault((e['family'], e['tag']), dict(n=0, ms=0.0, flops=0.0, bytes=0.0))
+        g['n'] += 1; g['ms'] += e['ms']; g['flops'] += e['flops']; g['bytes'] += e['bytes']
+
+    def rows(fam):
+        out = [(tag, g) for (f, tag), g in groups.items() if f == fam]
+        out.sort(key=lambda r: -r[1]['ms'])
+        return out
+
+    L = ['# Per-layer launch table (bench.py --layers-md, %s workload, %d tile pairs/GPU, %d bands %dx%d, %d profiled step(s))'
+         % (args.workload, args.batch, args.bands, args.size, args.size, psteps), '',
+         'HIP events around every launch on its stream; fp32 MFMA peak %.1f TFLOP/s.  "/step" = launches per step.' % PEAK_F32_MFMA_TFLOPS, '']
+    L += ['## wino_gemm_kernel (executed GEMM FLOPs = 2 x batch x M x N x Kc)', '',
+          '| launch | /step | avg us | ms/step | GFLOP | TFLOP/s | of peak | workgroups | resident slots filled |',
+          '|---|---|---|---|---|---|---|---|---|']
+    tot_ms = tot_fl = 0.0
+    for tag, g in rows('wino_gemm'):
+        m = re.search(r'M=(\d+) N=(\d+) Kc=(\d+) batch=(\d+)(?: splits=(\d+))?', tag)
+        M, N, Kc, B = (int(v) for v in m.groups()[:4])
+        splits = int(m.group(5) or 1)
+        if M <= 64:
+            wgs, per_cu = ((N + 255) // 256) * B * splits, 2
+        else:
+            wgs, per_cu = ((M + 127) // 128) * ((N + 127) // 128) * B * splits, 2
+        waves = wgs / float(256 * per_cu)
+        fill = wgs / (256.0 * per_cu * max(1, -(-wgs // (256 * per_cu))))       # average occupancy of the slot waves
+        us = 1e3 * g['ms'] / g['n']
+        tf = g['flops'] / (g['ms'] * 1e-3) / 1e12 if g['ms'] > 0 else 0.0
+        tot_ms += g['ms']; tot_fl += g['flops']
+        L.append('| %s | %.1f | %.1f | %.3f | %.2f | %.1f | %.2f | %d | %.2f waves, %.0f%% |' % (
+            tag, g['n'] / float(psteps), us, g['ms'] / psteps, g['flops'] / g['n'] / 1e9, tf, tf / PEAK_F32_MFMA_TFLOPS, wgs,
+            waves, 100 * fill))
+    if tot_ms > 0:
+        L += ['', 'all launches: %.2f ms/step, %.1f TFLOP/s = %.3f of peak' % (
+            tot_ms / psteps, tot_fl / (tot_ms * 1e-3) / 1e12, tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS)]
+    for fam, title in (('conv_igemm_fwd', 'direct convolution, forward (algorithmic FLOPs)'),
+                       ('conv_igemm_dgrad', 'direct convolution, data gradient (algorithmic FLOPs)'),
+                       ('conv_wgrad', 'weight gradient, whole call incl. re-layout / transforms / reduce (algorithmic FLOPs, direct count)'),
+                       ('conv_wino_fwd', 'Winograd layer calls, forward: three kernels (algorithmic conv FLOPs)'),
+                       ('conv_wino_dgrad', 'Winograd layer calls, data gradient: three kernels (algorithmic conv FLOPs)')):
+        rr = rows(fam)
+        if not rr:
+            continue
+        L += ['', '## %s' % title, '', '| launch | /step | avg us | ms/step | GFLOP | TFLOP/s | of peak | GB/s (algorithmic bytes) |',
+              '|---|---|---|---|---|---|---|---|']
+        tms = tfl = 0.0
+        for tag, g in rr:
+            us = 1e3 * g['ms'] / g['n']
+            tf = g['flops'] / (g['ms'] * 1e-3) / 1e12 if g['ms'] > 0 else 0.0
+            gb = g['bytes'] / (g['ms'] * 1e-3) / 1e9 if g['ms'] > 0 else 0.0
+            tms += g['ms']; tfl += g['flops']
+            L.append('| %s | %.1f | %.1f | %.3f | %.2f | %.1f | %.2f | %.0f |' % (
+                tag, g['n'] / float(psteps), us, g['ms'] / psteps, g['flops'] / g['n'] / 1e9, tf, tf / PEAK_F32_MFMA_TFLOPS, gb))
+        L += ['', 'all launches: %.2f ms/step, %.1f TFLOP/s = %.3f of peak' % (
+            tms / psteps, tfl / (tms * 1e-3) / 1e12, tfl / (tms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS)]
+    rr = rows('wino_transform')
+    if rr:
+        L += ['', '## Winograd transform kernels (bytes each pass streams)', '', '| launch | /step | avg us | ms/step | MB | GB/s | of 8 TB/s |',
+              '|---|---|---|---|---|---|---|']
+        tms = tby = 0.0
+        for tag, g in rr:
+            us = 1e3 * g['ms'] / g['n']
+            gb = g['bytes'] / (g['ms'] * 1e-3) / 1e9 if g['ms'] > 0 else 0.0
+            tms += g['ms']; tby += g['bytes']
+            L.append('| %s | %.1f | %.1f | %.3f | %.1f | %.0f | %.2f |' % (tag, g['n'] / float(psteps), us, g['ms'] / psteps,
+                                                                     g['bytes'] / g['n'] / 1e6, gb, gb / 8000.0))
+        L += ['', 'all launches: %.2f ms/step, %.1f GB/step, %.0f GB/s' % (tms / psteps, tby / psteps / 1e9, tby / (tms * 1e-3) / 1e9)]
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    with open(path, 'w') as f:
+        f.write('\n'.join(L) + '\n')
+
+
 def effective_cores():
     """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota
     (the GPU box advertises 256 logical CPUs but the container is quota-limited)."""
@@ -129,7 +207,7 @@ def cpu_baseline(args):
         sdD = fcd.Module.Discriminator_SRGAN_simple(C).state_dict()
         sdS = fcd.Module.Segmentor(C, bilinear=True).state_dict()
         sdG = fcd.Module.Generator(C).state_dict()
-        sdV = fcd.Loss.PerceptionLoss(1, True).net.state_dict()
+        sdV = fcd.Loss.PerceptionLoss(1, True, allow_seeded=True).net.state_dict()
     nets = osteps.Nets(sdG, sdS, sdD, sdV).make_optimizers('rsss')
     x, y, region = synthetic_tiles(1234, n, C, H, W)
     osteps.rsss_adversarial_step(nets, x, y, region)            # warm-up (oneDNN primitive creation)
@@ -162,7 +240,9 @@ def main():
     ap.add_argument('--bands', type=int, default=None)
     ap.add_argument('--size', type=int, default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-prof', action='store_true', help='do not bracket launches with HIP events')
+    ap.add_argument('--no-prof', action='store_true', help='skip the second (profiled) pass')
+    ap.add_argument('--prof-steps', type=int, default=3, help='steps of the profiled pass (HIP events around every launch)')
+    ap.add_argument('--layers-md', default=None, help='write per-layer tables of the profiled pass to this markdown file')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend: 'nccl' (= RCCL over xGMI); "
                     "'gloo' only for functional tests of the multi-rank path on a single-GPU box")
     args = ap.parse_args()
@@ -199,21 +279,34 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    if not args.no_prof:
-        _lib.prof_read(reset=True)
-        _lib.lib.fcd_prof_enable(1)
+    # ---- headline: K steps, NO per-launch events (the profiler is a separate pass below)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     barrier()
     dt = time.perf_counter() - t0
-    _lib.lib.fcd_prof_enable(0)
-    prof = _lib.prof_read(reset=True) if not args.no_prof else {}
     losses = {k: float(v) for k, v in out.items() if v.dim() == 0}
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # ---- profiled pass (not part of `value`): every launch bracketed by HIP events on its stream
+    prof, detail, dt_prof, psteps = {}, [], None, 0
+    if not args.no_prof:
+        psteps = max(1, min(args.steps, args.prof_steps))
+        _lib.prof_read(reset=True)
+        _lib.lib.fcd_prof_enable(2 if (args.layers_md and rank == 0) else 1)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(psteps):
+            step()
+        barrier()
+        dt_prof = time.perf_counter() - t1
+        _lib.lib.fcd_prof_enable(0)
+        prof = _lib.prof_read(reset=True)
+        detail = _lib.prof_detail(reset=True)
+        if args.layers_md and rank == 0:
+            write_layer_tables(args.layers_md, detail, psteps, args)
 
     if rank == 0:
         total_pairs = args.batch * n_gpus * args.steps
@@ -222,11 +315,14 @@ def main():
             'value': total_pairs / dt, 'unit': 'tile-pairs/s', 'n_gpus': n_gpus, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': '%s, %d bands %dx%d, random-init weights'
+            'config': {'workload': '%s, %d bands %dx%d, random-init weights, seeded (not ImageNet) VGG16 filters'
                                    % (wl_desc, args.bands, args.size, args.size),
                        'baseline_config': 'BASELINE.json configs[%d]' % WORKLOADS[args.workload][0],
                        'tile_pairs_per_gpu': args.batch, 'global_batch': args.batch * n_gpus,
-                       'parallelism': 'dp%d' % n_gpus, 'bn': 'per-replica statistics'},
+                       'parallelism': 'dp%d' % n_gpus, 'bn': 'per-replica statistics',
+                       'world_size': dist.get_world_size() if world > 1 else 1,
+                       'backend': (dist.get_backend() if world > 1 else 'none'),
+                       'grad_exchange': 'bucketed all-reduce overlapped with backward' if world > 1 else 'none (1 rank)'},
             'losses_last_step': losses,
         }
         if prof:
@@ -239,9 +335,9 @@ def main():
                 ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
                 return {'bound': 'mfma', 'kernel': name, 'flops_counted': what, 'achieved': ach,
                         'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS,
-                        'traffic': None, 'launches_per_step': launches / args.steps,
+                        'traffic': None, 'launches_per_step': launches / psteps,
                         'avg_launch_ms': ms / max(launches, 1), 'gflop_per_launch': flops / max(launches, 1) / 1e9,
-                        'share_of_step_time': ms / (1e3 * dt) if dt > 0 else None}
+                        'share_of_step_time': ms / (1e3 * dt_prof) if dt_prof else None}
             # the MFMA-bound kernels of the step, each priced on the FLOPs its launches really issue:
             #  * conv_igemm*: direct implicit-GEMM convolution -> algorithmic FLOPs 2 N K P Q C R S
             #  * wino_gemm: the batched GEMM of the Winograd path -> 2 (m+2)^2 rows Kc T (= the algorithmic conv
@@ -263,7 +359,7 @@ def main():
             # HBM bytes per launch of the direct-conv family from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate
             # rocprofv3 passes over this very command: tools/pmc_bench.sh); bench.py cannot run the profiler on itself,
             # so it reports the committed measurement of the family it belongs to.
-            tpath = os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')
+            tpath = os.path.join(ROOT, 'profiles', 'r02_hbm_traffic.json')
             if os.path.exists(tpath) and args.workload == 'rsss' and args.batch == 8 and args.bands == 13 and args.size == 256:
                 with open(tpath) as f:
                     tj = json.load(f)
@@ -271,7 +367,7 @@ def main():
                     key = 'wino_gemm' if e['kernel'].startswith('wino_gemm') else ('conv_igemm' if e['kernel'].startswith('conv_igemm') else None)
                     if key and key in tj:
                         e['traffic'] = tj[key]['hbm_bytes_per_launch']
-                        e['traffic_unit'] = 'HBM bytes per launch (PMC, profiles/r01_hbm_traffic.json)'
+                        e['traffic_unit'] = 'HBM bytes per launch (PMC FETCH_SIZE + WRITE_SIZE with the gfx950 corrections of MI355X_MICROARCH.md, profiles/r02_hbm_traffic.json)'
                         e['algorithmic_bytes_per_launch'] = tj[key].get('algorithmic_bytes_per_launch')
             if wf['launches'] + wd['launches'] > 0:
                 wms, wfl = wf['ms'] + wd['ms'], wf['flops'] + wd['flops']
@@ -282,22 +378,38 @@ def main():
                             'F(%dx%d, 3x3): input transform + batched fp32 MFMA GEMM + output transform (three kernels per '
                             'layer call); results equal the direct kernels within fp32 transform rounding (<= 2e-5 relative, '
                             'tests/test_gpu_ops.py)' % (mt, mt),
-                    'layer_calls_per_step': (wf['launches'] + wd['launches']) / args.steps, 'ms_per_step': wms / args.steps,
+                    'layer_calls_per_step': (wf['launches'] + wd['launches']) / psteps, 'ms_per_step': wms / psteps,
                     'algorithmic_conv_tflops': wfl / (wms * 1e-3) / 1e12,
-                    'gemm_ms_per_step': wgemm['ms'] / args.steps, 'transform_ms_per_step': wxf['ms'] / args.steps,
+                    'gemm_ms_per_step': wgemm['ms'] / psteps, 'transform_ms_per_step': wxf['ms'] / psteps,
                     'transform_gbps': wxf['bytes'] / (wxf['ms'] * 1e-3) / 1e9 if wxf['ms'] > 0 else None,
-                    'share_of_step_time': wms / (1e3 * dt),
+                    'share_of_step_time': wms / (1e3 * dt_prof),
                 }
                 dms, dfl = fwd['ms'] + dg['ms'], fwd['flops'] + dg['flops']
                 res['conv_fwd_dgrad_algorithmic_tflops'] = (dfl + wfl) / ((dms + wms) * 1e-3) / 1e12
             res['kernel_families'] = {
-                k: {'ms_per_step': v['ms'] / args.steps, 'launches_per_step': v['launches'] / args.steps,
+                k: {'ms_per_step': v['ms'] / psteps, 'launches_per_step': v['launches'] / psteps,
                     'tflops': (v['flops'] / (v['ms'] * 1e-3) / 1e12) if v['ms'] > 0 and v['flops'] > 0 else None,
                     'gbps': (v['bytes'] / (v['ms'] * 1e-3) / 1e9) if v['ms'] > 0 and v['bytes'] > 0 else None}
                 for k, v in prof.items() if v['launches'] > 0}
             for k in ('wino_gemm', 'wino_transform'):
                 if k in res['kernel_families']:
-                    res['kernel_families'][k]['nested_in'] = 'conv_wino_fwd + conv_wino_dgrad'
+                    res['kernel_families'][k]['nested_in'] = 'conv_wino_fwd + conv_wino_dgrad + conv_wgrad_wino'
+            if 'conv_wgrad_wino' in res['kernel_families']:
+                res['kernel_families']['conv_wgrad_wino']['nested_in'] = 'conv_wgrad'
+            # the whole step on both FLOP counts: algorithmic = direct-convolution FLOPs of every conv launch;
+            # executed = what the MFMA units are really asked to do (Winograd layers: the batched GEMM, 1/4 of the direct
+            # count + tile padding); both over the HEADLINE step time (events off)
+            wgw = prof.get('conv_wgrad_wino', zero)
+            alg = fwd['flops'] + dg['flops'] + wf['flops'] + wd['flops'] + wg['flops']
+            exe = fwd['flops'] + dg['flops'] + wgemm['flops'] + (wg['flops'] - wgw['flops'])
+            step_s = dt / args.steps
+            res['whole_step'] = {'algorithmic_tflops': alg / psteps / step_s / 1e12,
+                                 'executed_tflops': exe / psteps / step_s / 1e12,
+                                 'frac_executed': exe / psteps / step_s / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                 'algorithmic_tflop_per_step': alg / psteps / 1e12,
+                                 'profiled_ms_per_step': 1e3 * dt_prof / psteps,
+                                 'note': 'value / ms_per_step are timed with the per-launch events OFF; the roofline and '
+                                         'kernel_families numbers come from a second pass of %d step(s) with them on' % psteps}
         if n_gpus == 1 and not args.no_cpu_baseline and args.workload == 'rsss':
             res['cpu_baseline'] = cpu_baseline(args)
         print(json.dumps(res))

@@ -38,19 +38,48 @@ def _vgg16_features():
     return nn.Sequential(*layers)
 
 
-def _load_vgg_weights(net):
-    """The reference downloads torchvision's ImageNet checkpoint (Loss.py:25).  There
-    is no network here: point FCDGAN_VGG16_WEIGHTS at a torch-saved state_dict of
-    ``vgg16().features`` (keys '0.weight'... or 'features.0.weight'...).  Without it
-    the stack gets a fixed-seed He initialisation and a warning."""
+_HUB_FILE = 'vgg16-397923af.pth'      # torchvision's ImageNet checkpoint (the file vgg16(pretrained=True) caches)
+
+
+def _vgg_checkpoint_path():
+    """Where the ImageNet VGG16 weights can come from offline, in order: the file named by
+    FCDGAN_VGG16_WEIGHTS (a missing file is an error, not a fallback), then torchvision's hub cache
+    ($TORCH_HOME/hub/checkpoints, ~/.cache/torch/hub/checkpoints)."""
     path = os.environ.get('FCDGAN_VGG16_WEIGHTS', '')
-    if path and os.path.exists(path):
+    if path:
+        if not os.path.exists(path):
+            raise FileNotFoundError('FCDGAN_VGG16_WEIGHTS=%s does not exist' % path)
+        return path
+    roots = [os.path.join(os.environ['TORCH_HOME'], 'hub')] if os.environ.get('TORCH_HOME') else []
+    roots.append(os.path.join(os.path.expanduser('~'), '.cache', 'torch', 'hub'))
+    for r in roots:
+        cand = os.path.join(r, 'checkpoints', _HUB_FILE)
+        if os.path.exists(cand):
+            return cand
+    return None
+
+
+def _load_vgg_weights(net, allow_seeded):
+    """The reference downloads torchvision's ImageNet checkpoint (Loss.py:25).  There is no network
+    here: the weights come from FCDGAN_VGG16_WEIGHTS (a torch-saved state_dict of ``vgg16()`` or of
+    ``vgg16().features``: keys 'features.0.weight'... or '0.weight'...) or from torchvision's hub cache.
+    Without either the constructor RAISES -- a perception term on random filters is a different loss,
+    not a degraded one -- unless the caller passes ``allow_seeded=True`` (tests, benchmarks), which gives
+    the stack a fixed-seed He initialisation.  Returns True when ImageNet weights were loaded."""
+    path = _vgg_checkpoint_path()
+    if path:
         sd = torch.load(path, map_location='cpu')
         sd = {k.replace('features.', ''): v for k, v in sd.items() if 'classifier' not in k}
         net.load_state_dict(sd)
         return True
-    warnings.warn('PerceptionLoss: pretrained VGG16 weights unavailable offline (set FCDGAN_VGG16_WEIGHTS); '
-                  'using a fixed-seed He initialisation.')
+    if not allow_seeded:
+        raise RuntimeError(
+            'PerceptionLoss: the ImageNet VGG16 weights the reference uses (Loss.py:25, vgg16(pretrained=True)) are '
+            'not available offline.  Set FCDGAN_VGG16_WEIGHTS to a torch-saved state_dict of torchvision\'s vgg16 '
+            '(or place %s in the torch hub cache), or pass allow_seeded=True to run on fixed-seed random filters '
+            '(parity tests / benchmarks only: the loss value then differs from the reference\'s).' % _HUB_FILE)
+    warnings.warn('PerceptionLoss: allow_seeded=True -- VGG16 runs on a fixed-seed He initialisation, NOT on the '
+                  'ImageNet weights of the reference.')
     g = torch.Generator().manual_seed(16)
     with torch.no_grad():
         for m in net:
@@ -62,12 +91,13 @@ def _load_vgg_weights(net):
 
 
 class PerceptionLoss(nn.Module):
-    """VGG16 feature MSE -- reference Loss.py:17-61."""
+    """VGG16 feature MSE -- reference Loss.py:17-61.  ``allow_seeded`` (not in the reference): see
+    :func:`_load_vgg_weights`; ``self.pretrained`` tells which weights the stack carries."""
 
-    def __init__(self, feature_layer=1, perception_perBand=False):
+    def __init__(self, feature_layer=1, perception_perBand=False, allow_seeded=False):
         super(PerceptionLoss, self).__init__()
         vgg = _vgg16_features().eval()
-        self.pretrained = _load_vgg_weights(vgg)
+        self.pretrained = _load_vgg_weights(vgg, allow_seeded)
         for param in vgg.parameters():
             param.requires_grad = False
         self.net = vgg
@@ -161,11 +191,12 @@ class CNetLoss(nn.Module):
     """USSS criterion -- reference Loss.py:64-95.  Returns
     (generator_loss, l1_loss, perception_loss, ssim_loss)."""
 
-    def __init__(self, channel=4, perception_layer=1, perception_perBand=True):
+    def __init__(self, channel=4, perception_layer=1, perception_perBand=True, allow_seeded=False):
         super(CNetLoss, self).__init__()
         self.mse = nn.MSELoss()
         self.loss_generator = nn.L1Loss()
-        self.loss_perception = PerceptionLoss(feature_layer=perception_layer, perception_perBand=perception_perBand)
+        self.loss_perception = PerceptionLoss(feature_layer=perception_layer, perception_perBand=perception_perBand,
+                                              allow_seeded=allow_seeded)
         self.ssim = MS_SSIM(data_range=1.0, channel=channel)
 
     def forward(self, target_image, generate_image, cmap, generator_mask_switch=False):
@@ -186,11 +217,12 @@ class CGeneratorLoss(nn.Module):
     """WSSS / RSSS criterion -- reference Loss.py:100-124.  Returns
     (generator_loss, ssim_loss, perception_loss)."""
 
-    def __init__(self, channel=3, perception_layer=1, perception_perBand=False):
+    def __init__(self, channel=3, perception_layer=1, perception_perBand=False, allow_seeded=False):
         super(CGeneratorLoss, self).__init__()
         self.loss_generator = nn.MSELoss()
         self.ssim = MS_SSIM(data_range=1.0, channel=channel)
-        self.loss_perception = PerceptionLoss(feature_layer=perception_layer, perception_perBand=perception_perBand)
+        self.loss_perception = PerceptionLoss(feature_layer=perception_layer, perception_perBand=perception_perBand,
+                                              allow_seeded=allow_seeded)
 
     def forward(self, target_image, generate_image, cmap):
         C = target_image.shape[1]

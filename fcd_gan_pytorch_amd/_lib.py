@@ -97,6 +97,7 @@ _SIGS = {
     'fcd_rmsprop_step': (c_int, [P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, P]),
     'fcd_prof_enable': (None, [c_int]),
     'fcd_prof_families': (c_int, []),
+    'fcd_prof_detail_read': (c_int64, [c_char_p, c_int64, c_int]),
     'fcd_prof_read': (c_int, [POINTER(c_double), c_int]),
     'fcd_prof_family_name': (c_char_p, [c_int]),
 }
@@ -137,4 +138,17 @@ def prof_read(reset=True):
     for f in range(nf):
         out[lib.fcd_prof_family_name(f).decode()] = dict(ms=buf[f * 4], launches=int(buf[f * 4 + 1]),
                                                          flops=buf[f * 4 + 2], bytes=buf[f * 4 + 3])
+    return out
+
+
+def prof_detail(reset=True):
+    """Per-launch log of a profiled region (``lib.fcd_prof_enable(2)``; call :func:`prof_read` first):
+    list of dict(family, tag, ms, flops, bytes)."""
+    need = lib.fcd_prof_detail_read(None, 0, 0)
+    buf = ctypes.create_string_buffer(int(need))
+    lib.fcd_prof_detail_read(buf, need, 1 if reset else 0)
+    out = []
+    for line in buf.value.decode().splitlines():
+        fam, tag, ms, fl, by = line.split('\t')
+        out.append(dict(family=fam, tag=tag, ms=float(ms), flops=float(fl), bytes=float(by)))
     return out

@@ -325,7 +325,14 @@ class _BnAct(torch.autograd.Function):
                                      _p(running_mean), _p(running_var), float(momentum), float(eps), int(training),
                                      _p(save_mean), _p(save_invstd), act, _p(slope), float(slope_imm), _p(ws),
                                      ws.numel(), _stream()), 'fcd_bn_act_fwd')
-        ctx.save_for_backward(x, gamma, beta, slope, save_mean, save_invstd, running_mean, running_var)
+        if has_bn and training and running_mean is not None:
+            # the kernel moved the running statistics through raw pointers: bump their version counters so that
+            # an eval-mode backward over a graph that saved the OLD statistics raises instead of silently
+            # using the new ones (the train-mode backward does not read them, so they are not saved)
+            torch._C._increment_version([running_mean, running_var])
+        keep_running = has_bn and not training
+        ctx.save_for_backward(x, gamma, beta, slope, save_mean, save_invstd,
+                              running_mean if keep_running else None, running_var if keep_running else None)
         ctx.cfg = (bool(training), float(eps), groups, act, float(slope_imm), has_bn, world)
         return y
 

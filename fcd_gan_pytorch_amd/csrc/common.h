@@ -46,7 +46,8 @@ enum {
   FCD_K_WINO_DGRAD = 10,// ... used as data gradient
   FCD_K_WINO_GEMM = 11, // nested in 9/10: the batched MFMA GEMM alone (FLOPs = executed GEMM FLOPs)
   FCD_K_WINO_XFORM = 12,// nested in 9/10: input + output transform kernels (bytes streamed)
-  FCD_K_COUNT = 13
+  FCD_K_WGRAD_WINO = 13,// nested in 2: weight-gradient calls that take the Winograd form (FLOPs = direct count)
+  FCD_K_COUNT = 14
 };
 
 struct FcdProfScope {
@@ -54,9 +55,17 @@ struct FcdProfScope {
   hipStream_t st;
   hipEvent_t e0, e1;
   bool on;
-  FcdProfScope(int family, hipStream_t stream, double flops, double bytes);
+  int detail_idx;
+  // tag: optional per-launch label (layer geometry) kept when the detail log is on (fcd_prof_enable(2)); use
+  // fcd_prof_tagf() to format one only when somebody is listening
+  FcdProfScope(int family, hipStream_t stream, double flops, double bytes, const char* tag = nullptr);
   ~FcdProfScope();
 };
+// printf into a thread-local buffer when the per-launch detail log is on; returns NULL otherwise
+const char* fcd_prof_tagf(const char* fmt, ...);
+static inline const char* fcd_prof_tag_desc(const char* what, const fcd_conv_desc* d) {
+  return fcd_prof_tagf("%s N=%d C=%d H=%d W=%d K=%d R=%d s=%d", what, d->N, d->C, d->H, d->W, d->K, d->R, d->stride);
+}
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

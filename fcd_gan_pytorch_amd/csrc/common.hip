@@ -4,6 +4,7 @@
 #include <stdarg.h>
 
 #include <mutex>
+#include <string>
 #include <vector>
 
 static thread_local char g_err[512] = "";
@@ -23,15 +24,24 @@ namespace {
 struct Pending {
   int fam;
   hipEvent_t e0, e1;
+  int detail;   // index into g_detail, -1: none
+};
+struct Detail {
+  int fam;
+  std::string tag;
+  double flops, bytes, ms;
 };
 std::mutex g_mu;
 bool g_prof_on = false;
+bool g_detail_on = false;
+std::vector<Detail> g_detail;
 std::vector<Pending> g_pending;
 std::vector<hipEvent_t> g_free_events;
 double g_ms[FCD_K_COUNT], g_launches[FCD_K_COUNT], g_flops[FCD_K_COUNT], g_bytes[FCD_K_COUNT];
 const char* kNames[FCD_K_COUNT] = {"conv_igemm_fwd", "conv_igemm_dgrad", "conv_wgrad", "pack_weights",
                                    "norm_act",       "pool_resize",      "loss",       "optim",
-                                   "misc", "conv_wino_fwd", "conv_wino_dgrad", "wino_gemm", "wino_transform"};
+                                   "misc", "conv_wino_fwd", "conv_wino_dgrad", "wino_gemm", "wino_transform",
+                                   "conv_wgrad_wino"};
 
 hipEvent_t get_event() {
   if (!g_free_events.empty()) {
@@ -45,8 +55,18 @@ hipEvent_t get_event() {
 }
 }  // namespace
 
-FcdProfScope::FcdProfScope(int family, hipStream_t stream, double flops, double bytes)
-    : fam(family), st(stream), on(false) {
+const char* fcd_prof_tagf(const char* fmt, ...) {
+  if (!g_detail_on) return nullptr;
+  static thread_local char buf[192];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  return buf;
+}
+
+FcdProfScope::FcdProfScope(int family, hipStream_t stream, double flops, double bytes, const char* tag)
+    : fam(family), st(stream), on(false), detail_idx(-1) {
   // Every launching entry point opens one of these scopes first.  hipGetLastError() is per-thread
   // and sticky: drop whatever an earlier, unrelated HIP user of this thread left behind (e.g. a
   // benign device probe of the host framework), so that FCD_LAUNCH_CHECK reports OUR launches only.
@@ -59,6 +79,10 @@ FcdProfScope::FcdProfScope(int family, hipStream_t stream, double flops, double 
   g_launches[fam] += 1;
   g_flops[fam] += flops;
   g_bytes[fam] += bytes;
+  if (g_detail_on) {
+    g_detail.push_back({fam, tag ? tag : "", flops, bytes, 0.0});
+    detail_idx = (int)g_detail.size() - 1;
+  }
   hipEventRecord(e0, st);
 }
 
@@ -66,12 +90,14 @@ FcdProfScope::~FcdProfScope() {
   if (!on) return;
   std::lock_guard<std::mutex> lk(g_mu);
   hipEventRecord(e1, st);
-  g_pending.push_back({fam, e0, e1});
+  g_pending.push_back({fam, e0, e1, detail_idx});
 }
 
+// 0 off, 1 per-family totals, 2 totals + a per-launch log (family, tag, ms, flops, bytes: fcd_prof_detail_read)
 extern "C" void fcd_prof_enable(int on) {
   std::lock_guard<std::mutex> lk(g_mu);
   g_prof_on = on != 0;
+  g_detail_on = on == 2;
 }
 extern "C" int fcd_prof_families(void) { return FCD_K_COUNT; }
 extern "C" const char* fcd_prof_family_name(int f) { return (f >= 0 && f < FCD_K_COUNT) ? kNames[f] : "?"; }
@@ -81,7 +107,10 @@ extern "C" int fcd_prof_read(double* out, int reset) {
   for (auto& p : g_pending) {
     hipEventSynchronize(p.e1);
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) g_ms[p.fam] += ms;
+    if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
+      g_ms[p.fam] += ms;
+      if (p.detail >= 0 && p.detail < (int)g_detail.size()) g_detail[p.detail].ms = ms;
+    }
     g_free_events.push_back(p.e0);
     g_free_events.push_back(p.e1);
   }
@@ -94,4 +123,24 @@ extern "C" int fcd_prof_read(double* out, int reset) {
     if (reset) g_ms[f] = g_launches[f] = g_flops[f] = g_bytes[f] = 0.0;
   }
   return FCD_OK;
+}
+
+// Per-launch log as text, one line per scope: "family\ttag\tms\tflops\tbytes\n".  Call fcd_prof_read() first (it
+// resolves the events).  Returns the number of bytes needed (incl. NUL); copies at most cap - 1; clears the log
+// when ``reset``.
+extern "C" int64_t fcd_prof_detail_read(char* buf, int64_t cap, int reset) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  std::string out;
+  char line[320];
+  for (auto& d : g_detail) {
+    snprintf(line, sizeof(line), "%s\t%s\t%.6f\t%.6g\t%.6g\n", kNames[d.fam], d.tag.c_str(), d.ms, d.flops, d.bytes);
+    out += line;
+  }
+  if (buf && cap > 0) {
+    const size_t n = std::min<size_t>(out.size(), (size_t)cap - 1);
+    memcpy(buf, out.data(), n);
+    buf[n] = 0;
+  }
+  if (reset) g_detail.clear();
+  return (int64_t)out.size() + 1;
 }

@@ -822,7 +822,7 @@ extern "C" int fcd_conv2d_fwd_ex(const fcd_conv_desc* d, const float* x, const f
   const double flops = 2.0 * d->N * d->K * (double)d->P * d->Q * d->C * d->R * d->S;
   const double bytes = 4.0 * ((double)d->N * d->C * d->H * d->W + (double)d->N * d->K * d->P * d->Q +
                               (double)d->K * d->C * d->R * d->S);
-  FcdProfScope prof(FCD_K_CONV_FWD, (hipStream_t)stream, flops, bytes);
+  FcdProfScope prof(FCD_K_CONV_FWD, (hipStream_t)stream, flops, bytes, fcd_prof_tag_desc("fwd", d));
   if (!a.act_slope && !residual && thin_fwd_on() &&
       fcd_try_fwd_thin(d, x, wp, bias, y, a.relu, (hipStream_t)stream, nullptr) == 0) {   // <= 4 input channels: VALU kernel
     FCD_LAUNCH_CHECK("conv2d_fwd(thin)");
@@ -849,7 +849,7 @@ extern "C" int fcd_conv2d_bwd_data(const fcd_conv_desc* d, const float* dy, cons
   const double flops = 2.0 * d->N * d->K * (double)d->P * d->Q * d->C * d->R * d->S;
   const double bytes = 4.0 * ((double)d->N * d->C * d->H * d->W + (double)d->N * d->K * d->P * d->Q +
                               (double)d->K * d->C * d->R * d->S);
-  FcdProfScope prof(FCD_K_CONV_DGRAD, (hipStream_t)stream, flops, bytes);
+  FcdProfScope prof(FCD_K_CONV_DGRAD, (hipStream_t)stream, flops, bytes, fcd_prof_tag_desc("dgrad", d));
   if (fcd_try_dgrad_thin(d, dy, relu_out, wp_bwd, dx, (hipStream_t)stream, 0) == 0) {   // <= 4 input channels: VALU kernel
     FCD_LAUNCH_CHECK("conv2d_bwd_data(thin)");
     return FCD_OK;
@@ -879,7 +879,8 @@ extern "C" int fcd_conv2d_fwd_relu_bits(const fcd_conv_desc* d, const float* x, 
   FCD_CHECK_ARG(fcd_conv2d_relu_bits_bytes(d) > 0, "fcd_conv2d_fwd_relu_bits: layer has no bit-mask path");
   const double flops = 2.0 * d->N * d->K * (double)d->P * d->Q * d->C * 9;
   FcdProfScope prof(FCD_K_CONV_FWD, (hipStream_t)stream, flops,
-                    4.0 * ((double)d->N * d->C * d->H * d->W + 1.0625 * d->N * d->K * (double)d->P * d->Q));
+                    4.0 * ((double)d->N * d->C * d->H * d->W + 1.0625 * d->N * d->K * (double)d->P * d->Q),
+                    fcd_prof_tag_desc("fwd_bits", d));
   FCD_CHECK_ARG(fcd_try_fwd_thin(d, x, wp, bias, y, 1, (hipStream_t)stream, bits) == 0,
                 "fcd_conv2d_fwd_relu_bits: unsupported shape");
   FCD_LAUNCH_CHECK("conv2d_fwd_relu_bits");
@@ -894,7 +895,8 @@ extern "C" int fcd_conv2d_bwd_data_bits(const fcd_conv_desc* d, const float* dy,
   FCD_CHECK_ARG(fcd_conv2d_relu_bits_bytes(d) > 0, "fcd_conv2d_bwd_data_bits: layer has no bit-mask path");
   const double flops = 2.0 * d->N * d->K * (double)d->P * d->Q * d->C * 9;
   FcdProfScope prof(FCD_K_CONV_DGRAD, (hipStream_t)stream, flops,
-                    4.0 * ((double)d->N * d->C * d->H * d->W + 1.0625 * d->N * d->K * (double)d->P * d->Q));
+                    4.0 * ((double)d->N * d->C * d->H * d->W + 1.0625 * d->N * d->K * (double)d->P * d->Q),
+                    fcd_prof_tag_desc("dgrad_bits", d));
   FCD_CHECK_ARG(fcd_try_dgrad_thin(d, dy, (const float*)bits, wp_bwd, dx, (hipStream_t)stream, 1) == 0,
                 "fcd_conv2d_bwd_data_bits: unsupported shape");
   FCD_LAUNCH_CHECK("conv2d_bwd_data_bits");
@@ -926,7 +928,7 @@ extern "C" int fcd_conv2d_fwd_relu_pool(const fcd_conv_desc* d, const float* x, 
   a.P = d->P; a.Q = d->Q; a.pad = d->pad;
   const double flops = 2.0 * d->N * d->K * (double)d->P * d->Q * d->C * 9;
   const double bytes = 4.0 * ((double)d->N * d->C * d->H * d->W + 0.3125 * d->N * d->K * d->P * d->Q + (double)d->K * d->C * 9);
-  FcdProfScope prof(FCD_K_CONV_FWD, (hipStream_t)stream, flops, bytes);
+  FcdProfScope prof(FCD_K_CONV_FWD, (hipStream_t)stream, flops, bytes, fcd_prof_tag_desc("fwd", d));
   rc = conv_dispatch(a, 3, 3, 1, 1, (hipStream_t)stream);
   FCD_CHECK_ARG(rc == 0, "fcd_conv2d_fwd_relu_pool: dispatch failed");
   FCD_LAUNCH_CHECK("conv2d_fwd_relu_pool");
@@ -949,7 +951,7 @@ extern "C" int fcd_conv2d_bwd_data_pooled(const fcd_conv_desc* d, const float* d
   a.P = d->H; a.Q = d->W; a.pad = 1;
   const double flops = 2.0 * d->N * d->K * (double)d->P * d->Q * d->C * 9;
   const double bytes = 4.0 * ((double)d->N * d->C * d->H * d->W + 0.3125 * d->N * d->K * d->P * d->Q + (double)d->K * d->C * 9);
-  FcdProfScope prof(FCD_K_CONV_DGRAD, (hipStream_t)stream, flops, bytes);
+  FcdProfScope prof(FCD_K_CONV_DGRAD, (hipStream_t)stream, flops, bytes, fcd_prof_tag_desc("dgrad", d));
   rc = conv_dispatch(a, 3, 3, 1, 1, (hipStream_t)stream);
   FCD_CHECK_ARG(rc == 0, "fcd_conv2d_bwd_data_pooled: dispatch failed");
   FCD_LAUNCH_CHECK("conv2d_bwd_data_pooled");

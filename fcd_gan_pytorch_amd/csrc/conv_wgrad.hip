@@ -583,7 +583,7 @@ extern "C" int fcd_conv2d_bwd_weight_bias(const fcd_conv_desc* d, const float* x
   const double flops = 2.0 * d->N * d->K * (double)d->P * d->Q * d->C * d->R * d->S;
   const double bytes = 4.0 * ((double)d->N * d->C * d->H * d->W + (double)d->N * d->K * d->P * d->Q +
                               (double)d->K * d->C * d->R * d->S);
-  FcdProfScope prof(FCD_K_CONV_WGRAD, st, flops, bytes);
+  FcdProfScope prof(FCD_K_CONV_WGRAD, st, flops, bytes, fcd_prof_tag_desc("wgrad", d));
   if (fcd_wino_wgrad_ws_bytes(d) > 0 && fcd_wino_wgrad_run(d, x, dy, relu_out, dw, db, ws, st) == 0) {
     FCD_LAUNCH_CHECK("conv2d_bwd_weight(winograd)");
     return FCD_OK;

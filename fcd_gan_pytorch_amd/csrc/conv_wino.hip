@@ -682,7 +682,8 @@ static int wino_run(const WinoPlan& pl, int N, int in_ch, int H, int W, const fl
   const int srcmode = code_in ? 2 : (mask ? 1 : 0);
   const double in_elems = (double)N * in_ch * H * W, mm = pl.m * pl.m;
   {
-    FcdProfScope p1(FCD_K_WINO_XFORM, st, 0.0, 4.0 * in_elems * (srcmode == 1 ? 2.0 : 1.0) + (double)pl.v_bytes);
+    FcdProfScope p1(FCD_K_WINO_XFORM, st, 0.0, 4.0 * in_elems * (srcmode == 1 ? 2.0 : 1.0) + (double)pl.v_bytes,
+                    fcd_prof_tagf("in src=%d C=%d img=%dx%dx%d", srcmode, in_ch, N, H, W));
     if (pl.m == 2) wino_launch_input<2>(ia, srcmode, st); else wino_launch_input<4>(ia, srcmode, st);
   }
 
@@ -697,7 +698,8 @@ static int wino_run(const WinoPlan& pl, int N, int in_ch, int H, int W, const fl
   ga.stages_per_split = pl.Q;
   {
     FcdProfScope p2(FCD_K_WINO_GEMM, st, 2.0 * pl.A2 * pl.rows * (double)pl.Kc * (double)pl.T,
-                    (double)pl.v_bytes + (double)pl.m_bytes + 4.0 * pl.A2 * pl.rows * pl.Kc);
+                    (double)pl.v_bytes + (double)pl.m_bytes + 4.0 * pl.A2 * pl.rows * pl.Kc,
+                    fcd_prof_tagf("conv M=%d N=%lld Kc=%d batch=%d img=%dx%dx%d", pl.rows, pl.T, pl.Kc, pl.A2, N, H, W));
     wino_gemm_launch(ga, pl.A2, 1, st);
   }
 
@@ -708,7 +710,8 @@ static int wino_run(const WinoPlan& pl, int N, int in_ch, int H, int W, const fl
   dim3 og((unsigned)cdiv64(pl.T, 256), (unsigned)pl.rows);
   {
     FcdProfScope p3(FCD_K_WINO_XFORM, st, 0.0,
-                    (double)pl.m_bytes + (double)pl.m_bytes / pl.A2 * mm * (pool_y ? 0.3125 : 1.0));
+                    (double)pl.m_bytes + (double)pl.m_bytes / pl.A2 * mm * (pool_y ? 0.3125 : 1.0),
+                    fcd_prof_tagf("out pool=%d K=%d img=%dx%dx%d", pool_y ? 1 : 0, pl.rows, N, H, W));
     if (pl.m == 2) hipLaunchKernelGGL(wino_output_kernel<2>, og, dim3(256), 0, st, oa);
     else hipLaunchKernelGGL(wino_output_kernel<4>, og, dim3(256), 0, st, oa);
   }
@@ -734,7 +737,7 @@ extern "C" int fcd_conv2d_fwd_wino(const fcd_conv_desc* d, const float* x, const
     fcd_set_error("fcd_conv2d_fwd_wino: workspace %zu < %zu bytes", ws_bytes, fcd_conv_wino_ws_bytes(d, 0));
     return FCD_ERR_WORKSPACE;
   }
-  FcdProfScope prof(FCD_K_WINO_FWD, (hipStream_t)stream, conv_flops(d), wino_bytes(pl));
+  FcdProfScope prof(FCD_K_WINO_FWD, (hipStream_t)stream, conv_flops(d), wino_bytes(pl), fcd_prof_tag_desc("wino_fwd", d));
   wino_run(pl, d->N, d->C, d->H, d->W, x, nullptr, nullptr, 0, 0, U, bias, (fuse_relu || pool_y) ? 1 : 0,
            pool_y ? nullptr : y, pool_y, code, ws, (hipStream_t)stream);
   FCD_LAUNCH_CHECK("conv2d_fwd_wino");
@@ -752,7 +755,7 @@ extern "C" int fcd_conv2d_bwd_data_wino(const fcd_conv_desc* d, const float* dy,
     fcd_set_error("fcd_conv2d_bwd_data_wino: workspace %zu < %zu bytes", ws_bytes, fcd_conv_wino_ws_bytes(d, 1));
     return FCD_ERR_WORKSPACE;
   }
-  FcdProfScope prof(FCD_K_WINO_DGRAD, (hipStream_t)stream, conv_flops(d), wino_bytes(pl));
+  FcdProfScope prof(FCD_K_WINO_DGRAD, (hipStream_t)stream, conv_flops(d), wino_bytes(pl), fcd_prof_tag_desc("wino_dgrad", d));
   wino_run(pl, d->N, d->K, d->P, d->Q, dy, pool_code ? nullptr : relu_out, pool_code, d->P / 2, d->Q / 2, U, nullptr, 0,
            dx, nullptr, nullptr, ws, (hipStream_t)stream);
   FCD_LAUNCH_CHECK("conv2d_bwd_data_wino");
@@ -999,6 +1002,8 @@ int fcd_wino_wgrad_run(const fcd_conv_desc* d, const float* x, const float* dy, 
                        float* db, void* ws, hipStream_t st) {
   WinoWgPlan pl;
   if (!fcd_wino_wgrad_plan(d, &pl)) return 1;
+  FcdProfScope pw(FCD_K_WGRAD_WINO, st, 2.0 * d->N * d->K * (double)d->P * d->Q * d->C * 9, 0.0,
+                  fcd_prof_tag_desc("wgrad_wino", d));
   char* wsp = (char*)ws;
   float* Wb = (float*)wsp; wsp += (pl.w_bytes + 255) & ~(size_t)255;
   float* Vb = (float*)wsp; wsp += (pl.v_bytes + 255) & ~(size_t)255;
@@ -1008,7 +1013,7 @@ int fcd_wino_wgrad_run(const fcd_conv_desc* d, const float* x, const float* dy, 
   {
     FcdProfScope p1(FCD_K_WINO_XFORM, st, 0.0,
                     4.0 * ((double)d->N * d->C * d->H * d->W + (double)d->N * d->K * d->P * d->Q) + (double)pl.w_bytes +
-                        (double)pl.v_bytes);
+                        (double)pl.v_bytes, fcd_prof_tag_desc("wgrad_in", d));
     WinoWgArgs ia;
     memset(&ia, 0, sizeof(ia));
     ia.src = x; ia.dst = Vb; ia.N = d->N; ia.CH = d->C; ia.H = d->H; ia.W = d->W;
@@ -1030,11 +1035,13 @@ int fcd_wino_wgrad_run(const fcd_conv_desc* d, const float* x, const float* dy, 
   ga.stages_per_split = pl.sps;
   {
     FcdProfScope p2(FCD_K_WINO_GEMM, st, 2.0 * 36 * d->K * (double)d->C * (double)pl.Tpad,
-                    (double)pl.w_bytes + (double)pl.v_bytes + (double)pl.du_bytes);
+                    (double)pl.w_bytes + (double)pl.v_bytes + (double)pl.du_bytes,
+                    fcd_prof_tagf("wgrad M=%d N=%d Kc=%lld batch=36 splits=%d img=%dx%dx%d", d->K, d->C, pl.Tpad, pl.splits,
+                                  d->N, d->H, d->W));
     wino_gemm_launch(ga, 36, pl.splits, st);
   }
   {
-    FcdProfScope p3(FCD_K_WINO_XFORM, st, 0.0, (double)pl.du_bytes + 4.0 * 9 * d->K * d->C);
+    FcdProfScope p3(FCD_K_WINO_XFORM, st, 0.0, (double)pl.du_bytes + 4.0 * 9 * d->K * d->C, fcd_prof_tag_desc("wgrad_fin", d));
     hipLaunchKernelGGL(wino_wg_final_kernel, dim3((unsigned)cdiv64((long long)d->K * d->C, 256)), dim3(256), 0, st,
                        (const float*)dU, dw, d->K, d->C, pl.splits);
   }

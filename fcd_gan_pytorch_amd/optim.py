@@ -41,29 +41,38 @@ class _FlatOptimizer:
         self.param_groups = [{'params': self.params, 'lr': lr}]
         self.steps = 0
         self.grad_scale = 1.0
+        self.pre_step_hooks = []
 
     def zero_grad(self, set_to_none=False):
-        # in place: gradients must stay views of the flat buffer
+        # in place: gradients must stay views of the flat buffer (re-point first, WITHOUT copying: whatever a
+        # detached .grad holds is exactly what zero_grad is meant to discard)
+        self._bind_grads(copy=False)
         self.flat_g.zero_()
-        for p in self.params:
-            if p.grad is None or p.grad.data_ptr() < self.flat_g.data_ptr() or \
-                    p.grad.data_ptr() >= self.flat_g.data_ptr() + 4 * self.flat_g.numel():
-                self._rebind_grads()
-                break
 
-    def _rebind_grads(self):
+    def _bind_grads(self, copy=True):
+        """Make every ``p.grad`` the matching view of ``flat_g`` again.  A gradient that was detached from the
+        flat buffer (``net.zero_grad()`` with its set_to_none default, ``p.grad = None``, a backward that ran
+        while ``.grad`` was None) is copied in first when ``copy`` (a None gradient contributes zeros), so that
+        the fused update never steps on stale numbers."""
+        lo = self.flat_g.data_ptr()
         off = 0
         for p in self.params:
             k = p.numel()
-            view = self.flat_g[off:off + k].view(p.shape)
-            if p.grad is not None and p.grad.data_ptr() != view.data_ptr():
-                view.copy_(p.grad)
-            p.grad = view
+            g = p.grad
+            if g is None or g.data_ptr() != lo + 4 * off or not g.is_contiguous():
+                view = self.flat_g[off:off + k].view(p.shape)
+                if copy:
+                    if g is None:
+                        view.zero_()
+                    else:
+                        view.copy_(g)
+                p.grad = view
             off += k
 
     def allreduce_grads(self, group=None):
         """Data-parallel exchange: one all-reduce(sum) of the flat gradient buffer over
         RCCL (xGMI); the mean is applied inside the next ``step`` (grad_scale)."""
+        self._bind_grads()
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=group)
             self.grad_scale = 1.0 / dist.get_world_size(group)
@@ -75,10 +84,20 @@ class _FlatOptimizer:
             raise ops._lib.FcdError('fcd optimizers step on a CUDA/ROCm device only (call net.to(device) before '
                                     'constructing the optimizer); there is no CPU fallback')
 
+    def _before_step(self):
+        self._require_device()
+        self._bind_grads()
+        for hook in self.pre_step_hooks:      # e.g. the parity tests snapshot flat_g here
+            hook(self)
+
     def _after_step(self):
         self.steps += 1
         self.grad_scale = 1.0
-        ops.invalidate_packs(self.params)     # packed conv weights are now stale
+        # the kernel wrote the parameters through raw pointers: tell autograd (a backward over a graph that
+        # saved the old weights now raises, as it would after torch.optim's in-place update) and drop the
+        # packed / transformed filter copies
+        torch._C._increment_version(self.params)
+        ops.invalidate_packs(self.params)
 
     @property
     def lr(self):
@@ -94,7 +113,7 @@ class Adam(_FlatOptimizer):
 
     @torch.no_grad()
     def step(self):
-        self._require_device()
+        self._before_step()
         ops.adam_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0],
                       self.betas[1], self.eps, self.weight_decay, self.steps + 1, self.grad_scale)
         self._after_step()
@@ -108,7 +127,7 @@ class RMSprop(_FlatOptimizer):
 
     @torch.no_grad()
     def step(self):
-        self._require_device()
+        self._before_step()
         ops.rmsprop_step(self.flat_p, self.flat_g, self.square_avg, self.lr, self.alpha, self.eps,
                          self.weight_decay, self.grad_scale)
         self._after_step()

@@ -241,8 +241,11 @@ int fcd_rmsprop_step(float* p, const float* g, float* sq, int64_t n, float lr, f
  * When enabled every launch is bracketed by HIP events on its stream; read()
  * synchronises and returns per-family totals: out[f*4+0]=ms, +1=launches,
  * +2=algorithmic FLOPs (direct-convolution count, also for the Winograd families), +3=bytes
- * (f < fcd_prof_families()). */
+ * (f < fcd_prof_families()).  enable(2) additionally keeps a per-launch log (family, layer tag, ms,
+ * FLOPs, bytes); fcd_prof_detail_read() returns it as tab-separated text lines (call fcd_prof_read() first:
+ * it resolves the events), returns the buffer size needed incl. NUL, clears the log when reset. */
 void fcd_prof_enable(int on);
+int64_t fcd_prof_detail_read(char* buf, int64_t cap, int reset);
 int fcd_prof_families(void);
 int fcd_prof_read(double* out, int reset);
 const char* fcd_prof_family_name(int f);

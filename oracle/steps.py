@@ -19,6 +19,16 @@ class Nets:
         self.VGG = nets.clone_state(sdVGG, requires_grad=False) if sdVGG is not None else None
         self.bilinear = bilinear
         self.opt = {}
+        self.capture = None     # set to {} to record the gradients each optimizer is about to step on
+
+    def step(self, which):
+        """optimizer.step() of net ``which``; with ``capture`` set, first snapshots name -> gradient
+        exactly as the optimizer sees it (the parity tests compare the HIP path's pre-step gradients)."""
+        if self.capture is not None:
+            sd = getattr(self, which)
+            self.capture[which] = {k: (sd[k].grad.detach().clone() if sd[k].grad is not None else None)
+                                   for k in nets.param_keys(sd)}
+        self.opt[which].step()
 
     def params(self, which):
         sd = getattr(self, which)
@@ -69,7 +79,7 @@ def usss_g_pretrain_step(n, x, y, perception_weight=0.4, ssim_weight=0):
     gen, l1, perc, ssim = losses.cnet_loss(n.VGG, y, y_fake, cmap)
     loss = gen + perception_weight * perc + ssim_weight * ssim
     loss.backward()
-    n.opt['G'].step()
+    n.step('G')
     return dict(loss=loss, gen=gen, perc=perc, ssim=ssim, y_fake=y_fake)
 
 
@@ -81,7 +91,7 @@ def usss_s_pretrain_step(n, x, y, perception_weight=0.4, l1_weight=0.65, ssim_we
     net_loss = gen + l1_weight * l1 + perception_weight * perc + ssim_weight * ssim
     n.opt['S'].zero_grad()
     net_loss.backward()
-    n.opt['S'].step()
+    n.step('S')
     return dict(net_loss=net_loss, gen=gen, l1=l1, perc=perc, ssim=ssim, cmap=cmap)
 
 
@@ -97,8 +107,8 @@ def usss_joint_step(n, x, y, perception_weight=0.4, l1_weight=0.65, ssim_weight=
     net_loss = gen + l1_weight * l1 + perception_weight * perc + ssim_weight * ssim
     n.opt['S'].zero_grad()
     net_loss.backward()
-    n.opt['G'].step()
-    n.opt['S'].step()
+    n.step('G')
+    n.step('S')
     return dict(loss=loss, net_loss=net_loss, gen=gen, l1=l1, perc=perc, ssim=ssim, cmap=cmap)
 
 
@@ -110,7 +120,7 @@ def rsss_g_pretrain_step(n, x, y, region, perception_weight=0.1, ssim_weight=0, 
     gen, ssim, perc = losses.cgenerator_loss(n.VGG, y, y_fake, region, 1, per_band)
     g_loss = gen + perception_weight * perc + ssim_weight * ssim
     g_loss.backward()
-    n.opt['G'].step()
+    n.step('G')
     return dict(g_loss=g_loss, gen=gen, perc=perc, ssim=ssim)
 
 
@@ -129,7 +139,7 @@ def rsss_adversarial_step(n, x, y, region, perception_weight=0.1, ssim_weight=0,
     n.opt['D'].zero_grad()
     d_loss = 1 + nc_out.mean() - c_out.mean()
     d_loss.backward(retain_graph=True)
-    n.opt['D'].step()
+    n.step('D')
 
     c_out = nets.discriminator(n.D, x_mask, y_mask, train=True)
     y_fake = nets.generator(n.G, x, train=False)
@@ -141,7 +151,7 @@ def rsss_adversarial_step(n, x, y, region, perception_weight=0.1, ssim_weight=0,
     s_loss = d_weight * s_d_loss + l1_weight * l1_loss + g_weight * g_loss + r_weight * r_loss
     n.opt['S'].zero_grad()
     s_loss.backward()
-    n.opt['S'].step()
+    n.step('S')
     return dict(d_loss=d_loss, s_loss=s_loss, s_d_loss=s_d_loss, g_loss=g_loss, l1_loss=l1_loss,
                 r_loss=r_loss, gen=gen, ssim=ssim, perc=perc, cmap=cmap)
 
@@ -163,7 +173,7 @@ def wsss_adversarial_step(n, x, y, x_nc, y_nc, perception_weight=0.5, ssim_weigh
     n.opt['D'].zero_grad()
     d_loss = 1 + nc_out.mean() - c_out.mean()
     d_loss.backward(retain_graph=True)
-    n.opt['D'].step()
+    n.step('D')
 
     nc_loss = torch.mean(torch.pow(ncmap, 2))
     c_out = nets.discriminator(n.D, x_mask, y_mask, train=True)
@@ -175,6 +185,6 @@ def wsss_adversarial_step(n, x, y, x_nc, y_nc, perception_weight=0.5, ssim_weigh
     s_loss = d_weight * s_d_loss + l1_weight * l1_loss + g_weight * g_loss + nc_weight * nc_loss
     n.opt['S'].zero_grad()
     s_loss.backward()
-    n.opt['S'].step()
+    n.step('S')
     return dict(d_loss=d_loss, s_loss=s_loss, s_d_loss=s_d_loss, g_loss=g_loss, l1_loss=l1_loss,
                 nc_loss=nc_loss, gen=gen, ssim=ssim, perc=perc, cmap=cmap, ncmap=ncmap)

@@ -9,7 +9,7 @@ GDAL are absent here, so empty ``sys.modules`` stubs are installed first, with a
 then overwritten with seeded values: the ImageNet checkpoint is unobtainable
 offline => perception parity is pinned for seeded VGG weights only).
 
-Usage:  python tests/golden/gen_golden.py [--only modules|losses|steps]
+Usage:  python tests/golden/gen_golden.py [--only modules|losses|steps|steps2|ckpt]
 """
 import argparse
 import os
@@ -293,6 +293,147 @@ def gen_steps(RM, RL):
     np.savez_compressed(os.path.join(HERE, 'steps.npz'), **out)
 
 
+def grad_summaries(out, tag, module):
+    for k, p in module.named_parameters():
+        out['%s/%s' % (tag, k)] = summary(p.grad)
+
+
+def ref_adjust_lr():
+    """The reference's own adjust_learning_rate (CommonFunc.py:23-37); CommonFunc imports osgeo / cv2 at module
+    level, which the stubs satisfy."""
+    import CommonFunc as RC  # noqa
+    return RC.adjust_learning_rate
+
+
+def gen_steps_extra(RM, RL):
+    """steps2.npz: (1) the gradients each optimizer steps on in the FIRST iteration of the three demos (before any
+    sign-like RMSprop / Adam update can amplify rounding noise) -- pins the oracle's backward bit-for-bit;
+    (2) a 6-iteration Demo_RSSS trajectory with the reference's adjust_learning_rate in the loop
+    (Demo_RSSS.py:248-249: one "epoch" per iteration here).  The trajectory runs at epochs 40..45 of the schedule
+    (decay branch, lr_S ~1.4e-6): at the warm-up rates (1e-4..1e-3 with RMSprop's sign-like first steps) the
+    reference's own trajectory is chaotic -- the CPU oracle, same ATen ops with a 5e-6 relative difference in
+    gradient summation order, is 0.1 off in the density map after 3 iterations -- and pins nothing."""
+    out = {}
+    H = W = 176
+    adjust = ref_adjust_lr()
+    # ---- RSSS: 6 iterations, LR schedule per iteration, gradients of iteration 0
+    C, N = 4, 2
+    G, S, D, crit = build_nets(RM, RL, C, 'CGeneratorLoss', dict(channel=C, perception_layer=1, perception_perBand=True), 7000)
+    S.train(); D.train(); G.eval()
+    oS = torch.optim.RMSprop(S.parameters(), lr=5e-5); oD = torch.optim.RMSprop(D.parameters(), lr=5e-5)
+    x, y, region = seeded_tiles(7100, N, C, H, W)
+    lrs = []
+    EP0 = 40
+    for it in range(6):
+        adjust(oS, EP0 + it, lr_start=1e-4, lr_max=1e-3, lr_warm_up_epoch=5)                      # Demo_RSSS.py:248
+        adjust(oD, EP0 + it, lr_start=5e-6, lr_max=5e-5, lr_min=5e-7, lr_warm_up_epoch=5)         # Demo_RSSS.py:249
+        lrs.append([oS.param_groups[0]['lr'], oD.param_groups[0]['lr']])
+        cmap = S(x, y); cmask = cmap
+        x_mask = x * (1 - cmask.repeat((1, C, 1, 1))); y_mask = y * (1 - cmask.repeat((1, C, 1, 1)))
+        c_out = D(x_mask, y_mask)
+        x_unc = x; y_unc = y * (1 - region) + x * region
+        x_unc = x_unc * (1 - cmask.repeat((1, C, 1, 1))); y_unc = y_unc * (1 - cmask.repeat((1, C, 1, 1)))
+        nc_out = D(x_unc, y_unc)
+        oD.zero_grad(); d_loss = 1 + nc_out.mean() - c_out.mean(); d_loss.backward(retain_graph=True)
+        if it == 0:
+            grad_summaries(out, 'rsss/it0/gradD', D)
+        oD.step()
+        c_out = D(x_mask, y_mask)
+        y_fake = G(x)
+        generator_loss, ssim_loss, perception_loss = crit(y, y_fake, cmap)
+        g_loss = generator_loss + 0.1 * perception_loss + 0 * ssim_loss
+        l1_loss = RL.region_loss(cmap, region, nn.L1Loss()); s_d_loss = c_out.mean()
+        r_loss = RL.region_loss(cmap, 1 - region, nn.MSELoss())
+        s_loss = 1 * s_d_loss + 0.02 * l1_loss + 0.5 * g_loss + 2 * r_loss
+        oS.zero_grad(); s_loss.backward()
+        if it == 0:
+            grad_summaries(out, 'rsss/it0/gradS', S)
+        oS.step()
+        out['traj/it%d/scalars' % it] = np.array([float(v) for v in (d_loss, s_loss, s_d_loss, g_loss, l1_loss, r_loss, generator_loss, ssim_loss, perception_loss)], np.float64)
+        out['traj/it%d/cmap' % it] = cmap.detach()[:, :, ::4, ::4].numpy()
+        print('traj rsss it', it, out['traj/it%d/scalars' % it])
+    out['traj/lrs'] = np.array(lrs, np.float64)
+    weights_summary(out, 'traj/S', S); weights_summary(out, 'traj/D', D)
+    out['traj/meta'] = np.array([7000, 7100, N, C, H, W, 6, EP0], np.int64)
+
+    # ---- USSS joint, iteration 0 gradients (G: grad(Loss)+grad(NetLoss); S: grad(NetLoss))
+    C, N = 4, 1
+    G, S, D, crit = build_nets(RM, RL, C, 'CNetLoss', dict(channel=C, perception_layer=1, perception_perBand=True), 8000)
+    S.train(); G.train()
+    oG = torch.optim.Adam(G.parameters(), lr=2e-4, betas=(0.9, 0.99)); oS = torch.optim.Adam(S.parameters(), lr=2e-4, betas=(0.9, 0.99))
+    x, y, _ = seeded_tiles(8100, N, C, H, W)
+    oG.zero_grad()
+    y_fake = G(x); cmap = S(x, y)
+    generator_loss, l1_loss, perception_loss, ssim_loss = crit(y, y_fake, cmap)
+    Loss = generator_loss + 0.4 * perception_loss + 0 * ssim_loss
+    Loss.backward(retain_graph=True)
+    NetLoss = generator_loss + 0.65 * l1_loss + 0.4 * perception_loss + 0 * ssim_loss
+    oS.zero_grad(); NetLoss.backward()
+    grad_summaries(out, 'usss/it0/gradG', G); grad_summaries(out, 'usss/it0/gradS', S)
+
+    # ---- WSSS, iteration 0 gradients
+    C, N = 3, 1
+    G, S, D, crit = build_nets(RM, RL, C, 'CGeneratorLoss', dict(channel=C, perception_layer=1, perception_perBand=False), 9000)
+    S.train(); D.train(); G.eval()
+    oS = torch.optim.RMSprop(S.parameters(), lr=1e-3); oD = torch.optim.RMSprop(D.parameters(), lr=1e-5)
+    x, y, _ = seeded_tiles(9100, N, C, H, W)
+    x_nc, _, _ = seeded_tiles(9200, N, C, H, W)
+    y_nc = x_nc + 0.05 * seeded_tiles(9300, N, C, H, W)[0]
+    cmap = S(x, y); cmask = cmap
+    x_mask = x * (1 - cmask.repeat((1, C, 1, 1))); y_mask = y * (1 - cmask.repeat((1, C, 1, 1)))
+    c_out = D(x_mask, y_mask)
+    ncmap = S(x_nc, y_nc)
+    x_mask_nc = x_nc * (1 - cmask.repeat((1, C, 1, 1))); y_mask_nc = y_nc * (1 - cmask.repeat((1, C, 1, 1)))
+    nc_out = D(x_mask_nc, y_mask_nc)
+    oD.zero_grad(); d_loss = 1 + nc_out.mean() - c_out.mean(); d_loss.backward(retain_graph=True)
+    grad_summaries(out, 'wsss/it0/gradD', D)
+    oD.step()
+    nc_loss = torch.mean(torch.pow(ncmap, 2))
+    c_out = D(x_mask, y_mask)
+    y_fake = G(x)
+    generator_loss, ssim_loss, perception_loss = crit(y, y_fake, cmap)
+    g_loss = generator_loss + 0.5 * perception_loss + 0 * ssim_loss
+    l1_loss = torch.mean(abs(cmap)); s_d_loss = c_out.mean()
+    s_loss = 1 * s_d_loss + 1.6 * l1_loss + 0.2 * g_loss + 1.5 * nc_loss
+    oS.zero_grad(); s_loss.backward()
+    grad_summaries(out, 'wsss/it0/gradS', S)
+    np.savez_compressed(os.path.join(HERE, 'steps2.npz'), **out)
+
+
+def gen_checkpoint(RM):
+    """Checkpoint interchange (Demo_RSSS.py:167-171,507-514; Demo_USSS.py:477-481): ``netG_ref.pkl`` is
+    ``torch.save(netG.state_dict())`` of the REFERENCE Generator class (tensors only), ``ckpt.npz`` its eval-mode
+    output on a seeded tile.  The reverse direction is asserted here: state_dicts saved from the new package's
+    Generator / Segmentor / Discriminator classes load into the reference classes with strict=True."""
+    import io
+    torch.manual_seed(1234)
+    C = 3
+    G = RM.Generator(C)
+    with torch.no_grad():                       # make the BN statistics non-trivial, as after training
+        for m in G.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.6, 1.4)
+                m.num_batches_tracked.fill_(17)
+    torch.save(G.state_dict(), os.path.join(HERE, 'netG_ref.pkl'))
+    G.eval()
+    x, _, _ = seeded_tiles(4321, 1, C, 40, 40)
+    with torch.no_grad():
+        y = G(x)
+    np.savez_compressed(os.path.join(HERE, 'ckpt.npz'), out=y.numpy(), meta=np.array([4321, 1, C, 40, 40], np.int64))
+    import fcd_gan_pytorch_amd as fcd
+    for ours, theirs in ((fcd.Module.Generator(4), RM.Generator(4)),
+                         (fcd.Module.Segmentor(4, 1, True), RM.Segmentor(4, 1, True)),
+                         (fcd.Module.Segmentor(3, 1, False), RM.Segmentor(3, 1, False)),
+                         (fcd.Module.Discriminator_SRGAN_simple(4), RM.Discriminator_SRGAN_simple(4))):
+        buf = io.BytesIO()
+        torch.save(ours.state_dict(), buf)
+        buf.seek(0)
+        theirs.load_state_dict(torch.load(buf), strict=True)
+        for (k1, v1), (k2, v2) in zip(ours.state_dict().items(), theirs.state_dict().items()):
+            assert k1 == k2 and torch.equal(v1, v2), k1
+    print('checkpoint interchange: reference-written netG_ref.pkl; ours -> reference strict load OK')
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', default=None)
@@ -306,3 +447,7 @@ if __name__ == '__main__':
         gen_losses(RL, RS)
     if a.only in (None, 'steps'):
         gen_steps(RM, RL)
+    if a.only in (None, 'steps2'):
+        gen_steps_extra(RM, RL)
+    if a.only in (None, 'ckpt'):
+        gen_checkpoint(RM)

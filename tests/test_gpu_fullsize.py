@@ -137,7 +137,7 @@ def test_rsss_step_full_size_is_finite_and_reproducible():
         netG = p.Module.Generator(C).to(DEV).eval()
         with warnings.catch_warnings():
             warnings.simplefilter('ignore')
-            crit = p.Loss.CGeneratorLoss(channel=C, perception_layer=1, perception_perBand=True).to(DEV)
+            crit = p.Loss.CGeneratorLoss(channel=C, perception_layer=1, perception_perBand=True, allow_seeded=True).to(DEV)
         oS, oD = p.optim.RMSprop(netS.parameters(), lr=5e-5), p.optim.RMSprop(netD.parameters(), lr=5e-5)
         outs = []
         for _ in range(2):
@@ -261,7 +261,7 @@ def test_rsss_step_full_size_vs_oracle(literal):
     netG.load_state_dict(sdG); netS.load_state_dict(sdS); netD.load_state_dict(sdD)
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
-        crit = p.Loss.CGeneratorLoss(channel=C, perception_layer=1, perception_perBand=True)
+        crit = p.Loss.CGeneratorLoss(channel=C, perception_layer=1, perception_perBand=True, allow_seeded=True)
     crit.loss_perception.net.load_state_dict(sdV)
     for m in (netG, netS, netD, crit):
         m.to(DEV)
@@ -296,7 +296,7 @@ def test_usss_g_step_full_size_vs_oracle():
     netG.load_state_dict(sdG)
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
-        crit = p.Loss.CNetLoss(channel=C, perception_layer=1, perception_perBand=True)
+        crit = p.Loss.CNetLoss(channel=C, perception_layer=1, perception_perBand=True, allow_seeded=True)
     crit.loss_perception.net.load_state_dict(sdV)
     netG.to(DEV).train(); crit.to(DEV)
     oG = p.optim.Adam(netG.parameters(), lr=2e-4, betas=(0.9, 0.99))
@@ -323,7 +323,7 @@ def test_wsss_step_full_size_vs_oracle():
     netG.load_state_dict(sdG); netS.load_state_dict(sdS); netD.load_state_dict(sdD)
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
-        crit = p.Loss.CGeneratorLoss(channel=C, perception_layer=1, perception_perBand=False)
+        crit = p.Loss.CGeneratorLoss(channel=C, perception_layer=1, perception_perBand=False, allow_seeded=True)
     crit.loss_perception.net.load_state_dict(sdV)
     for m in (netG, netS, netD, crit):
         m.to(DEV)

@@ -1,0 +1,163 @@
+"""SURVEY.md 8(f)-4 on the GPU: checkpoint interchange with the reference's ``.pkl`` files, a multi-iteration
+Demo_RSSS trajectory with ``adjust_learning_rate`` in the loop, and the first-iteration gradients of the three demos
+against fixtures written by the REFERENCE (tests/golden/gen_golden.py --only steps2|ckpt)."""
+import io
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from seeded import seeded_state, seeded_tiles, summary
+from oracle import nets as onets
+from test_gpu_modules import _load_nets, is_pre_bn_bias
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), 'golden')
+DEV = 'cuda'
+
+
+def pkg():
+    import fcd_gan_pytorch_amd as p
+    return p
+
+
+def test_reference_pkl_loads_and_runs():
+    """``netG_ref.pkl`` = torch.save(netG.state_dict()) of the reference's Generator class (Demo_RSSS.py:507-514);
+    loaded exactly as Demo_RSSS.py:167-171 does, its eval-mode output must match the reference's own output."""
+    p = pkg()
+    zc = np.load(os.path.join(G, 'ckpt.npz'))
+    seed, N, C, H, W = [int(v) for v in zc['meta']]
+    netG = p.Module.Generator(n_channels=C).to(DEV)
+    netG.load_state_dict(torch.load(os.path.join(G, 'netG_ref.pkl')))
+    netG.eval()
+    x, _, _ = seeded_tiles(seed, N, C, H, W)
+    ref = torch.from_numpy(zc['out'])
+    with torch.no_grad():
+        folded = netG(x.to(DEV)).cpu()                       # BN folded into the convs (inference path)
+    plain = netG(x.to(DEV)).detach().cpu()                    # autograd path, eval-mode BN kernels
+    tol = 1e-4 * max(1.0, ref.abs().max().item())
+    assert (folded - ref).abs().max().item() <= tol and (plain - ref).abs().max().item() <= tol
+    # save from the device model -> reload into a fresh one -> bit-equal tensors (Demo_RSSS.py:507-514 round trip)
+    buf = io.BytesIO()
+    torch.save(netG.state_dict(), buf)
+    buf.seek(0)
+    again = p.Module.Generator(n_channels=C)
+    again.load_state_dict(torch.load(buf, map_location='cpu'))
+    sd0 = torch.load(os.path.join(G, 'netG_ref.pkl'))
+    for k, v in again.state_dict().items():
+        assert torch.equal(v, sd0[k]), k
+
+
+def test_checkpoint_survives_flat_optimizer():
+    """The fcd optimizers re-point every parameter at a slice of one flat buffer; state_dict() / load_state_dict()
+    must keep working on such a net (save after training, Demo_USSS.py:477-481; resume, Demo_RSSS.py:167-171)."""
+    p = pkg()
+    C = 4
+    net = p.Module.Discriminator_SRGAN_simple(C).to(DEV).train()
+    opt = p.optim.RMSprop(net.parameters(), lr=1e-4)
+    x, y, _ = (t.to(DEV) for t in seeded_tiles(3, 2, C, 48, 48))
+    opt.zero_grad(); net(x, y).mean().backward(); opt.step()
+    buf = io.BytesIO()
+    torch.save(net.state_dict(), buf)
+    buf.seek(0)
+    sd = torch.load(buf, map_location='cpu')
+    other = p.Module.Discriminator_SRGAN_simple(C).to(DEV).train()
+    opt2 = p.optim.RMSprop(other.parameters(), lr=1e-4)
+    other.load_state_dict(sd)                                  # copies INTO the flat buffer views
+    assert all(q.data_ptr() >= opt2.flat_p.data_ptr() for q in other.parameters())
+    with torch.no_grad():
+        a, b = net.eval()(x, y), other.eval()(x, y)
+    assert torch.equal(a, b)
+    # packed / folded filter caches must notice the load: a second load with other weights changes the output
+    sd2 = {k: (v * 1.5 if v.is_floating_point() and v.dim() == 4 else v) for k, v in sd.items()}
+    other.load_state_dict(sd2)
+    with torch.no_grad():
+        c = other(x, y)
+    assert not torch.equal(b, c)
+
+
+def _grads_vs_fixture(z, prefix, net, flat_g, rtol):
+    off, worst = 0, 0.0
+    wmax = max(float(z['%s/%s' % (prefix, k)][1]) for k, _ in net.named_parameters())
+    for k, prm in net.named_parameters():
+        n = prm.numel()
+        g = flat_g[off:off + n].view(prm.shape).cpu()
+        off += n
+        ref = z['%s/%s' % (prefix, k)]
+        if is_pre_bn_bias(k) or ref[1] <= 1e-4 * wmax:
+            continue
+        got = summary(g)
+        worst = max(worst, abs(got[1] - ref[1]) / ref[1])
+    assert worst <= rtol, (prefix, worst)
+    return worst
+
+
+def test_step0_gradients_vs_reference_fixture(conv_path):
+    """Per-tensor L2 norms of the gradients the optimizers step on in iteration 0 of Demo_RSSS / Demo_WSSS /
+    Demo_USSS-joint against the reference's (steps2.npz).  176x176 tiles: BN populations >= N*11*11."""
+    p = pkg()
+    z = np.load(os.path.join(G, 'steps2.npz'))
+    zs = np.load(os.path.join(G, 'steps.npz'))
+    rtol = 5e-3 if conv_path == 'direct' else 1e-2
+    store = {}
+
+    def hook(key):
+        def f(opt):
+            store[key] = opt.flat_g.detach().clone()
+        return f
+    # RSSS
+    wseed, tseed, N, C, H, W = [int(v) for v in zs['rsss/meta']]
+    ep0 = int(z['traj/meta'][7])
+    netG, netS, netD, crit, opts = _load_nets(C, wseed, 'CGeneratorLoss', True, 'rsss')
+    netS.train(); netD.train(); netG.eval()
+    p.optim.adjust_learning_rate(opts['S'], ep0, lr_start=1e-4, lr_max=1e-3, lr_warm_up_epoch=5)
+    p.optim.adjust_learning_rate(opts['D'], ep0, lr_start=5e-6, lr_max=5e-5, lr_min=5e-7, lr_warm_up_epoch=5)
+    opts['S'].pre_step_hooks.append(hook('S')); opts['D'].pre_step_hooks.append(hook('D'))
+    x, y, region = (t.to(DEV) for t in seeded_tiles(tseed, N, C, H, W))
+    p.steps.rsss_adversarial_step(netS, netD, netG, crit, opts['S'], opts['D'], x, y, region)
+    w = [_grads_vs_fixture(z, 'rsss/it0/gradD', netD, store['D'], rtol), _grads_vs_fixture(z, 'rsss/it0/gradS', netS, store['S'], rtol)]
+    # USSS joint (literal=False: one backward, G's gradient doubled == grad(Loss) + grad(NetLoss))
+    wseed, tseed, N, C, H, W = [int(v) for v in zs['usss/meta']]
+    netG, netS, netD, crit, opts = _load_nets(C, wseed, 'CNetLoss', True, 'usss')
+    netS.train(); netG.train()
+    opts['S'].pre_step_hooks.append(hook('S')); opts['G'].pre_step_hooks.append(hook('G'))
+    x, y, _ = (t.to(DEV) for t in seeded_tiles(tseed, N, C, H, W))
+    p.steps.usss_joint_step(netS, netG, crit, opts['S'], opts['G'], x, y)
+    w += [_grads_vs_fixture(z, 'usss/it0/gradG', netG, store['G'], rtol), _grads_vs_fixture(z, 'usss/it0/gradS', netS, store['S'], rtol)]
+    # WSSS
+    wseed, tseed, N, C, H, W = [int(v) for v in zs['wsss/meta']]
+    netG, netS, netD, crit, opts = _load_nets(C, wseed, 'CGeneratorLoss', False, 'wsss')
+    netS.train(); netD.train(); netG.eval()
+    opts['S'].pre_step_hooks.append(hook('S')); opts['D'].pre_step_hooks.append(hook('D'))
+    x, y, _ = (t.to(DEV) for t in seeded_tiles(tseed, N, C, H, W))
+    x_nc = seeded_tiles(tseed + 100, N, C, H, W)[0]
+    y_nc = (x_nc + 0.05 * seeded_tiles(tseed + 200, N, C, H, W)[0]).to(DEV)
+    p.steps.wsss_adversarial_step(netS, netD, netG, crit, opts['S'], opts['D'], x, y, x_nc.to(DEV), y_nc)
+    w += [_grads_vs_fixture(z, 'wsss/it0/gradD', netD, store['D'], rtol), _grads_vs_fixture(z, 'wsss/it0/gradS', netS, store['S'], rtol)]
+    print('\n[step-0 gradient norms vs reference, worst per-tensor relative difference, %s] %s' % (conv_path, ['%.1e' % v for v in w]))
+
+
+def test_rsss_trajectory_with_lr_schedule_vs_reference_fixture(conv_path):
+    """Six Demo_RSSS iterations with adjust_learning_rate in the loop (Demo_RSSS.py:246-332) against the trajectory
+    the reference produced.  The CPU oracle's own drift from this fixture (same ATen ops, another gradient summation
+    order) is max 5.2e-3 / mean 7.7e-4 in the density map after six iterations; the bounds are 4x that."""
+    p = pkg()
+    z = np.load(os.path.join(G, 'steps2.npz'))
+    wseed, tseed, N, C, H, W, iters, ep0 = [int(v) for v in z['traj/meta']]
+    netG, netS, netD, crit, opts = _load_nets(C, wseed, 'CGeneratorLoss', True, 'rsss')
+    netS.train(); netD.train(); netG.eval()
+    x, y, region = (t.to(DEV) for t in seeded_tiles(tseed, N, C, H, W))
+    drift = []
+    for it in range(iters):
+        lrS = p.optim.adjust_learning_rate(opts['S'], ep0 + it, lr_start=1e-4, lr_max=1e-3, lr_warm_up_epoch=5)
+        lrD = p.optim.adjust_learning_rate(opts['D'], ep0 + it, lr_start=5e-6, lr_max=5e-5, lr_min=5e-7, lr_warm_up_epoch=5)
+        assert [lrS, lrD] == list(z['traj/lrs'][it])
+        r = p.steps.rsss_adversarial_step(netS, netD, netG, crit, opts['S'], opts['D'], x, y, region)
+        got = [float(r[k]) for k in ('d_loss', 's_loss', 's_d_loss', 'g_loss', 'l1_loss', 'r_loss',
+                                     'generator_loss', 'ssim_loss', 'perception_loss')]
+        np.testing.assert_allclose(got, z['traj/it%d/scalars' % it], rtol=2e-3, atol=1e-5)
+        d = (r['cmap'].detach().cpu()[:, :, ::4, ::4] - torch.from_numpy(z['traj/it%d/cmap' % it])).abs()
+        drift.append((d.max().item(), d.mean().item()))
+        assert d.max().item() <= (1e-4 if it == 0 else 2e-2) and d.mean().item() <= (2e-5 if it == 0 else 3e-3), (it, drift)
+    print('\n[trajectory drift per iteration (max, mean), %s] %s' % (conv_path, ['%.1e/%.1e' % v for v in drift]))

@@ -212,7 +212,7 @@ def make_crit(cls, channel, layer, pb):
     L = pkg().Loss
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
-        crit = getattr(L, cls)(channel=channel, perception_layer=layer, perception_perBand=pb)
+        crit = getattr(L, cls)(channel=channel, perception_layer=layer, perception_perBand=pb, allow_seeded=True)
     crit.loss_perception.net.load_state_dict(seeded_state(onets.vgg_spec(), 4242))
     return crit.to(DEV)
 

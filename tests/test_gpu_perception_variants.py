@@ -26,7 +26,7 @@ def test_cnet_loss_variants(layers, per_band, switch, size, conv_path):
     vgg = seeded_state(onets.vgg_spec(), 4242)
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
-        crit = p.Loss.CNetLoss(channel=C, perception_layer=layers, perception_perBand=per_band)
+        crit = p.Loss.CNetLoss(channel=C, perception_layer=layers, perception_perBand=per_band, allow_seeded=True)
     crit.loss_perception.net.load_state_dict(vgg)
     crit.to(DEV)
     t, g, _ = seeded_tiles(31 + layers, N, C, size, size)

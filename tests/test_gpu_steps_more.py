@@ -29,7 +29,7 @@ def make(C, crit_cls, pb, wseed):
     S = p.Module.Segmentor(C, 1, True); S.load_state_dict(sdS); S.to(DEV).train()
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
-        crit = getattr(p.Loss, crit_cls)(channel=C, perception_layer=1, perception_perBand=pb)
+        crit = getattr(p.Loss, crit_cls)(channel=C, perception_layer=1, perception_perBand=pb, allow_seeded=True)
     crit.loss_perception.net.load_state_dict(sdV)
     crit.to(DEV)
     return G, S, crit, (sdG, sdS, sdV)
@@ -101,7 +101,7 @@ def test_config_a_generator_step_batch16_256():
         G = p.Module.Generator(C).to(DEV).train()
         with warnings.catch_warnings():
             warnings.simplefilter('ignore')
-            crit = p.Loss.CNetLoss(channel=C, perception_layer=1, perception_perBand=True).to(DEV)
+            crit = p.Loss.CNetLoss(channel=C, perception_layer=1, perception_perBand=True, allow_seeded=True).to(DEV)
         oG = p.optim.Adam(G.parameters(), lr=2e-4, betas=(0.9, 0.99))
         vals = []
         for _ in range(2):

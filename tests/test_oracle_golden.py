@@ -1,7 +1,14 @@
 """Pin the CPU oracle (oracle/) against fixtures produced by the reference itself
-(tests/golden/gen_golden.py).  Same ATen ops in the same order => the match is
-expected to be bit-exact on the generating machine; a tiny tolerance absorbs
-CPU-ISA dispatch differences (oneDNN picks kernels per host CPU)."""
+(tests/golden/gen_golden.py).  Same ATen ops in the same order => bit-exact on the generating
+machine.  MEASURED max differences in the build container (8 threads, the generator's setting):
+  modules (outputs, input + parameter gradients, BN buffers), MS-SSIM, region loss .... 0  (bit-exact)
+  criteria values 0; their gradient summaries ......................................... <= 1.6e-7 relative
+  first-iteration gradients of the three demo steps (steps2.npz) ..................... see test_step0_gradients
+  multi-iteration states: iteration 0 bit-exact; later iterations differ by up to a few optimizer steps on
+  elements whose gradient is rounding noise (conv biases in front of a BatchNorm: true gradient 0), because
+  RMSprop / Adam's first updates are sign-like -- bounded by ``step_atol`` below, not by a relative tolerance.
+The tolerances are clamped to 10x the measured differences (floor 1e-6 relative: oneDNN may pick another kernel /
+summation order on a different host CPU or thread count)."""
 import os
 
 import numpy as np
@@ -12,7 +19,7 @@ from seeded import seeded_state, seeded_tiles, summary
 from oracle import nets, losses, steps
 
 G = os.path.join(os.path.dirname(__file__), 'golden')
-RTOL, ATOL = 2e-4, 2e-5
+RTOL, ATOL = 1e-6, 1e-7
 
 
 def close(a, b, rtol=RTOL, atol=ATOL):
@@ -20,14 +27,14 @@ def close(a, b, rtol=RTOL, atol=ATOL):
     np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
 
 
-def sum_close(t, ref, rtol=5e-4, samp_atol=0.0):
+def sum_close(t, ref, rtol=2e-6, samp_atol=0.0):
     """compare a tensor with a stored summary (sum, L2, samples)."""
     got = summary(t)
     scale = max(ref[1], 1e-12)
     n = max(t.numel(), 1)
     assert abs(got[1] - ref[1]) <= rtol * scale + 1e-7 + samp_atol * np.sqrt(n) * 0.1, ('L2', got[1], ref[1])
     assert abs(got[0] - ref[0]) <= rtol * scale * np.sqrt(n) + 1e-6 + samp_atol * np.sqrt(n), ('sum', got[0], ref[0])
-    np.testing.assert_allclose(got[2:], ref[2:], rtol=5e-3, atol=rtol * scale / np.sqrt(n) * 10 + 1e-7 + samp_atol)
+    np.testing.assert_allclose(got[2:], ref[2:], rtol=max(2e-5, 10 * rtol), atol=rtol * scale / np.sqrt(n) * 10 + 1e-9 + samp_atol)
 
 
 def probe_like(shape, seed):
@@ -81,11 +88,11 @@ def test_msssim_matches_reference(tag):
     x.requires_grad_(True); y.requires_grad_(True)
     v = losses.ms_ssim(x, y, data_range=1.0)
     v.backward()
-    close(v.item(), z[tag + '/val'], rtol=1e-5)
+    close(v.item(), z[tag + '/val'], rtol=1e-6)
     sum_close(x.grad, z[tag + '/dx']); sum_close(y.grad, z[tag + '/dy'])
-    close(x.grad[0, 0, ::8, ::8].numpy(), z[tag + '/dx_full'], rtol=1e-3, atol=1e-9)
+    close(x.grad[0, 0, ::8, ::8].numpy(), z[tag + '/dx_full'], rtol=1e-6, atol=1e-12)
     s, _ = losses.ssim_level(x.detach(), y.detach(), losses.gauss_window())
-    close(s.mean().item(), z[tag + '/ssim_val'], rtol=1e-5)
+    close(s.mean().item(), z[tag + '/ssim_val'], rtol=1e-6)
 
 
 def make_cmap(seed, N, H, W, all_changed=None):
@@ -115,7 +122,7 @@ def test_criteria_match_reference(tag):
         vals = losses.cgenerator_loss(vgg, t, g, cmap, layer, pb)
     tot = sum(w * v for w, v in zip([1.0, 0.3, 0.7, 0.2], vals))
     tot.backward()
-    close([float(v) for v in vals], z[tag + '/vals'], rtol=2e-5)
+    close([float(v.detach()) for v in vals], z[tag + '/vals'], rtol=1e-6)
     sum_close(g.grad, z[tag + '/dgen']); sum_close(cmap.grad, z[tag + '/dcmap'])
 
 
@@ -129,7 +136,7 @@ def test_region_loss_matches_reference():
     sum_close(cm.grad, z['region/dcmap'])
 
 
-def _state_close(z, tag, sd, rtol=2e-3, step_atol=0.0):
+def _state_close(z, tag, sd, rtol=2e-3, step_atol=0.0):     # rtol here: multi-iteration states, see module docstring
     """step_atol: RMSprop/Adam's first steps are sign-like (|dw| ~ lr/sqrt(1-alpha) whatever |g| is), so a
     gradient element at rounding-noise level may move the other way: allow a few step sizes per sample."""
     for k, v in sd.items():
@@ -149,8 +156,9 @@ def test_rsss_step_matches_reference():
     for it in range(2):
         r = steps.rsss_adversarial_step(n, x, y, region)
         got = [float(r[k]) for k in ('d_loss', 's_loss', 's_d_loss', 'g_loss', 'l1_loss', 'r_loss', 'gen', 'ssim', 'perc')]
-        close(got, z['rsss/it%d/scalars' % it], rtol=5e-4, atol=1e-6)
-        close(r['cmap'].detach()[:, :, ::4, ::4].numpy(), z['rsss/it%d/cmap' % it], rtol=2e-3, atol=2e-5)
+        close(got, z['rsss/it%d/scalars' % it], rtol=1e-6 if it == 0 else 5e-4, atol=1e-7 if it == 0 else 1e-6)
+        close(r['cmap'].detach()[:, :, ::4, ::4].numpy(), z['rsss/it%d/cmap' % it], rtol=1e-6 if it == 0 else 2e-3,
+              atol=1e-7 if it == 0 else 1e-4)
     _state_close(z, 'rsss/S', n.S, step_atol=2 * 2 * 5e-4); _state_close(z, 'rsss/D', n.D, step_atol=2 * 2 * 5e-4)
     _state_close(z, 'rsss/G', n.G)
 
@@ -164,8 +172,8 @@ def test_usss_joint_step_matches_reference():
     for it in range(2):
         r = steps.usss_joint_step(n, x, y)
         got = [float(r[k]) for k in ('loss', 'net_loss', 'gen', 'l1', 'perc', 'ssim')]
-        close(got, z['usss/it%d/scalars' % it], rtol=5e-4, atol=1e-6)
-        sum_close(r['cmap'], z['usss/it%d/cmap_sum' % it], rtol=2e-3)
+        close(got, z['usss/it%d/scalars' % it], rtol=1e-6 if it == 0 else 5e-4, atol=1e-7 if it == 0 else 1e-6)
+        sum_close(r['cmap'], z['usss/it%d/cmap_sum' % it], rtol=2e-6 if it == 0 else 2e-3)
     _state_close(z, 'usss/S', n.S, step_atol=2 * 2 * 2e-4); _state_close(z, 'usss/G', n.G, step_atol=2 * 2 * 2e-4)
 
 
@@ -179,6 +187,107 @@ def test_wsss_step_matches_reference():
     y_nc = x_nc + 0.05 * seeded_tiles(tseed + 200, N, C, H, W)[0]
     r = steps.wsss_adversarial_step(n, x, y, x_nc, y_nc)
     got = [float(r[k]) for k in ('d_loss', 's_loss', 's_d_loss', 'g_loss', 'l1_loss', 'nc_loss', 'gen', 'ssim', 'perc')]
-    close(got, z['wsss/it0/scalars'], rtol=5e-4, atol=1e-6)
-    sum_close(r['cmap'], z['wsss/it0/cmap_sum'], rtol=2e-3)
+    close(got, z['wsss/it0/scalars'], rtol=1e-6, atol=1e-7)
+    sum_close(r['cmap'], z['wsss/it0/cmap_sum'], rtol=2e-6)
     _state_close(z, 'wsss/S', n.S, step_atol=2 * 1e-2); _state_close(z, 'wsss/D', n.D, step_atol=2 * 1e-4)
+
+
+# ------------------------------------------------------- first-iteration gradients, trajectory, checkpoint
+GRAD_RTOL = 2e-5      # measured: D 0 (bit-exact), S / G <= 5.6e-6 relative (L2 and samples) in the build container: the oracle's functional graph
+#                       sums multi-use gradients (cmap feeds four loss terms) in another order than the reference's
+#                       module graph, nothing else differs
+
+
+def _grads_close(z, prefix, cap, rtol=GRAD_RTOL):
+    worst = 0.0
+    wmax = max(float(z['%s/%s' % (prefix, k)][1]) for k in cap)
+    for k, g in cap.items():
+        ref = z['%s/%s' % (prefix, k)]
+        got = summary(g)
+        if ref[1] <= 1e-6 * wmax:
+            continue                 # conv biases in front of a BatchNorm: analytically zero, rounding noise
+        worst = max(worst, abs(got[1] - ref[1]) / ref[1], np.abs(got[2:] - ref[2:]).max() / max(np.abs(ref[2:]).max(), 1e-30))
+    assert worst <= rtol, (prefix, worst)
+    return worst
+
+
+def test_step0_gradients_match_reference():
+    """The gradients each optimizer steps on in iteration 0 of the three demos (steps2.npz, written by the reference)."""
+    z = np.load(os.path.join(G, 'steps2.npz'))
+    zs = np.load(os.path.join(G, 'steps.npz'))
+    wseed, tseed, N, C, H, W = [int(v) for v in zs['rsss/meta']]
+    n = steps.Nets(seeded_state(nets.generator_spec(C), wseed + 1), seeded_state(nets.segmentor_spec(C, 1, True), wseed + 2),
+                   seeded_state(nets.discriminator_spec(C), wseed + 3), seeded_state(nets.vgg_spec(), 4242)).make_optimizers('rsss')
+    n.capture = {}
+    x, y, region = seeded_tiles(tseed, N, C, H, W)
+    # the fixture's first iteration runs at the schedule's epoch-40 rates (S's gradient sees D AFTER its update)
+    ep0 = int(z['traj/meta'][7])
+    steps.adjust_learning_rate(n.opt['S'], ep0, lr_start=1e-4, lr_max=1e-3, lr_warm_up_epoch=5)
+    steps.adjust_learning_rate(n.opt['D'], ep0, lr_start=5e-6, lr_max=5e-5, lr_min=5e-7, lr_warm_up_epoch=5)
+    steps.rsss_adversarial_step(n, x, y, region)
+    w = [_grads_close(z, 'rsss/it0/gradD', n.capture['D']), _grads_close(z, 'rsss/it0/gradS', n.capture['S'])]
+    wseed, tseed, N, C, H, W = [int(v) for v in zs['usss/meta']]
+    n = steps.Nets(seeded_state(nets.generator_spec(C), wseed + 1), seeded_state(nets.segmentor_spec(C, 1, True), wseed + 2),
+                   None, seeded_state(nets.vgg_spec(), 4242)).make_optimizers('usss')
+    n.capture = {}
+    x, y, _ = seeded_tiles(tseed, N, C, H, W)
+    steps.usss_joint_step(n, x, y)
+    w += [_grads_close(z, 'usss/it0/gradG', n.capture['G']), _grads_close(z, 'usss/it0/gradS', n.capture['S'])]
+    wseed, tseed, N, C, H, W = [int(v) for v in zs['wsss/meta']]
+    n = steps.Nets(seeded_state(nets.generator_spec(C), wseed + 1), seeded_state(nets.segmentor_spec(C, 1, True), wseed + 2),
+                   seeded_state(nets.discriminator_spec(C), wseed + 3), seeded_state(nets.vgg_spec(), 4242)).make_optimizers('wsss')
+    n.capture = {}
+    x, y, _ = seeded_tiles(tseed, N, C, H, W)
+    x_nc, _, _ = seeded_tiles(tseed + 100, N, C, H, W)
+    y_nc = x_nc + 0.05 * seeded_tiles(tseed + 200, N, C, H, W)[0]
+    steps.wsss_adversarial_step(n, x, y, x_nc, y_nc)
+    w += [_grads_close(z, 'wsss/it0/gradD', n.capture['D']), _grads_close(z, 'wsss/it0/gradS', n.capture['S'])]
+    print('step-0 gradient max relative differences (rsss D,S / usss G,S / wsss D,S):', ['%.1e' % v for v in w])
+
+
+def test_rsss_trajectory_with_lr_schedule_matches_reference():
+    """Six Demo_RSSS iterations with adjust_learning_rate in the loop (Demo_RSSS.py:248-249), reference-generated,
+    at epochs 40..45 of the schedule (see gen_golden.gen_steps_extra for why not the chaotic warm-up rates)."""
+    z = np.load(os.path.join(G, 'steps2.npz'))
+    wseed, tseed, N, C, H, W, iters, ep0 = [int(v) for v in z['traj/meta']]
+    n = steps.Nets(seeded_state(nets.generator_spec(C), wseed + 1), seeded_state(nets.segmentor_spec(C, 1, True), wseed + 2),
+                   seeded_state(nets.discriminator_spec(C), wseed + 3), seeded_state(nets.vgg_spec(), 4242)).make_optimizers('rsss')
+    x, y, region = seeded_tiles(tseed, N, C, H, W)
+    for it in range(iters):
+        lrS = steps.adjust_learning_rate(n.opt['S'], ep0 + it, lr_start=1e-4, lr_max=1e-3, lr_warm_up_epoch=5)
+        lrD = steps.adjust_learning_rate(n.opt['D'], ep0 + it, lr_start=5e-6, lr_max=5e-5, lr_min=5e-7, lr_warm_up_epoch=5)
+        assert [lrS, lrD] == list(z['traj/lrs'][it])                      # schedule bit-equal
+        r = steps.rsss_adversarial_step(n, x, y, region)
+        got = [float(r[k]) for k in ('d_loss', 's_loss', 's_d_loss', 'g_loss', 'l1_loss', 'r_loss', 'gen', 'ssim', 'perc')]
+        close(got, z['traj/it%d/scalars' % it], rtol=1e-6 if it == 0 else 1e-3, atol=1e-7 if it == 0 else 1e-6)
+        # density map: iteration 0 bit-exact; later the sign-like RMSprop updates of noise-level gradient elements make
+        # the two runs drift (measured here: max 6e-6 / 8e-4 / 1.8e-3 / 4.6e-3 / 5.2e-3, mean <= 7.7e-4)
+        d = np.abs(r['cmap'].detach()[:, :, ::4, ::4].numpy() - z['traj/it%d/cmap' % it])
+        assert d.max() <= (1e-7 if it == 0 else 2e-2) and d.mean() <= (1e-7 if it == 0 else 2e-3), (it, d.max(), d.mean())
+
+
+def test_checkpoint_interchange_reference_pkl():
+    """A ``.pkl`` written by the REFERENCE's Generator class (torch.save(state_dict), Demo_RSSS.py:507-514) loads with
+    strict=True into the new Generator class and into the oracle; a state_dict saved from the new classes reloads
+    bit-equal.  (The reverse load -- ours into the reference classes -- is asserted by gen_golden.py --only ckpt.)"""
+    import io
+    from fcd_gan_pytorch_amd import Module
+    sd = torch.load(os.path.join(G, 'netG_ref.pkl'))
+    zc = np.load(os.path.join(G, 'ckpt.npz'))
+    seed, N, C, H, W = [int(v) for v in zc['meta']]
+    g = Module.Generator(C)
+    g.load_state_dict(sd, strict=True)
+    assert list(g.state_dict().keys()) == list(sd.keys())
+    for k, v in g.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+    x, _, _ = seeded_tiles(seed, N, C, H, W)
+    out = nets.generator(nets.clone_state(sd, requires_grad=False), x, train=False)
+    close(out.numpy(), zc['out'])
+    for m in (g, Module.Segmentor(4, 1, True), Module.Discriminator_SRGAN_simple(4)):
+        buf = io.BytesIO()
+        torch.save(m.state_dict(), buf)          # Demo_RSSS.py:507-514
+        buf.seek(0)
+        m2 = type(m)(*((C,) if m is g else ((4, 1, True) if isinstance(m, Module.Segmentor) else (4,))))
+        m2.load_state_dict(torch.load(buf), strict=True)
+        for (k1, v1), (k2, v2) in zip(m.state_dict().items(), m2.state_dict().items()):
+            assert k1 == k2 and torch.equal(v1, v2)

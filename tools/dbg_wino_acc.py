@@ -11,7 +11,7 @@ torch.manual_seed(0)
 netS = fcd.Module.Segmentor(C, 1, True).cuda().train()
 with warnings.catch_warnings():
     warnings.simplefilter('ignore')
-    crit = fcd.Loss.CGeneratorLoss(channel=C, perception_layer=1, perception_perBand=True).cuda()
+    crit = fcd.Loss.CGeneratorLoss(channel=C, perception_layer=1, perception_perBand=True, allow_seeded=True).cuda()
 x, y, region = (t.cuda() for t in synthetic_tiles(1234, N, C, H, H))
 cmap = netS(x, y)
 yf = y + 0.05 * torch.randn(y.shape, device='cuda', generator=torch.Generator(device='cuda').manual_seed(1))
