@@ -1,0 +1,122 @@
+"""Data-parallel plumbing of the demo loops (SURVEY.md 8e "Partitioning"): one process per GPU, tiles sharded
+across ranks, no data-path collective except the gradient exchange of ``optim`` and a handful of scalars per epoch.
+
+ * :class:`RankStridedBatches` -- the batch sampler.  Every rank draws the SAME permutation of the tile indices
+   (shared per-epoch seed), cuts it into global batches of ``world * batch_size`` and takes the elements
+   ``rank, rank + world, ...`` of each.  With one rank this is exactly the reference's
+   ``DataLoader(ds, batch_size, shuffle=True)`` (Demo_RSSS.py:242, Demo_USSS.py:102, Demo_WSSS.py:208): batches of
+   ``batch_size`` and a shorter last one (the reference has no ``drop_last``).
+ * Ragged last batch under DP: every loss is a batch mean, so mean-of-local-gradients equals the global-batch
+   gradient only if all ranks hold the same number of samples.  Rule (``ragged='pad'``, default): the last global
+   batch is cut into equal local batches of ``ceil(L / world)`` samples; the (< world) missing samples are taken from
+   the head of the same permutation and flagged, so that epoch statistics and the confusion matrix can leave them
+   out.  ``ragged='drop'`` drops the ragged global batch on every rank instead.  Either way all ranks run the same
+   number of steps -- a rank that ran out of tiles early would dead-lock the next all-reduce.
+ * :func:`sync_start` -- rank 0's weights, BatchNorm buffers and optimizer-visible parameters broadcast once.
+ * :func:`mean_scalars` / :func:`sum_counts` -- the per-epoch logging reductions (<= 9 loss averages, the 2x2
+   confusion matrix: SURVEY.md 8e collective 4).
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+
+def world_info(group=None):
+    """(rank, world) of this process; (0, 1) when torch.distributed is not initialised."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+class RankStridedBatches:
+    """Batch sampler (pass as ``DataLoader(batch_sampler=...)``).  ``pads[i]`` = number of trailing padded
+    (duplicate) samples in this rank's i-th batch of the current epoch."""
+
+    def __init__(self, n, batch_size, seed=0, shuffle=True, rank=None, world=None, ragged='pad', group=None):
+        if ragged not in ('pad', 'drop'):
+            raise ValueError("ragged must be 'pad' or 'drop'")
+        r, w = world_info(group)
+        self.n, self.batch_size, self.shuffle, self.ragged = int(n), int(batch_size), shuffle, ragged
+        self.rank = r if rank is None else int(rank)
+        self.world = w if world is None else int(world)
+        self.seed = int(seed)
+        self.pads = []
+
+    def set_epoch(self, seed):
+        """Same value on every rank (e.g. ``base_seed * 1000 + epoch``)."""
+        self.seed = int(seed)
+
+    def _order(self):
+        if not self.shuffle:
+            return list(range(self.n))
+        g = torch.Generator().manual_seed(self.seed)
+        return torch.randperm(self.n, generator=g).tolist()
+
+    def _plan(self):
+        order, gb = self._order(), self.batch_size * self.world
+        batches, pads = [], []
+        full = self.n // gb
+        for b in range(full):
+            chunk = order[b * gb:(b + 1) * gb]
+            batches.append(chunk[self.rank::self.world])
+            pads.append(0)
+        rest = order[full * gb:]
+        if rest and (self.ragged == 'pad' or self.world == 1):
+            local = math.ceil(len(rest) / self.world)
+            need = local * self.world - len(rest)
+            filler = [order[i % self.n] for i in range(need)]          # head of the same permutation
+            chunk = rest + filler
+            mine = chunk[self.rank::self.world]
+            npad = sum(1 for j in range(self.rank, len(chunk), self.world) if j >= len(rest))
+            batches.append(mine)
+            pads.append(npad)
+        return batches, pads
+
+    def __iter__(self):
+        batches, self.pads = self._plan()
+        return iter(batches)
+
+    def __len__(self):
+        gb = self.batch_size * self.world
+        full, rest = divmod(self.n, gb)
+        return full + (1 if rest and (self.ragged == 'pad' or self.world == 1) else 0)
+
+
+def sync_start(nets=(), optimizers=(), src=0, group=None):
+    """Make every rank start from rank ``src``'s state: flat parameter buffers of the fcd optimizers, then every
+    remaining parameter / buffer of ``nets`` (BatchNorm running statistics, nets without an optimizer such as a
+    pre-trained Generator).  No-op on one rank."""
+    _, world = world_info(group)
+    if world <= 1:
+        return
+    owned = set()
+    for opt in optimizers:
+        opt.broadcast_state(src, group)
+        owned.update(id(p) for p in opt.params)
+    from . import _ops as ops
+    for net in nets:
+        loose = [p for p in net.parameters() if id(p) not in owned]
+        for t in loose + list(net.buffers()):
+            dist.broadcast(t.data, src, group=group)
+        if loose:
+            torch._C._increment_version(loose)
+            ops.invalidate_packs(loose)
+
+
+def mean_scalars(values, weight=1.0, group=None):
+    """Weighted mean over ranks of a 1-D tensor of per-rank averages (weight = samples the rank averaged over)."""
+    _, world = world_info(group)
+    if world <= 1:
+        return values
+    buf = torch.cat([values.detach().double() * weight, torch.tensor([float(weight)], dtype=torch.float64,
+                                                                   device=values.device)])
+    dist.all_reduce(buf, group=group)
+    return (buf[:-1] / buf[-1].clamp_min(1e-30)).to(values.dtype)
+
+
+def sum_counts(counts, group=None):
+    _, world = world_info(group)
+    if world > 1:
+        dist.all_reduce(counts, group=group)
+    return counts

@@ -9,8 +9,21 @@ Demo_WSSS.py:116-122) and the same ``param_groups[i]['lr']`` knob that
 Flat layout: at construction every parameter is re-pointed at a slice of one
 contiguous fp32 buffer, and its ``.grad`` at the matching slice of one gradient
 buffer, so (a) the optimizer step is a single kernel, (b) the data-parallel
-gradient exchange is a single RCCL all-reduce per network (``allreduce_grads``),
-with the 1/world_size scaling folded into the update kernel.
+gradient exchange works on contiguous slices of that buffer with the
+1/world_size scaling folded into the update kernel.
+
+Data-parallel exchange (collective 1): the flat gradient buffer is
+cut into buckets in REVERSE registration order (the Segmentor's decoder first:
+``up1.conv.double_conv.0.weight`` alone is 75.5 MB), and ``begin_overlap()`` arms
+per-parameter post-accumulate hooks for ONE backward pass: as soon as every
+parameter of the next bucket in line has its gradient, that slice is all-reduced
+(sum) asynchronously -- on RCCL's own stream, behind the kernels that produced
+it -- while the backward pass keeps computing the encoder's gradients.
+``allreduce_grads()`` flushes what is left and makes the compute stream wait for
+the collectives; the update kernel then divides by the world size.  Buckets are
+issued strictly in bucket order, so every rank launches the same sequence of
+collectives.  Over xGMI (point-to-point links, ring collectives per-link bound)
+few large buckets beat many small ones: default 32 MB.
 """
 import torch
 import torch.distributed as dist
@@ -42,6 +55,10 @@ class _FlatOptimizer:
         self.steps = 0
         self.grad_scale = 1.0
         self.pre_step_hooks = []
+        self.bucket_bytes = 32 << 20
+        self._buckets = None          # [(lo, hi, n_params)] over flat_g, bucket 0 = LAST parameters
+        self._armed = False
+        self.last_exchange = None     # diagnostics of the most recent exchange (tests, bench)
 
     def zero_grad(self, set_to_none=False):
         # in place: gradients must stay views of the flat buffer (re-point first, WITHOUT copying: whatever a
@@ -69,15 +86,108 @@ class _FlatOptimizer:
                 p.grad = view
             off += k
 
-    def allreduce_grads(self, group=None):
-        """Data-parallel exchange: one all-reduce(sum) of the flat gradient buffer over
-        RCCL (xGMI); the mean is applied inside the next ``step`` (grad_scale)."""
+    # ------------------------------------------------------------- data-parallel exchange
+    @staticmethod
+    def _world(group=None):
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_world_size(group)
+        return 1
+
+    def _build_buckets(self):
+        """Contiguous slices of flat_g, walking the parameters from the LAST registered one backwards (the order in
+        which a backward pass produces their gradients), closing a bucket once it holds >= bucket_bytes."""
+        offs, off = [], 0
+        for p in self.params:
+            offs.append(off)
+            off += p.numel()
+        self._param_off = offs
+        buckets, owner = [], {}
+        hi, cnt, cur = off, 0, off
+        for i in range(len(self.params) - 1, -1, -1):
+            cur = offs[i]
+            cnt += 1
+            owner[i] = len(buckets)
+            if 4 * (hi - cur) >= self.bucket_bytes or i == 0:
+                buckets.append((cur, hi, cnt))
+                hi, cnt = cur, 0
+        self._buckets, self._bucket_of = buckets, owner
+        self._index = {id(p): i for i, p in enumerate(self.params)}
+        for p in self.params:
+            if p.requires_grad and not getattr(p, '_fcd_overlap_hook', None):
+                p._fcd_overlap_hook = p.register_post_accumulate_grad_hook(self._on_grad_ready)
+
+    def begin_overlap(self, group=None):
+        """Arm the bucketed exchange for the NEXT backward pass (exactly one ``backward()`` must produce this
+        net's gradients before ``allreduce_grads``).  No-op on a single rank."""
+        self._armed = False
+        if self._world(group) <= 1:
+            return False
+        if self._buckets is None:
+            self._build_buckets()
         self._bind_grads()
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=group)
-            self.grad_scale = 1.0 / dist.get_world_size(group)
-        else:
+        self._group = group
+        self._pending = [b[2] for b in self._buckets]
+        self._next = 0
+        self._works = []
+        self._armed = True
+        return True
+
+    def _launch_ready_buckets(self, force=False):
+        while self._next < len(self._buckets) and (force or self._pending[self._next] <= 0):
+            lo, hi, _ = self._buckets[self._next]
+            self._works.append(dist.all_reduce(self.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self._group, async_op=True))
+            self._launched_early += 0 if force else 1
+            self._next += 1
+
+    def _on_grad_ready(self, p):
+        if not self._armed:
+            return
+        i = self._index[id(p)]
+        g, off = p.grad, self._param_off[i]
+        if g is None or g.data_ptr() != self.flat_g.data_ptr() + 4 * off:
+            # a gradient that did not land in the flat buffer (``.grad`` was None when backward ran): move it there
+            view = self.flat_g[off:off + p.numel()].view(p.shape)
+            if g is not None:
+                view.copy_(g)
+            p.grad = view
+        self._pending[self._bucket_of[i]] -= 1
+        self._launch_ready_buckets()
+
+    _launched_early = 0
+
+    def allreduce_grads(self, group=None):
+        """Data-parallel exchange: all-reduce(sum) of the flat gradient buffer over RCCL (xGMI); the mean is applied
+        inside the next ``step`` (grad_scale).  After ``begin_overlap`` the buckets that became ready during the
+        backward pass are already in flight: flush the rest, then make the compute stream wait for all of them.
+        Without it: one all-reduce of the whole buffer."""
+        world = self._world(group)
+        if world <= 1:
+            self._armed = False
             self.grad_scale = 1.0
+            return
+        if self._armed:
+            early = self._launched_early
+            self._launch_ready_buckets(force=True)
+            for w in self._works:
+                w.wait()                     # NCCL: stream-level wait; gloo: blocks the host
+            self.last_exchange = dict(buckets=len(self._buckets), launched_during_backward=early,
+                                      bytes=[4 * (hi - lo) for lo, hi, _ in self._buckets])
+            self._launched_early = 0
+            self._works = []
+            self._armed = False
+        else:
+            self._bind_grads()
+            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=group)
+            self.last_exchange = dict(buckets=1, launched_during_backward=0, bytes=[4 * self.flat_g.numel()])
+        self.grad_scale = 1.0 / world
+
+    def broadcast_state(self, src=0, group=None):
+        """Start-of-training weight sync (SURVEY.md 8e "weights broadcast from rank 0"): parameters as ONE flat
+        buffer; optimizer moments are zeros on every rank at that point and need no exchange."""
+        if self._world(group) > 1:
+            dist.broadcast(self.flat_p, src, group=group)
+            torch._C._increment_version(self.params)
+            ops.invalidate_packs(self.params)
 
     def _require_device(self):
         if self.flat_p.device.type != 'cuda':

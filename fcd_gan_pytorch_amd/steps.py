@@ -15,8 +15,10 @@ look).  Two modes:
     graph.  This is the "minimal-necessary" FLOP count of SURVEY.md section 8(d).
 
 Data parallelism (one process per GPU): gradients of the network being stepped
-are all-reduced (sum) over RCCL as one flat buffer and averaged inside the
-optimizer kernel; BatchNorm uses per-replica batch statistics (DDP semantics).
+are all-reduced (sum) over RCCL in buckets of its flat gradient buffer, issued from
+gradient-ready hooks while the backward pass is still running (``begin_overlap`` /
+``allreduce_grads``, optim.py), and averaged inside the optimizer kernel; BatchNorm
+uses per-replica batch statistics (DDP semantics) unless SyncBN is switched on.
 """
 import contextlib
 
@@ -59,6 +61,7 @@ def rsss_g_pretrain_step(netG, crit, optG, x, y, region, perception_weight=0.1, 
     y_fake = netG(x)
     generator_loss, ssim_loss, perception_loss = crit(y, y_fake, region)
     g_loss = generator_loss + perception_weight * perception_loss + ssim_weight * ssim_loss
+    optG.begin_overlap(group)
     g_loss.backward()
     optG.allreduce_grads(group)
     optG.step()
@@ -80,6 +83,7 @@ def rsss_adversarial_step(netS, netD, netG, crit, optS, optD, x, y, region, perc
         nc_out = netD(x * keep, y_unc * keep)
         optD.zero_grad()
         d_loss = 1 + nc_out.mean() - c_out.mean()
+        optD.begin_overlap(group)
         d_loss.backward(retain_graph=True)
     else:
         keep_d = _bcast_keep(cmask.detach(), x.shape[1])
@@ -87,6 +91,7 @@ def rsss_adversarial_step(netS, netD, netG, crit, optS, optD, x, y, region, perc
         c_out, nc_out = netD.forward_pairs([(xm_d, y * keep_d), (xm_d, y_unc * keep_d)])
         optD.zero_grad()
         d_loss = 1 + nc_out.mean() - c_out.mean()
+        optD.begin_overlap(group)
         d_loss.backward()
     optD.allreduce_grads(group)
     optD.step()
@@ -107,6 +112,7 @@ def rsss_adversarial_step(netS, netD, netG, crit, optS, optD, x, y, region, perc
     r_loss = region_loss(cmap, 1 - region, 'mse')
     s_loss = d_weight * s_d_loss + l1_weight * l1_loss + g_weight * g_loss + r_weight * r_loss
     optS.zero_grad()
+    optS.begin_overlap(group)
     s_loss.backward()
     optS.allreduce_grads(group)
     optS.step()
@@ -130,6 +136,7 @@ def wsss_adversarial_step(netS, netD, netG, crit, optS, optD, x, y, x_nc, y_nc, 
         nc_out = netD(x_nc * keep, y_nc * keep)
         optD.zero_grad()
         d_loss = 1 + nc_out.mean() - c_out.mean()
+        optD.begin_overlap(group)
         d_loss.backward(retain_graph=True)
     else:
         ncmap = netS(x_nc, y_nc)
@@ -137,6 +144,7 @@ def wsss_adversarial_step(netS, netD, netG, crit, optS, optD, x, y, x_nc, y_nc, 
         c_out, nc_out = netD.forward_pairs([(x * keep_d, y * keep_d), (x_nc * keep_d, y_nc * keep_d)])
         optD.zero_grad()
         d_loss = 1 + nc_out.mean() - c_out.mean()
+        optD.begin_overlap(group)
         d_loss.backward()
     optD.allreduce_grads(group)
     optD.step()
@@ -161,6 +169,7 @@ def wsss_adversarial_step(netS, netD, netG, crit, optS, optD, x, y, x_nc, y_nc, 
     s_d_loss = c_out.mean()
     s_loss = d_weight * s_d_loss + l1_weight * l1_loss + g_weight * g_loss + nc_weight * nc_loss
     optS.zero_grad()
+    optS.begin_overlap(group)
     s_loss.backward()
     optS.allreduce_grads(group)
     optS.step()
@@ -177,6 +186,7 @@ def usss_g_pretrain_step(netG, crit, optG, x, y, perception_weight=0.4, ssim_wei
     cmap = torch.zeros((x.shape[0], 1, x.shape[2], x.shape[3]), device=x.device)
     generator_loss, l1_loss, perception_loss, ssim_loss = crit(y, y_fake, cmap)
     loss = generator_loss + perception_weight * perception_loss + ssim_weight * ssim_loss
+    optG.begin_overlap(group)
     loss.backward()
     optG.allreduce_grads(group)
     optG.step()
@@ -196,6 +206,7 @@ def usss_s_pretrain_step(netS, netG, crit, optS, x, y, perception_weight=0.4, l1
     generator_loss, l1_loss, perception_loss, ssim_loss = crit(y, y_fake, cmap)
     net_loss = generator_loss + l1_weight * l1_loss + perception_weight * perception_loss + ssim_weight * ssim_loss
     optS.zero_grad()
+    optS.begin_overlap(group)
     net_loss.backward()
     optS.allreduce_grads(group)
     optS.step()
@@ -218,12 +229,16 @@ def usss_joint_step(netS, netG, crit, optS, optG, x, y, perception_weight=0.4, l
     if literal:
         loss.backward(retain_graph=True)
         optS.zero_grad()
+        optS.begin_overlap(group)          # G collects gradients from BOTH backward passes: exchanged afterwards
         net_loss.backward()
+        optG.allreduce_grads(group)
     else:
         optS.zero_grad()
+        optG.begin_overlap(group)
+        optS.begin_overlap(group)
         net_loss.backward()
+        optG.allreduce_grads(group)         # (waits for G's buckets before the in-place doubling)
         optG.flat_g.mul_(2.0)
-    optG.allreduce_grads(group)
     optS.allreduce_grads(group)
     optG.step()
     optS.step()

@@ -363,6 +363,7 @@ class Prefetcher:
     def __iter__(self):
         q = queue.Queue(maxsize=self.depth)
         stop = object()
+        failure = []
 
         def work():
             try:
@@ -381,6 +382,8 @@ class Prefetcher:
                         ev = torch.cuda.Event()
                         ev.record(self.stream)
                     q.put((out, ev))
+            except BaseException as e:          # surfaced in the consumer: a dying loader must not end the epoch quietly
+                failure.append(e)
             finally:
                 q.put(stop)
         th = threading.Thread(target=work, daemon=True)
@@ -391,6 +394,15 @@ class Prefetcher:
                 break
             out, ev = item
             if ev is not None:
-                torch.cuda.current_stream(self.device).wait_event(ev)
+                cur = torch.cuda.current_stream(self.device)
+                cur.wait_event(ev)
+                for d, p in out:
+                    if p is not None:
+                        # the block was allocated on the copy stream: tell the caching allocator that the consumer
+                        # stream uses it too, or it may be handed to the worker's next H2D copy while train-step
+                        # kernels queued on the main stream still read it (the step functions never sync the host)
+                        d.record_stream(cur)
             yield tuple(d for d, _ in out)
         th.join()
+        if failure:
+            raise failure[0]

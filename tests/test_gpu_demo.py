@@ -25,7 +25,7 @@ def test_demo_usss_end_to_end(tmp_path):
     tiles.write_tiff(px, t1); tiles.write_tiff(py, t2); tiles.write_tiff(pr, ref)
     logs = []
     out = demos.demo_usss(px, py, pr, patch_size=(200, 200), overlap_padding=(10, 10), epochs_g=2, epochs_s=1,
-                          epochs_joint=1, batch_size=2, out_density=str(tmp_path / 'density.tif'),
+                          epochs_joint=1, batch_size=2, allow_seeded=True, out_density=str(tmp_path / 'density.tif'),
                           out_color=str(tmp_path / 'color.tif'), log=logs.append)
     assert len(logs) == 4 and all(np.isfinite(v) for k in out['history'] for v in out['history'][k])
     assert out['history']['g'][1] < out['history']['g'][0]            # G pre-training reduces its loss
@@ -36,9 +36,8 @@ def test_demo_usss_end_to_end(tmp_path):
     # oracle: eval-mode forward per tile with the trained weights, stitched with the same geometry
     netS = out['netS']
     sd = {k: v.detach().cpu() for k, v in netS.state_dict().items()}
-    mx, sx = t1.reshape(C, -1).astype(np.float64).mean(1), t1.reshape(C, -1).astype(np.float64).std(1)
-    my, sy = t2.reshape(C, -1).astype(np.float64).mean(1), t2.reshape(C, -1).astype(np.float64).std(1)
-    ds = tiles.PairTileDataset(t1, t2, ref, (200, 200), (10, 10), stats=(mx, sx, my, sy))
+    stats = demos._tile_stats(t1, t2, (200, 200))      # Dataset_meanstd over the non-overlapped tiling (Demo_USSS.py:88-95)
+    ds = tiles.PairTileDataset(t1, t2, ref, (200, 200), (10, 10), stats=stats)
     want = np.zeros((1, H, W), np.float32)
     for item in range(len(ds)):
         x, y, _, _ = ds[item]
@@ -79,7 +78,8 @@ def test_demo_rsss_and_wsss_run_end_to_end():
                                                  overlap_padding=(10, 10)))
     ds = datasets.MultiSceneDataset(scenes)
     logs = []
-    out = demos.demo_rsss(ds, n_channels=4, epochs_g=1, epochs_adv=2, init_batch_size=2, batch_size=2, log=logs.append)
+    out = demos.demo_rsss(ds, n_channels=4, epochs_g=1, epochs_adv=2, init_batch_size=2, batch_size=2, log=logs.append,
+                          allow_seeded=True)
     assert len(logs) == 3 and np.isfinite(out['history']['adv']).all() and np.isfinite(out['history']['g']).all()
     cm = out['evaluator']._sync()
     assert cm.sum() == 210 * 230 + 200 * 200          # every scene pixel scored exactly once per epoch
@@ -90,5 +90,5 @@ def test_demo_rsss_and_wsss_run_end_to_end():
         a = torch.from_numpy(rng.standard_normal((3, 176, 176)).astype(np.float32))
         unc.append((a, a + 0.05 * torch.randn_like(a)))
     out = demos.demo_wsss(chg, unc, n_channels=3, epochs_g=1, epochs_adv=1, unc_batch_size=2, batch_size=2,
-                          log=logs.append)
+                          log=logs.append, allow_seeded=True)
     assert np.isfinite(out['history']['adv']).all() and len(out['history']['g']) == 1

@@ -130,6 +130,7 @@ def check_net(tag, which, net, opt_kind, lr, store, oracle_grads, oracle_sd, tra
             assert int(v) == int(oracle_sd[k]), (tag, which, k, int(v), int(oracle_sd[k]))
     rep['bn_running_rel_err'] = worst_bn
     _REPORT.setdefault(tag, {})[which] = rep
+    _dump_report()
     print('\n[parity %s %s] %s' % (tag, which, json.dumps(rep)))
     assert rep['flat_rel_l2'] <= FLAT_TOL, (tag, which, rep)
     assert rep['worst_tensor_rel_l2'] <= TENSOR_TOL, (tag, which, rep)
