@@ -279,6 +279,9 @@ struct WinoGemmArgs {
   int M, N, Kc, m_tiles, n_tiles, xcd_remap;
   long long a_ld, a_batch, b_ld, b_adv, b_batch;
   int stages_per_split;   // blockIdx.z = split of the reduction: stages [z * sps, min((z + 1) * sps, Kc / 32))
+  int batches, xb;        // blockIdx.y = group of xb consecutive batches (transform positions) run by ONE workgroup as a
+                          // single software pipeline: the first slabs of batch b + 1 are in flight while batch b's last
+                          // MFMAs run and its C tile is stored -- no pipeline refill per batch
 };
 
 template <int WM, int WN>      // waves along M / N, each 64 x 64: block tile (64 WM) x (64 WN)
@@ -312,14 +315,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void wino_gem
     }
   }
   const int mt = (int)(v % (unsigned)a.m_tiles), nt = (int)(v / (unsigned)a.m_tiles);
-  const int batch = blockIdx.y;
   const int m0 = mt * BM, n0 = nt * BN;
   const int q_all = a.Kc / KC;
   const int q_beg = (int)blockIdx.z * a.stages_per_split;
-  const int Q = min(a.stages_per_split, q_all - q_beg);      // pipeline stages of this block
+  const int Q = min(a.stages_per_split, q_all - q_beg);      // pipeline stages per batch of this block
+  const int b_first = (int)blockIdx.y * a.xb;
+  const int nb = min(a.xb, a.batches - b_first);             // batches of this block
+  const int S = nb * Q;                                      // stages of the whole pipeline
   // 64-bit part of the addresses in the (scalar) bases, the per-lane offsets stay 32-bit
-  const float* Ab = a.A + (size_t)batch * a.a_batch + (size_t)q_beg * KC + (size_t)m0 * a.a_ld;
-  const float* Bb = a.B + (size_t)batch * a.b_batch + (size_t)q_beg * a.b_adv + (size_t)n0 * a.b_ld;
+  const float* Ab = a.A + (size_t)b_first * a.a_batch + (size_t)q_beg * KC + (size_t)m0 * a.a_ld;
+  const float* Bb = a.B + (size_t)b_first * a.b_batch + (size_t)q_beg * a.b_adv + (size_t)n0 * a.b_ld;
 
   int a_goff[PPW_A], b_goff[PPW_B];
 #pragma unroll
@@ -355,20 +360,25 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void wino_gem
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-#define WG_DMA(QC, SA, SB)                                                                       \
+  // fq / fb: chunk and batch of the NEXT slab pair to fetch.  The prefetch runs one stage ahead of the MFMAs and does
+  // not stop at a batch boundary: while the last chunk of batch b is multiplied and its C tile stored, chunk 0 of batch
+  // b + 1 is already in flight.  (Launcher guarantees an even Q whenever nb > 1, so every batch starts on stage 0.)
+  int fq = 0, fb = 0;
+#define WG_DMA(SA, SB)                                                                           \
   {                                                                                              \
-    const float* as_ = Ab + (size_t)(QC) * KC;                                                   \
-    const float* bs_ = Bb + (size_t)(QC) * a.b_adv;                                              \
+    const float* as_ = Ab + (size_t)fb * a.a_batch + (size_t)fq * KC;                            \
+    const float* bs_ = Bb + (size_t)fb * a.b_batch + (size_t)fq * a.b_adv;                       \
     _Pragma("unroll") for (int j = 0; j < PPW_A; ++j)                                            \
       __builtin_amdgcn_global_load_lds((gbl_void_t*)(as_ + a_goff[j]),                           \
                                        (lds_void_t*)((SA) + (wave + NW * j) * 256), 16, 0, 0);   \
     _Pragma("unroll") for (int j = 0; j < PPW_B; ++j)                                            \
       __builtin_amdgcn_global_load_lds((gbl_void_t*)(bs_ + b_goff[j]),                           \
                                        (lds_void_t*)((SB) + (wave + NW * j) * 256), 16, 0, 0);   \
+    if (++fq == Q) { fq = 0; ++fb; }                                                             \
   }
-#define WG_STEP(QC, SA, SB, SAN, SBN)                                                            \
+#define WG_STEP(SA, SB, SAN, SBN)                                                                \
   {                                                                                              \
-    if (!(FCD_GEXP & 1)) if ((QC) + 1 < Q) WG_DMA((QC) + 1, SAN, SBN)                            \
+    if (!(FCD_GEXP & 1)) if (fb < nb) WG_DMA(SAN, SBN)                                           \
     _Pragma("unroll") for (int j4 = 0; j4 < UH; ++j4) {                                          \
       f32x4 av[2], bv[2];                                                                        \
       _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                            \
@@ -383,28 +393,34 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void wino_gem
     if (!(FCD_GEXP & 4)) __syncthreads();                                                        \
   }
 
-  WG_DMA(0, sa0, sb0)
+  WG_DMA(sa0, sb0)
   __syncthreads();
-  for (int qc = 0; qc < Q; qc += 2) {
-    WG_STEP(qc, sa0, sb0, sa1, sb1)
-    if (qc + 1 < Q) WG_STEP(qc + 1, sa1, sb1, sa0, sb0)
+#pragma unroll 1
+  for (int cb = 0; cb < nb; ++cb) {
+    for (int qc = 0; qc < Q; qc += 2) {
+      WG_STEP(sa0, sb0, sa1, sb1)
+      if (qc + 1 < Q) WG_STEP(sa1, sb1, sa0, sb0)
+    }
+    // (the row pitch goes through an opaque copy: otherwise the 64 store offsets are hoisted out of the batch loop
+    // and held in registers across the MFMA loop -- +50 VGPRs and 60 spilled SGPRs)
+    int ldc = a.N;
+    asm volatile("" : "+s"(ldc));
+    float* Cb = a.C + ((size_t)blockIdx.z * a.batches + (b_first + cb)) * a.M * ldc;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int n = n0 + wn * 64 + j * 32 + l31;
+          if (m < a.M && n < ldc) Cb[(size_t)m * ldc + n] = acc[i][j][r];
+          acc[i][j][r] = 0.f;
+        }
+      }
   }
 #undef WG_STEP
 #undef WG_DMA
-
-  float* Cb = a.C + ((size_t)blockIdx.z * gridDim.y + batch) * a.M * a.N;
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (m >= a.M) continue;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + l31;
-        if (n < a.N) Cb[(size_t)m * a.N + n] = acc[i][j][r];
-      }
-    }
 }
 
 static int wino_gemm_cfg() {     // FCD_WINO_TILE: 0 = 128x128 (4 waves), 1 = 256x128 (8 waves), 2 = 256x256 (16 waves)
@@ -416,27 +432,49 @@ static int wino_gemm_cfg() {     // FCD_WINO_TILE: 0 = 128x128 (4 waves), 1 = 25
   return v;
 }
 
+// Batches (transform positions) per workgroup.  The per-batch pipeline is only Kc / 32 stages long (2 ... 16 for the VGG
+// layers), so its fill and the C-tile store are a large share of a workgroup's life; chaining xb batches into one
+// pipeline pays them once.  Keep >= ~4 full rounds of the 512 resident workgroup slots (256 CUs x 2) so that the
+// tail stays small.  FCD_WINO_XB forces a value (1 = one batch per workgroup, the round-1 behaviour).
+static int wino_gemm_xb(long long tiles, int batches, int splits, int q_stages) {
+  static int forced = -1;
+  if (forced < 0) {
+    const char* e = getenv("FCD_WINO_XB");
+    forced = e ? atoi(e) : 0;
+  }
+  if (forced > 0) return std::min(forced, batches);
+  if (q_stages & 1) return 1;          // the two LDS stages alternate: a batch must start on stage 0
+  static const int cand[] = {36, 18, 12, 9, 6, 4, 3, 2};
+  for (int xb : cand) {
+    if (batches % xb) continue;
+    if (tiles * (batches / xb) * splits >= 2048) return xb;
+  }
+  return 1;
+}
+
 static void wino_gemm_launch(WinoGemmArgs ga, int batches, int splits, hipStream_t st) {
   int cfg = wino_gemm_cfg();
   if (cfg == 2 && (ga.M < 256 || ga.N < 256)) cfg = 1;
   if (cfg == 1 && ga.M < 256) cfg = 0;
-  if (ga.M <= 64) {        // 64-row GEMMs: 64 x 256 tiles, no wasted MFMA rows
-    ga.m_tiles = 1; ga.n_tiles = cdiv(ga.N, 256);
-    hipLaunchKernelGGL((wino_gemm_kernel<1, 4>), dim3((unsigned)(ga.m_tiles * ga.n_tiles), (unsigned)batches, (unsigned)splits),
-                       dim3(256), 0, st, ga);
-  } else if (cfg == 2) {
-    ga.m_tiles = cdiv(ga.M, 256); ga.n_tiles = cdiv(ga.N, 256);
-    hipLaunchKernelGGL((wino_gemm_kernel<4, 4>), dim3((unsigned)(ga.m_tiles * ga.n_tiles), (unsigned)batches, (unsigned)splits),
-                       dim3(1024), 0, st, ga);
-  } else if (cfg == 1) {
-    ga.m_tiles = cdiv(ga.M, 256); ga.n_tiles = cdiv(ga.N, 128);
-    hipLaunchKernelGGL((wino_gemm_kernel<4, 2>), dim3((unsigned)(ga.m_tiles * ga.n_tiles), (unsigned)batches, (unsigned)splits),
-                       dim3(512), 0, st, ga);
-  } else {
-    ga.m_tiles = cdiv(ga.M, 128); ga.n_tiles = cdiv(ga.N, 128);
-    hipLaunchKernelGGL((wino_gemm_kernel<2, 2>), dim3((unsigned)(ga.m_tiles * ga.n_tiles), (unsigned)batches, (unsigned)splits),
-                       dim3(256), 0, st, ga);
+  ga.batches = batches;
+#define WG_LAUNCH(WM_, WN_, BM_, BN_, THREADS_)                                                              \
+  {                                                                                                          \
+    ga.m_tiles = cdiv(ga.M, BM_); ga.n_tiles = cdiv(ga.N, BN_);                                              \
+    ga.xb = splits > 1 ? 1 : wino_gemm_xb((long long)ga.m_tiles * ga.n_tiles, batches, splits, ga.Kc / 32);                               \
+    hipLaunchKernelGGL((wino_gemm_kernel<WM_, WN_>),                                                         \
+                       dim3((unsigned)(ga.m_tiles * ga.n_tiles), (unsigned)cdiv(batches, ga.xb), (unsigned)splits), \
+                       dim3(THREADS_), 0, st, ga);                                                           \
   }
+  if (ga.M <= 64) {        // 64-row GEMMs: 64 x 256 tiles, no wasted MFMA rows
+    WG_LAUNCH(1, 4, 64, 256, 256)
+  } else if (cfg == 2) {
+    WG_LAUNCH(4, 4, 256, 256, 1024)
+  } else if (cfg == 1) {
+    WG_LAUNCH(4, 2, 256, 128, 512)
+  } else {
+    WG_LAUNCH(2, 2, 128, 128, 256)
+  }
+#undef WG_LAUNCH
 }
 
 // --------------------------------------------------------------------------------------------

@@ -74,7 +74,17 @@ def test_two_rank_step_equals_full_batch():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, backend, q)) for r in range(2)]
     for pr in procs:
         pr.start()
-    res = dict(q.get(timeout=900) for _ in range(2))
+    import queue as _queue
+    import time
+    res, t0 = {}, time.time()
+    while len(res) < 2:
+        try:
+            rank, out = q.get(timeout=5)
+            res[rank] = out
+        except _queue.Empty:
+            dead = [pr.exitcode for pr in procs if pr.exitcode not in (None, 0)]
+            assert not dead, 'a rank died (exit codes %s) -- see its traceback above' % dead
+            assert time.time() - t0 < 600, 'two-rank step did not finish in 10 minutes'
     for pr in procs:
         pr.join(120)
         assert pr.exitcode == 0
