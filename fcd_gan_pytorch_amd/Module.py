@@ -158,6 +158,36 @@ class Segmentor(nn.Module):
     def forward(self, x1, x2):
         n = x1.shape[0]
         f = self.inc(torch.cat([x1, x2], dim=0), groups=2)      # both temporal branches in one batch
+        return self._after_inc(f, n)
+
+    @torch.no_grad()
+    def forward_raw(self, x1_raw, x2_raw, valid, stats):
+        """Inference on RAW (un-normalised) tiles: the per-band ``(x - mean) / std`` of NORMALIZE (CommonFunc.py:199-224)
+        is folded into the first convolution instead of being a pass of its own.  ``stats`` = (meanX, stdX, meanY,
+        stdY); ``valid`` (N,1,H,W) = 1 where the patch holds scene pixels (the reference embeds the NORMALISED block
+        in a zero patch, data_utils.py:106-116, so padding is 0 in normalised space, i.e. ``mean`` in raw space).
+
+        Exact at the borders: the input gets one extra channel holding ``valid`` whose filter taps are
+        ``-sum_c w[k][c][r][s] * mean_c / std_c``, the band filters are divided by ``std_c``.  The convolution's own
+        zero padding zeroes that channel too, so every tap contributes ``w * (x - mean) / std`` inside the scene and
+        0 outside -- the same sum as the reference's, up to fp32 rounding of the re-associated products.
+        eval() + folded BatchNorm only (the Demo_RSSS / Demo_USSS inference path)."""
+        if self.training:
+            raise RuntimeError('Segmentor.forward_raw is the eval-mode inference path (call .eval() first)')
+        (w0, b0), (w1, b1) = self.inc._folded_params()
+        n = x1_raw.shape[0]
+        feats = []
+        for x, mean, std in ((x1_raw, stats[0], stats[1]), (x2_raw, stats[2], stats[3])):
+            m = torch.as_tensor(mean, dtype=torch.float64, device=w0.device)[:w0.shape[1]]
+            s = torch.as_tensor(std, dtype=torch.float64, device=w0.device)[:w0.shape[1]]
+            wd = w0.double()
+            w_aug = torch.cat([wd / s.view(1, -1, 1, 1), -(wd * (m / s).view(1, -1, 1, 1)).sum(dim=1, keepdim=True)], dim=1)
+            xa = torch.cat([x, valid.to(x.dtype)], dim=1)
+            feats.append(ops.conv2d(xa, w_aug.float().contiguous(), b0, 1, 1, relu=True))
+        f = ops.conv2d(torch.cat(feats, dim=0), w1, b1, 1, 1, relu=True)
+        return self._after_inc(f, n)
+
+    def _after_inc(self, f, n):
         skips = [self._pair(f, n)]
         for stage in (self.down1, self.down2, self.down3, self.down4):
             f = stage(f, groups=2)

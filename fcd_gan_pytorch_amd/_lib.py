@@ -87,6 +87,7 @@ _SIGS = {
     'fcd_upsample2x_bwd': (c_int, [P, P, c_int, c_int, c_int, P]),
     'fcd_avgpool2_pad_fwd': (c_int, [P, P, c_int, c_int, c_int, P]),
     'fcd_avgpool2_pad_bwd': (c_int, [P, P, c_int, c_int, c_int, P]),
+    'fcd_normalize_tiles': (c_int, [P, P, P, P, P, c_int, c_int, c_int, P]),
     'fcd_masked_recon_ws_bytes': (c_size_t, [c_int]),
     'fcd_masked_recon_fwd': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     'fcd_masked_recon_bwd': (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),

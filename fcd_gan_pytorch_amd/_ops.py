@@ -463,6 +463,22 @@ def avgpool2_pad(x):
     return _AvgPool2Pad.apply(x)
 
 
+@torch.no_grad()
+def normalize_tiles(x, mean, std, valid=None, out=None):
+    """Per-band ``(x - mean) / std`` of raw (N,C,H,W) tiles on the device, zero outside ``valid`` (N,1,H,W);
+    fp64 per element -- bit-identical to the reference's host normalisation (CommonFunc.py:199-224)."""
+    x = _dev(x, 'raw tiles')
+    N, C, H, W = x.shape
+    m = torch.as_tensor(mean, dtype=torch.float64, device=x.device).contiguous()
+    s = torch.as_tensor(std, dtype=torch.float64, device=x.device).contiguous()
+    if m.numel() < C or s.numel() < C:
+        raise _lib.FcdError("normalize_tiles: The input channel doesn't match the stats list")   # CommonFunc.py:212
+    v = _dev(valid, 'valid mask') if valid is not None else None
+    out = torch.empty_like(x) if out is None else out
+    check(lib.fcd_normalize_tiles(_p(x), _p(v), _p(m), _p(s), _p(out), N, C, H * W, _stream()), 'fcd_normalize_tiles')
+    return out
+
+
 # ------------------------------------------------------------------------ losses
 class _MaskedSums(torch.autograd.Function):
     """out[2N] = {num[n], wsum[n]} of include/fcdgan_hip.h:fcd_masked_recon_fwd."""

@@ -270,3 +270,32 @@ extern "C" int fcd_avgpool2_pad_bwd(const float* dy, float* dx, int NC, int H, i
   FCD_LAUNCH_CHECK("avgpool2_pad_bwd");
   return FCD_OK;
 }
+
+// ---------------------------------------------------------------------------
+// Per-band normalisation of raw tiles (NORMALIZE, CommonFunc.py:199-224, applied by the reference on the HOST to the
+// float64 read block before it is embedded in the zero patch, data_utils.py:106-116): out = float((double(x) - mean_c)
+// / std_c) inside the valid window, 0 outside.  fp64 arithmetic per element => bit-identical to the reference's
+// float32 tensors; one pass, HBM-bound.
+__global__ void normalize_tiles_kernel(const float* __restrict__ x, const float* __restrict__ valid,
+                                       const double* __restrict__ mean, const double* __restrict__ stdv,
+                                       float* __restrict__ out, int C, long long HW, long long total) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long pl = i / HW;
+    const int c = (int)(pl % C);
+    const long long n = pl / C;
+    const float v = valid ? valid[n * HW + (i - pl * HW)] : 1.f;
+    out[i] = v != 0.f ? (float)(((double)x[i] - mean[c]) / stdv[c]) : 0.f;
+  }
+}
+
+extern "C" int fcd_normalize_tiles(const float* x, const float* valid, const double* mean, const double* stdv,
+                                   float* out, int N, int C, int HW, void* stream) {
+  FCD_CHECK_ARG(x && mean && stdv && out && N > 0 && C > 0 && HW > 0, "fcd_normalize_tiles: bad arguments");
+  const long long total = (long long)N * C * HW;
+  FcdProfScope prof(FCD_K_POOL, (hipStream_t)stream, 0.0, 8.0 * total);
+  hipLaunchKernelGGL(normalize_tiles_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, valid, mean,
+                     stdv, out, C, (long long)HW, total);
+  FCD_LAUNCH_CHECK("normalize_tiles");
+  return FCD_OK;
+}

@@ -257,6 +257,14 @@ def infer_density(netS, x, y, prob_thresh=0.5):
     return cmap, (cmap > prob_thresh)
 
 
+@torch.no_grad()
+def infer_density_raw(netS, x_raw, y_raw, valid, stats, prob_thresh=0.5):
+    """``infer_density`` on raw tiles: NORMALIZE (CommonFunc.py:199-224) folded into the first convolution
+    (``Segmentor.forward_raw``) -- no normalisation pass on the host or the device."""
+    cmap = netS.forward_raw(x_raw, y_raw, valid, stats)
+    return cmap, (cmap > prob_thresh)
+
+
 # ------------------------------------------------------- on-device confusion matrix
 def confusion_counts(cmap, ref_changed, prob_thresh=0.5, group=None):
     """2x2 confusion counts of the thresholded map vs. a {0,1} reference on device

@@ -251,6 +251,25 @@ class PairTileDataset(torch.utils.data.Dataset):
             a[b] = (a[b] - mean[b]) / std[b]
         return a
 
+    def raw_item(self, item):
+        """The patch WITHOUT host normalisation: ``(x_raw, y_raw, item, ref, valid)`` with ``valid`` (1,py,px) = 1 on
+        the window that holds scene pixels.  Normalise on the device (``_ops.normalize_tiles``: one fused pass, fp64 per
+        element, bit-identical to ``__getitem__``) or not at all (``Segmentor.forward_raw`` folds the statistics into
+        its first convolution)."""
+        _, (rx, ry, rw, rh), (wx, wy, ww, wh) = self.grid.slices(item)
+        px, py = self.grid.patch_size
+        cx = np.zeros((self.x.shape[0], py, px), dtype=np.float32)
+        cy = np.zeros_like(cx)
+        cx[:, wy:wy + wh, wx:wx + ww] = self.x[:, ry:ry + rh, rx:rx + rw]
+        cy[:, wy:wy + wh, wx:wx + ww] = self.y[:, ry:ry + rh, rx:rx + rw]
+        r = np.zeros((1, py, px), dtype=np.float32)
+        if self.ref is not None:
+            r[:, wy:wy + wh, wx:wx + ww] = self.ref[:, ry:ry + rh, rx:rx + rw]
+        valid = np.zeros((1, py, px), dtype=np.float32)
+        valid[:, wy:wy + wh, wx:wx + ww] = 1.0
+        return (torch.from_numpy(cx), torch.from_numpy(cy), torch.tensor(item), torch.from_numpy(r),
+                torch.from_numpy(valid))
+
     def __getitem__(self, item):
         _, (rx, ry, rw, rh), (wx, wy, ww, wh) = self.grid.slices(item)
         bx = np.array(self.x[:, ry:ry + rh, rx:rx + rw], dtype=float)
@@ -268,6 +287,19 @@ class PairTileDataset(torch.utils.data.Dataset):
             r[:, wy:wy + wh, wx:wx + ww] = self.ref[:, ry:ry + rh, rx:rx + rw]
         return (torch.from_numpy(cx).float(), torch.from_numpy(cy).float(), torch.tensor(item),
                 torch.from_numpy(r).float())
+
+
+class RawTiles(torch.utils.data.Dataset):
+    """View of a PairTileDataset that yields ``raw_item`` tuples (normalisation left to the device)."""
+
+    def __init__(self, ds):
+        self.ds, self.grid, self.ref, self.stats = ds, ds.grid, ds.ref, ds.stats
+
+    def __len__(self):
+        return len(self.ds)
+
+    def __getitem__(self, item):
+        return self.ds.raw_item(item)
 
 
 # ------------------------------------------------------------------------ dataset statistics

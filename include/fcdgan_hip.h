@@ -197,6 +197,13 @@ int fcd_upsample2x_bwd(const float* dy, float* dx, int NC, int H, int W, void* s
 int fcd_avgpool2_pad_fwd(const float* x, float* y, int NC, int H, int W, void* stream);
 int fcd_avgpool2_pad_bwd(const float* dy, float* dx, int NC, int H, int W, void* stream);
 
+/* ---- raw-tile normalisation (NORMALIZE, CommonFunc.py:199-224, as GDALDataset applies it: data_utils.py:106-116)
+ * out[n][c] = float((double(x[n][c]) - mean[c]) / std[c]) where valid[n] != 0, else 0.  x, out: N*C*HW floats;
+ * valid: N*HW floats (the window of the patch that holds scene pixels) or NULL; mean, std: C doubles on the device.
+ * fp64 per element: bit-identical to the reference's host-side float64 arithmetic followed by .float(). */
+int fcd_normalize_tiles(const float* x, const float* valid, const double* mean, const double* stdv, float* out,
+                        int N, int C, int HW, void* stream);
+
 /* ---- loss terms ------------------------------------------------------------
  * Masked per-sample sums -- the reconstruction terms of Loss.py:76-84 (L1) and
  * :110-119 (MSE), and region_loss Loss.py:127-141:
