@@ -362,13 +362,18 @@ def main():
             tpath = os.path.join(ROOT, 'profiles', 'r02_hbm_traffic.json')
             if os.path.exists(tpath) and args.workload == 'rsss' and args.batch == 8 and args.bands == 13 and args.size == 256:
                 with open(tpath) as f:
-                    tj = json.load(f)
+                    tj = json.load(f).get('families', {})
+                alg = {'wino_gemm': wgemm['bytes'] / max(wgemm['launches'], 1),
+                       'conv_igemm': (fwd['bytes'] + dg['bytes']) / max(fwd['launches'] + dg['launches'], 1)}
                 for e in cands:
                     key = 'wino_gemm' if e['kernel'].startswith('wino_gemm') else ('conv_igemm' if e['kernel'].startswith('conv_igemm') else None)
                     if key and key in tj:
                         e['traffic'] = tj[key]['hbm_bytes_per_launch']
-                        e['traffic_unit'] = 'HBM bytes per launch (PMC FETCH_SIZE + WRITE_SIZE with the gfx950 corrections of MI355X_MICROARCH.md, profiles/r02_hbm_traffic.json)'
-                        e['algorithmic_bytes_per_launch'] = tj[key].get('algorithmic_bytes_per_launch')
+                        e['traffic_unit'] = ('HBM bytes per launch: PMC FETCH_SIZE x %.2f + WRITE_SIZE x %.2f (factors calibrated in the same '
+                                             'session on known 2 GiB streams in the kernel\'s access pattern, profiles/r02_hbm_traffic.json)'
+                                             % (tj[key]['fetch_factor'] or 1.0, tj[key]['write_factor'] or 1.0))
+                        e['algorithmic_bytes_per_launch'] = alg[key]
+                        e['traffic_over_algorithmic'] = e['traffic'] / alg[key] if alg[key] else None
             if wf['launches'] + wd['launches'] > 0:
                 wms, wfl = wf['ms'] + wd['ms'], wf['flops'] + wd['flops']
                 from fcd_gan_pytorch_amd import _lib as _l

@@ -83,8 +83,31 @@ def wino_weight(weight, mode, m):
     return U
 
 
+def wino2_weight(weight, mode):
+    """Filters transformed and packed for the fused F(2x2,3x3) kernel (fcd_conv_wino2_pack), cached like
+    :func:`packed_weight`."""
+    cache = weight.__dict__.setdefault('_fcd_pack', {})
+    ver = weight._version
+    key = ('wino2', mode)
+    hit = cache.get(key)
+    if hit is not None and hit[0] == ver and hit[1].device == weight.device:
+        return hit[1]
+    K, C = weight.shape[:2]
+    U = torch.empty(lib.fcd_conv_wino2_filter_elems(K, C, mode), dtype=torch.float32, device=weight.device)
+    w = weight.detach().contiguous()
+    check(lib.fcd_conv_wino2_pack(_p(w), _p(U), K, C, mode, _stream()), 'fcd_conv_wino2_pack')
+    cache[key] = (ver, U)
+    return U
+
+
 def _fwd_conv(d, x, weight, bias, y, relu, pool_y=None, code=None):
-    """Forward launch: Winograd path when the library plans one for this layer, else direct."""
+    """Forward launch: fused F(2x2) kernel for the 64-row layers, three-kernel F(4x4) for the wide ones when the
+    library plans them so, else direct."""
+    if lib.fcd_conv_wino2_plan(ctypes.byref(d), 0):
+        check(lib.fcd_conv2d_fwd_wino2(ctypes.byref(d), _p(x), _p(wino2_weight(weight, 0)), _p(bias), _p(y),
+                                       ACT_RELU if relu else ACT_NONE, None, 0.0, None, _p(pool_y), _p(code), _stream()),
+              'fcd_conv2d_fwd_wino2')
+        return
     m = lib.fcd_conv_wino_plan(ctypes.byref(d), 0)
     if m:
         ws = _ws(lib.fcd_conv_wino_ws_bytes(ctypes.byref(d), 0), x.device)
@@ -99,6 +122,10 @@ def _fwd_conv(d, x, weight, bias, y, relu, pool_y=None, code=None):
 
 
 def _bwd_data_conv(d, dy, weight, dx, yrelu=None, code=None):
+    if lib.fcd_conv_wino2_plan(ctypes.byref(d), 1):
+        check(lib.fcd_conv2d_bwd_data_wino2(ctypes.byref(d), _p(dy), _p(yrelu), _p(code), _p(wino2_weight(weight, 1)), _p(dx),
+                                            _stream()), 'fcd_conv2d_bwd_data_wino2')
+        return
     m = lib.fcd_conv_wino_plan(ctypes.byref(d), 1)
     if m:
         ws = _ws(lib.fcd_conv_wino_ws_bytes(ctypes.byref(d), 1), dy.device)
@@ -110,6 +137,17 @@ def _bwd_data_conv(d, dy, weight, dx, yrelu=None, code=None):
     else:
         check(lib.fcd_conv2d_bwd_data(ctypes.byref(d), _p(dy), _p(yrelu), _p(packed_weight(weight, 1)), _p(dx),
                                       _stream()), 'fcd_conv2d_bwd_data')
+
+
+def _grad_out(param, shape, device):
+    """Where a parameter gradient should be written: the parameter's slice of its fcd optimizer's flat gradient buffer
+    when that is allowed (optim._FlatOptimizer.grad_slot), else a new tensor."""
+    slot = getattr(param, '_fcd_slot', None) if param is not None else None
+    if slot is not None:
+        view = slot[0].grad_slot(param)
+        if view is not None and view.device == device and tuple(view.shape) == tuple(shape):
+            return view
+    return torch.empty(shape, dtype=torch.float32, device=device)
 
 
 def invalidate_packs(params):
@@ -144,6 +182,7 @@ class _Conv2d(torch.autograd.Function):
         # x is only needed for the weight gradient; the fused-ReLU output doubles as the backward mask
         ctx.save_for_backward(x if weight.requires_grad else None, weight, (y if relu and bits is None else None), bits)
         ctx.geom = (stride, pad, bias is not None, tuple(x.shape))
+        ctx.bias_param = bias
         return y
 
     @staticmethod
@@ -162,9 +201,9 @@ class _Conv2d(torch.autograd.Function):
                 _bwd_data_conv(d, dy, weight, dx, yrelu=yrelu)
         want_db = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            dw = torch.empty(weight.shape, dtype=torch.float32, device=dy.device)
+            dw = _grad_out(weight, weight.shape, dy.device)
             if want_db:        # channel sums come out of the dy re-layout pass of the weight gradient
-                db = torch.empty((d.K,), dtype=torch.float32, device=dy.device)
+                db = _grad_out(ctx.bias_param, (d.K,), dy.device)
             ws = _ws(lib.fcd_conv2d_bwd_weight_ws_bytes(ctypes.byref(d)), dy.device)
             check(lib.fcd_conv2d_bwd_weight_bias(ctypes.byref(d), _p(x), _p(dy), _p(yrelu), _p(dw), _p(db), _p(ws),
                                                  ws.numel(), _stream()), 'fcd_conv2d_bwd_weight_bias')
@@ -185,10 +224,14 @@ def conv2d_infer(x, weight, bias, stride=1, padding=0, act=ACT_NONE, slope=None,
     x = _dev(x, 'conv input')
     d = _desc(x.shape, weight.shape, int(stride), int(padding))
     y = torch.empty((d.N, d.K, d.P, d.Q), dtype=torch.float32, device=x.device)
-    wp = packed_weight(weight, 0)
     res = _dev(residual, 'residual') if residual is not None else None
     if res is not None and res.shape != y.shape:
         raise _lib.FcdError('conv2d_infer: residual shape %s != output shape %s' % (tuple(res.shape), tuple(y.shape)))
+    if lib.fcd_conv_wino2_plan(ctypes.byref(d), 0):
+        check(lib.fcd_conv2d_fwd_wino2(ctypes.byref(d), _p(x), _p(wino2_weight(weight, 0)), _p(bias), _p(y), act, _p(slope),
+                                       float(slope_imm), _p(res), None, None, _stream()), 'fcd_conv2d_fwd_wino2')
+        return y
+    wp = packed_weight(weight, 0)
     check(lib.fcd_conv2d_fwd_ex(ctypes.byref(d), _p(x), _p(wp), _p(bias), _p(y), act, _p(slope), float(slope_imm),
                                 _p(res), _stream()), 'fcd_conv2d_fwd_ex')
     return y
@@ -270,7 +313,7 @@ class _ConvT2x2(torch.autograd.Function):
             wp = packed_weight(weight, 0)
             check(lib.fcd_conv2d_fwd(ctypes.byref(d), _p(dy), _p(wp), None, _p(dx), 0, _stream()), 'convT bwd data')
         if ctx.needs_input_grad[1]:
-            dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
+            dw = _grad_out(weight, weight.shape, x.device)
             ws = _ws(lib.fcd_conv2d_bwd_weight_ws_bytes(ctypes.byref(d)), x.device)
             check(lib.fcd_conv2d_bwd_weight(ctypes.byref(d), _p(dy), _p(x), None, _p(dw), _p(ws), ws.numel(), _stream()),
                   'convT bwd weight')
@@ -364,16 +407,14 @@ class _BnAct(torch.autograd.Function):
                                            ws.numel(), _stream()), 'fcd_bn_bwd_from_sums')
             return dx, dgamma, dbeta, dslope, None, None, None, None, None, None, None, None
         if has_bn and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
-            dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
-            dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+            dgamma = _grad_out(gamma, (C,), x.device)
+            dbeta = _grad_out(beta, (C,), x.device)
         if slope is not None and ctx.needs_input_grad[3]:
-            dslope = torch.empty(1, dtype=torch.float32, device=x.device)
+            dslope = _grad_out(slope, tuple(slope.shape), x.device)
         check(lib.fcd_bn_act_bwd(_p(dz), _p(x), _p(dx), N, C, H * W, groups, int(has_bn), _p(gamma), _p(beta),
                                  _p(running_mean), _p(running_var), eps, int(training), _p(save_mean),
                                  _p(save_invstd), act, _p(slope), slope_imm, _p(dgamma), _p(dbeta), _p(dslope),
                                  _p(ws), ws.numel(), _stream()), 'fcd_bn_act_bwd')
-        if dslope is not None:
-            dslope = dslope.view(slope.shape)
         return dx, dgamma, dbeta, dslope, None, None, None, None, None, None, None, None
 
 

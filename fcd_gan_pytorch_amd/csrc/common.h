@@ -47,7 +47,9 @@ enum {
   FCD_K_WINO_GEMM = 11, // nested in 9/10: the batched MFMA GEMM alone (FLOPs = executed GEMM FLOPs)
   FCD_K_WINO_XFORM = 12,// nested in 9/10: input + output transform kernels (bytes streamed)
   FCD_K_WGRAD_WINO = 13,// nested in 2: weight-gradient calls that take the Winograd form (FLOPs = direct count)
-  FCD_K_COUNT = 14
+  FCD_K_WINO2_FWD = 14, // fused Winograd F(2x2,3x3) kernel (64-row layers), forward; FLOPs = direct count (executed: x 16/36)
+  FCD_K_WINO2_DGRAD = 15,
+  FCD_K_COUNT = 16
 };
 
 struct FcdProfScope {

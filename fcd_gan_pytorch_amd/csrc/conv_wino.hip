@@ -593,6 +593,8 @@ static int wino_env() {
   return g_wino_mode;
 }
 
+int fcd_wino_mode_now() { return wino_env(); }   // conv_wino2.hip: the fused F(2x2) kernel follows the same switch
+
 // 0 = direct kernels only, 2 / 4 = Winograd tile size for the planned layers; returns the previous value.
 // (Filters packed for another tile size stay valid: packs are keyed by m.)
 extern "C" int fcd_conv_wino_set(int m) {

@@ -1,0 +1,417 @@
+// Fused Winograd F(2x2, 3x3) convolution for the 64-row layers (3x3 / stride 1 / pad 1 with <= 64 GEMM rows: VGG
+// conv1_2 forward + data gradient, the data gradient of conv2_1, the Generator's eleven 64 -> 64 layers, the second
+// conv of the Segmentor's first stage).  For these the three-kernel F(4x4) form loses -- with only 64 rows the
+// transformed activations V / products M (2.25x the tensors each) cost more HBM time than the 4x smaller GEMM saves
+// (measured: 10.8 ms vs 8.3 ms direct on conv1_2) -- and the direct kernel sits at 0.79 of the fp32 MFMA peak with
+// nothing left but its FLOP count.  Here ONE kernel does input transform, the 16 batched GEMMs and the output
+// transform, so V and M never exist in memory: the FLOP count drops 2.25x (16 multiplies per 2x2 output tile and
+// channel pair instead of 36) at the direct kernel's HBM traffic (x read once + halo, y written once).
+//
+//   y_tile = A^T [ sum_c (G g_kc G^T) .* (B^T d_c B) ] A        4x4 patch d -> 2x2 outputs, 16 positions xi
+//
+// Why this shape works where a fused F(4x4) does not: with v_mfma_f32_16x16x4_f32 a lane's B operand is ONE float
+// = V_xi[channel kc][tile n] and its A operand ONE float = U_xi[row][channel kc].  A lane therefore needs, per
+// 4-channel chunk, all 16 xi of ITS (tile, channel): exactly the B^T d B of the 4x4 patch it reads from LDS with eight
+// ds_read_b64 -- 32 VALU adds for 16 MFMA operands (2 per MFMA, 0.5 LDS instructions per MFMA), no cross-lane
+// traffic.  The 16 accumulators of a (row, tile) end up in ONE lane (C/D layout: col = tile, 4 rows per lane), so the
+// output transform is 24 in-register adds, and a 2x2 tile is exactly one MaxPool2d(2) window: the pooled epilogue needs
+// no shuffles.
+//
+// Workgroup = 512 threads = 8 waves on an 8 x 32 pixel block (4 tile rows x 16 tiles), all 64 rows:
+//   wave w: rows 16 (w & 3) .. +15, tile rows 2 (w >> 2), 2 (w >> 2) + 1  -> 16 xi x 2 accumulators of 4 VGPRs = 128.
+// K loop over chunks of 4 reduction channels: transformed filters U2[chunk][row group][lane][16 xi (+4 pad)] arrive by
+// global_load_lds (20 KiB per chunk, lane-linear, 80-B lane pitch => conflict-free ds_read_b128), the 10 x 34 input
+// patch by dword loads issued one chunk ahead and stored to LDS after the MFMA block (source gating -- ReLU mask or
+// pooled-gradient routing -- applied at store time, as in conv_igemm.hip).
+#include "common.h"
+#include <stdlib.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+
+int fcd_wino_mode_now();   // conv_wino.hip: 0 = direct kernels only (tests' A/B switch), 2 / 4 otherwise
+
+namespace {
+constexpr int W2_ROWS = 64;                 // GEMM rows per workgroup (all of them)
+constexpr int W2_LP = 20;                   // floats per lane row in the filter slab: 16 xi + 4 pad (80-B pitch)
+constexpr int W2_SLAB = 4 * 64 * W2_LP;     // floats per chunk: [row group][lane][20]
+constexpr int W2_TH = 8, W2_TW = 32;        // output pixels per workgroup
+constexpr int W2_PH = W2_TH + 2, W2_PW = W2_TW + 2;
+constexpr int W2_RP = 36;                   // patch row pitch (floats): even => 8-B aligned ds_read_b64
+constexpr int W2_PL = 416;                  // patch plane pitch: >= 10 * 36 and == 32 (mod 64 banks)
+constexpr int W2_CB = 4;
+
+struct Wino2Args {
+  const float* x;       // source (N, C, H, W) -- or the pooled gradient (N, C, Hp, Wp) when SRC == 2
+  const float* U;       // packed transformed filters
+  const float* bias;
+  const float* mask;    // SRC == 1: same shape as x, source is read as x * (mask > 0)
+  const unsigned char* code_in;   // SRC == 2
+  float* y;             // (N, K, P, Q)   (EPI == 0)
+  float* pool_y;        // (N, K, P/2, Q/2) (EPI == 1)
+  unsigned char* code_out;
+  const float* residual;
+  const float* slope_ptr;
+  float slope_imm;
+  int relu, act_slope;
+  int N, C, H, W, K, Hp, Wp, nchunks, tiles_p, tiles_q, xcd_remap;
+};
+
+// U2 = G g G^T for F(2x2, 3x3), G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+__global__ void wino2_pack_kernel(const float* __restrict__ w, float* __restrict__ U, int K, int C, int mode,
+                                  long long total) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int e = (int)(i % W2_LP);
+    long long t = i / W2_LP;
+    const int l = (int)(t % 64); t /= 64;
+    const int g = (int)(t % 4);
+    const int q = (int)(t / 4);
+    const int row = 16 * g + (l & 15), red = 4 * q + (l >> 4);
+    const int rows = mode == 0 ? K : C, reds = mode == 0 ? C : K;
+    float v = 0.f;
+    if (e < 16 && row < rows && red < reds) {
+      float gk[3][3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+          gk[r][s] = mode == 0 ? w[(((size_t)row * C + red) * 3 + r) * 3 + s]
+                               : w[(((size_t)red * C + row) * 3 + (2 - r)) * 3 + (2 - s)];
+      const int a = e >> 2, b = e & 3;
+      // row a of G applied to the columns, then row b of G to the rows
+      float col[3];
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const float g0 = gk[0][s], g1 = gk[1][s], g2 = gk[2][s];
+        col[s] = a == 0 ? g0 : (a == 1 ? 0.5f * (g0 + g1 + g2) : (a == 2 ? 0.5f * (g0 - g1 + g2) : g2));
+      }
+      v = b == 0 ? col[0] : (b == 1 ? 0.5f * (col[0] + col[1] + col[2]) : (b == 2 ? 0.5f * (col[0] - col[1] + col[2]) : col[2]));
+    }
+    U[i] = v;
+  }
+}
+
+template <int SRC, int EPI>
+__global__ __launch_bounds__(512) void conv_wino2_kernel(Wino2Args a) {
+  constexpr int X_ELEMS = W2_CB * W2_PH * W2_PW;      // 1360
+  constexpr int X_PER_T = (X_ELEMS + 511) / 512;      // 3
+  constexpr int XS_SZ = W2_CB * W2_PL;
+  constexpr int U_INSTR = W2_SLAB / 256;              // 20 wave-instructions of 1 KiB per slab
+  __shared__ __attribute__((aligned(16))) float su0[W2_SLAB];
+  __shared__ __attribute__((aligned(16))) float su1[W2_SLAB];
+  __shared__ __attribute__((aligned(16))) float sx[2 * XS_SZ];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = wave & 3, hrow = wave >> 2;
+  const int ln = lane & 15, kc = lane >> 4;
+
+  unsigned v;
+  {
+    const unsigned total = gridDim.x, b = blockIdx.x;
+    if (a.xcd_remap) {
+      const unsigned q8 = total >> 3, r8 = total & 7u, xcd = b & 7u;
+      v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
+    } else {
+      v = b;
+    }
+  }
+  int bx = (int)v;
+  const int tq = bx % a.tiles_q;
+  bx /= a.tiles_q;
+  const int tp = bx % a.tiles_p;
+  const int n = bx / a.tiles_p;
+  const int p0 = tp * W2_TH, q0 = tq * W2_TW;
+
+  f32x4 acc[16][2];
+#pragma unroll
+  for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+    for (int gr = 0; gr < 2; ++gr) acc[xi][gr] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- loop-invariant addresses
+  const int aoff = (g * 64 + lane) * W2_LP;                         // A operands: 16 consecutive floats
+  int boff[2];
+#pragma unroll
+  for (int gr = 0; gr < 2; ++gr) boff[gr] = kc * W2_PL + (2 * (2 * hrow + gr)) * W2_RP + 2 * ln;
+
+  float xr[X_PER_T], mr[X_PER_T];
+  unsigned mcode[X_PER_T], x_want[X_PER_T], x_boff[X_PER_T];
+  int x_loff[X_PER_T], x_cc[X_PER_T];
+  const int ih0 = p0 - 1, iw0 = q0 - 1;
+#pragma unroll
+  for (int i = 0; i < X_PER_T; ++i) {
+    const int idx = tid + i * 512;
+    const int cc = idx / (W2_PH * W2_PW), rem = idx % (W2_PH * W2_PW);
+    const int ph = rem / W2_PW, pw = rem % W2_PW;
+    const int ih = ih0 + ph, iw = iw0 + pw;
+    bool ok = idx < X_ELEMS && ih >= 0 && iw >= 0 && ih < a.H && iw < a.W;
+    int goff = (cc * a.H + ih) * a.W + iw;
+    x_loff[i] = cc * W2_PL + ph * W2_RP + pw;
+    x_want[i] = 0;
+    if (SRC == 2) {
+      const int hp = ih >> 1, wq = iw >> 1;
+      if (hp >= a.Hp || wq >= a.Wp) ok = false;
+      goff = (cc * a.Hp + hp) * a.Wp + wq;
+      x_want[i] = (unsigned)((((ih & 1) << 1) | (iw & 1)) | 4);
+    }
+    x_cc[i] = ok ? cc : -1;
+    x_boff[i] = ok ? (unsigned)goff * 4u : 0u;
+  }
+  const int in_plane = (SRC == 2) ? a.Hp * a.Wp : a.H * a.W;
+  const float* xin = a.x + (size_t)n * a.C * in_plane;
+  const float* min_ = ((SRC == 1) ? a.mask : a.x) + (size_t)n * a.C * in_plane;
+  const unsigned char* cin_ = (SRC == 2) ? a.code_in + (size_t)n * a.C * in_plane : nullptr;
+  const int chunk_elems = W2_CB * in_plane;
+
+#define W2_DMA(CH, DST)                                                                              \
+  {                                                                                                  \
+    const float* usrc = a.U + (size_t)(CH) * W2_SLAB + lane * 4;                                     \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                                  \
+      const int ins = wave + 8 * j;                                                                  \
+      if (ins < U_INSTR)                                                                             \
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(usrc + ins * 256), (lds_void_t*)((DST) + ins * 256), 16, 0, 0); \
+    }                                                                                                \
+  }
+#define W2_LOAD_X(CH)                                                                                \
+  {                                                                                                  \
+    const int cleft = a.C - (CH) * W2_CB;                                                            \
+    const bool tail = cleft < W2_CB;                                                                 \
+    const char* xsrc = (const char*)(xin + (size_t)(CH) * chunk_elems);                              \
+    const char* msrc = (const char*)(min_ + (size_t)(CH) * chunk_elems);                             \
+    const unsigned char* csrc = cin_ + (size_t)(CH) * chunk_elems;                                   \
+    _Pragma("unroll") for (int i = 0; i < X_PER_T; ++i) {                                            \
+      unsigned off = x_boff[i];                                                                      \
+      if (tail) off = (x_cc[i] < cleft) ? off : 0u;                                                  \
+      xr[i] = *(const float*)(xsrc + off);                                                           \
+      if (SRC == 1) mr[i] = *(const float*)(msrc + off);                                             \
+      if (SRC == 2) mcode[i] = csrc[off >> 2];                                                       \
+    }                                                                                                \
+  }
+#define W2_STORE_X(BUF, CH)                                                                          \
+  {                                                                                                  \
+    const int cleft = a.C - (CH) * W2_CB;                                                            \
+    _Pragma("unroll") for (int i = 0; i < X_PER_T; ++i) {                                            \
+      if (tid + i * 512 < X_ELEMS) {                                                                 \
+        bool keep = (unsigned)x_cc[i] < (unsigned)cleft;                                             \
+        if (SRC == 2) keep = keep && mcode[i] == x_want[i];                                          \
+        if (SRC == 1) keep = keep && mr[i] > 0.f;                                                    \
+        sx[(BUF) * XS_SZ + x_loff[i]] = keep ? xr[i] : 0.f;                                          \
+      }                                                                                              \
+    }                                                                                                \
+  }
+#define W2_STEP(CH, UCUR, UNXT)                                                                      \
+  {                                                                                                  \
+    const int cch = (CH);                                                                             \
+    const bool have_next = cch + 1 < a.nchunks;                                                       \
+    const int xb = cch & 1;                                                                           \
+    if (have_next) {                                                                                 \
+      W2_DMA(cch + 1, UNXT)                                                                           \
+      W2_LOAD_X(cch + 1)                                                                              \
+    }                                                                                                \
+    float av[16];                                                                                    \
+    _Pragma("unroll") for (int v4 = 0; v4 < 4; ++v4) {                                               \
+      const f32x4 t4 = *(const f32x4*)((UCUR) + aoff + 4 * v4);                                      \
+      av[4 * v4] = t4[0]; av[4 * v4 + 1] = t4[1]; av[4 * v4 + 2] = t4[2]; av[4 * v4 + 3] = t4[3];    \
+    }                                                                                                \
+    const float* xl = sx + xb * XS_SZ;                                                               \
+    _Pragma("unroll") for (int gr = 0; gr < 2; ++gr) {                                               \
+      float d[4][4];                                                                                 \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                \
+        const f32x2 lo = *(const f32x2*)(xl + boff[gr] + i * W2_RP);                                 \
+        const f32x2 hi = *(const f32x2*)(xl + boff[gr] + i * W2_RP + 2);                             \
+        d[i][0] = lo[0]; d[i][1] = lo[1]; d[i][2] = hi[0]; d[i][3] = hi[1];                          \
+      }                                                                                              \
+      float t[4][4];   /* B^T d */                                                                   \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                \
+        t[0][j] = d[0][j] - d[2][j]; t[1][j] = d[1][j] + d[2][j];                                    \
+        t[2][j] = d[2][j] - d[1][j]; t[3][j] = d[1][j] - d[3][j];                                    \
+      }                                                                                              \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) {   /* (B^T d) B, then the 4 MFMAs of row i */  \
+        const float v0 = t[i][0] - t[i][2], v1 = t[i][1] + t[i][2], v2 = t[i][2] - t[i][1], v3 = t[i][1] - t[i][3]; \
+        acc[4 * i + 0][gr] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * i + 0], v0, acc[4 * i + 0][gr], 0, 0, 0); \
+        acc[4 * i + 1][gr] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * i + 1], v1, acc[4 * i + 1][gr], 0, 0, 0); \
+        acc[4 * i + 2][gr] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * i + 2], v2, acc[4 * i + 2][gr], 0, 0, 0); \
+        acc[4 * i + 3][gr] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * i + 3], v3, acc[4 * i + 3][gr], 0, 0, 0); \
+      }                                                                                              \
+    }                                                                                                \
+    if (have_next) W2_STORE_X(xb ^ 1, cch + 1)                                                        \
+    __syncthreads();                                                                                 \
+  }
+
+  W2_DMA(0, su0)
+  W2_LOAD_X(0)
+  W2_STORE_X(0, 0)
+  __syncthreads();
+  for (int ch = 0; ch < a.nchunks; ch += 2) {
+    W2_STEP(ch, su0, su1)
+    if (ch + 1 < a.nchunks) W2_STEP(ch + 1, su1, su0)
+  }
+#undef W2_STEP
+#undef W2_STORE_X
+#undef W2_LOAD_X
+#undef W2_DMA
+
+  // ---- output transform + epilogue.  Lane: tile column ln, rows 16 g + 4 kc + reg; A^T = [[1,1,1,0],[0,1,-1,-1]]
+  const int P = a.H, Q = a.W;          // stride 1 / pad 1: output extent == input extent
+#pragma unroll
+  for (int gr = 0; gr < 2; ++gr) {
+    const int trow = 2 * hrow + gr;
+    const int p = p0 + 2 * trow, q = q0 + 2 * ln;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int k = 16 * g + 4 * kc + reg;
+      float s[2][4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const float m0 = acc[b][gr][reg], m1 = acc[4 + b][gr][reg], m2 = acc[8 + b][gr][reg], m3 = acc[12 + b][gr][reg];
+        s[0][b] = m0 + m1 + m2;
+        s[1][b] = m1 - m2 - m3;
+      }
+      float o[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        o[i][0] = s[i][0] + s[i][1] + s[i][2];
+        o[i][1] = s[i][1] - s[i][2] - s[i][3];
+      }
+      if (k >= a.K) continue;
+      const float bv = a.bias ? a.bias[k] : 0.f;
+      if (EPI == 1) {
+        float m = fmaxf(o[0][0] + bv, 0.f);
+        int arg = 0;
+        const float v01 = fmaxf(o[0][1] + bv, 0.f), v10 = fmaxf(o[1][0] + bv, 0.f), v11 = fmaxf(o[1][1] + bv, 0.f);
+        if (v01 > m) { m = v01; arg = 1; }
+        if (v10 > m) { m = v10; arg = 2; }
+        if (v11 > m) { m = v11; arg = 3; }
+        const int pp = p >> 1, qq = q >> 1, Pp = P >> 1, Qp = Q >> 1;
+        if (pp < Pp && qq < Qp) {
+          const size_t oo = (((size_t)n * a.K + k) * Pp + pp) * Qp + qq;
+          a.pool_y[oo] = m;
+          a.code_out[oo] = (unsigned char)(arg | (m > 0.f ? 4 : 0));
+        }
+      } else {
+        const float slope = a.act_slope ? (a.slope_ptr ? a.slope_ptr[0] : a.slope_imm) : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          if (p + i >= P) continue;
+          const size_t yo = (((size_t)n * a.K + k) * P + (p + i)) * Q + q;
+          float v0 = o[i][0] + bv, v1 = o[i][1] + bv;
+          if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+          if (a.act_slope) { v0 = v0 > 0.f ? v0 : v0 * slope; v1 = v1 > 0.f ? v1 : v1 * slope; }
+          if (q + 1 < Q && !(Q & 1)) {           // 8-B aligned pair
+            if (a.residual) {
+              const f32x2 rr = *(const f32x2*)(a.residual + yo);
+              v0 += rr[0]; v1 += rr[1];
+            }
+            *(f32x2*)(a.y + yo) = f32x2{v0, v1};
+          } else {
+            if (q < Q) a.y[yo] = v0 + (a.residual ? a.residual[yo] : 0.f);
+            if (q + 1 < Q) a.y[yo + 1] = v1 + (a.residual ? a.residual[yo + 1] : 0.f);
+          }
+        }
+      }
+    }
+  }
+}
+
+int w2_env() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("FCD_WINO2");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v;
+}
+}  // namespace
+
+// mode 0 forward / 1 data gradient: 1 when the layer runs on the fused F(2x2,3x3) kernel
+extern "C" int fcd_conv_wino2_plan(const fcd_conv_desc* d, int mode) {
+  if (!d || !w2_env() || fcd_wino_mode_now() == 0) return 0;
+  if (!(d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1)) return 0;
+  const int rows = mode == 0 ? d->K : d->C, red = mode == 0 ? d->C : d->K;
+  static int min_red = -1;
+  if (min_red < 0) {
+    const char* e = getenv("FCD_WINO2_MINC");
+    min_red = e ? atoi(e) : 32;
+  }
+  if (rows <= 32 || rows > W2_ROWS || red < min_red) return 0;
+  if (d->H < 4 || d->W < 4) return 0;
+  return 1;
+}
+
+extern "C" int64_t fcd_conv_wino2_filter_elems(int K, int C, int mode) {
+  const int red = mode == 0 ? C : K;
+  return (int64_t)cdiv(red, W2_CB) * W2_SLAB;
+}
+
+extern "C" int fcd_conv_wino2_pack(const float* w, float* U, int K, int C, int mode, void* stream) {
+  FCD_CHECK_ARG(w && U && K > 0 && C > 0 && (mode == 0 || mode == 1), "fcd_conv_wino2_pack: bad arguments");
+  FCD_CHECK_ARG((mode == 0 ? K : C) <= W2_ROWS, "fcd_conv_wino2_pack: more than %d GEMM rows", W2_ROWS);
+  const long long total = fcd_conv_wino2_filter_elems(K, C, mode);
+  const int grid = (int)std::min<long long>(cdiv64(total, 256), 4096);
+  FcdProfScope prof(FCD_K_PACK, (hipStream_t)stream, 0.0, 4.0 * total);
+  hipLaunchKernelGGL(wino2_pack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, U, K, C, mode, total);
+  FCD_LAUNCH_CHECK("wino2_pack");
+  return FCD_OK;
+}
+
+static int w2_xcd() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("FCD_CONV_XCD");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v;
+}
+
+template <int SRC, int EPI>
+static void w2_launch(Wino2Args& a, hipStream_t st) {
+  a.tiles_p = cdiv(a.H, W2_TH);
+  a.tiles_q = cdiv(a.W, W2_TW);
+  a.xcd_remap = w2_xcd();
+  hipLaunchKernelGGL((conv_wino2_kernel<SRC, EPI>), dim3((unsigned)(a.N * a.tiles_p * a.tiles_q)), dim3(512), 0, st, a);
+}
+
+// y = act(conv(x, w) + bias) + residual, or (pool_y, code) = maxpool2(relu(conv + bias)) when pool_y != NULL
+extern "C" int fcd_conv2d_fwd_wino2(const fcd_conv_desc* d, const float* x, const float* U, const float* bias, float* y,
+                                    int act, const float* slope_ptr, float slope_imm, const float* residual, float* pool_y,
+                                    unsigned char* code, void* stream) {
+  FCD_CHECK_ARG(d && x && U && (y || (pool_y && code)), "fcd_conv2d_fwd_wino2: null pointer");
+  FCD_CHECK_ARG(fcd_conv_wino2_plan(d, 0), "fcd_conv2d_fwd_wino2: layer is not planned for the fused F(2x2,3x3) kernel");
+  FCD_CHECK_ARG(act >= FCD_ACT_NONE && act <= FCD_ACT_PRELU, "fcd_conv2d_fwd_wino2: bad activation code %d", act);
+  Wino2Args a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.U = U; a.bias = bias; a.y = y; a.pool_y = pool_y; a.code_out = code; a.residual = residual;
+  a.relu = act == FCD_ACT_RELU; a.act_slope = (act == FCD_ACT_LEAKY || act == FCD_ACT_PRELU) ? 1 : 0;
+  a.slope_ptr = slope_ptr; a.slope_imm = slope_imm;
+  a.N = d->N; a.C = d->C; a.H = d->H; a.W = d->W; a.K = d->K; a.nchunks = cdiv(d->C, W2_CB);
+  const double flops = 2.0 * d->N * d->K * (double)d->P * d->Q * d->C * 9;
+  const double bytes = 4.0 * ((double)d->N * d->C * d->H * d->W + (pool_y ? 0.3125 : 1.0) * d->N * d->K * d->P * d->Q +
+                              (double)d->K * d->C * 16);
+  FcdProfScope prof(FCD_K_WINO2_FWD, (hipStream_t)stream, flops, bytes, fcd_prof_tag_desc(pool_y ? "w2_fwd_pool" : "w2_fwd", d));
+  if (pool_y) w2_launch<0, 1>(a, (hipStream_t)stream); else w2_launch<0, 0>(a, (hipStream_t)stream);
+  FCD_LAUNCH_CHECK("conv2d_fwd_wino2");
+  return FCD_OK;
+}
+
+// dx = conv_transpose(dy') with dy' = dy, dy * [relu_out > 0], or the pooled gradient routed by pool_code
+extern "C" int fcd_conv2d_bwd_data_wino2(const fcd_conv_desc* d, const float* dy, const float* relu_out,
+                                         const unsigned char* pool_code, const float* U, float* dx, void* stream) {
+  FCD_CHECK_ARG(d && dy && U && dx, "fcd_conv2d_bwd_data_wino2: null pointer");
+  FCD_CHECK_ARG(fcd_conv_wino2_plan(d, 1), "fcd_conv2d_bwd_data_wino2: layer is not planned for the fused F(2x2,3x3) kernel");
+  Wino2Args a;
+  memset(&a, 0, sizeof(a));
+  a.x = dy; a.U = U; a.y = dx; a.mask = pool_code ? nullptr : relu_out; a.code_in = pool_code;
+  a.N = d->N; a.C = d->K; a.H = d->P; a.W = d->Q; a.K = d->C; a.Hp = d->P / 2; a.Wp = d->Q / 2;
+  a.nchunks = cdiv(d->K, W2_CB);
+  const double flops = 2.0 * d->N * d->K * (double)d->P * d->Q * d->C * 9;
+  const double bytes = 4.0 * ((double)d->N * d->C * d->H * d->W + (pool_code ? 0.3125 : (relu_out ? 2.0 : 1.0)) * d->N * d->K * d->P * d->Q +
+                              (double)d->K * d->C * 16);
+  FcdProfScope prof(FCD_K_WINO2_DGRAD, (hipStream_t)stream, flops, bytes, fcd_prof_tag_desc("w2_dgrad", d));
+  if (pool_code) w2_launch<2, 0>(a, (hipStream_t)stream);
+  else if (relu_out) w2_launch<1, 0>(a, (hipStream_t)stream);
+  else w2_launch<0, 0>(a, (hipStream_t)stream);
+  FCD_LAUNCH_CHECK("conv2d_bwd_data_wino2");
+  return FCD_OK;
+}

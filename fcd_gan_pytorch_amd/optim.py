@@ -43,12 +43,14 @@ class _FlatOptimizer:
         self.flat_p = torch.empty(n, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
         off = 0
+        self.epoch = 0                 # bumped by zero_grad: a gradient slot is handed out once per epoch (see grad_slot)
         with torch.no_grad():
             for p in self.params:
                 k = p.numel()
                 self.flat_p[off:off + k].copy_(p.detach().reshape(-1))
                 p.data = self.flat_p[off:off + k].view(p.shape)
                 p.grad = self.flat_g[off:off + k].view(p.shape)
+                p._fcd_slot = (self, off, -1)      # (owner, offset into flat_g, epoch the slot was last handed out in)
                 off += k
         ops.invalidate_packs(self.params)
         self.param_groups = [{'params': self.params, 'lr': lr}]
@@ -61,10 +63,30 @@ class _FlatOptimizer:
         self.last_exchange = None     # diagnostics of the most recent exchange (tests, bench)
 
     def zero_grad(self, set_to_none=False):
-        # in place: gradients must stay views of the flat buffer (re-point first, WITHOUT copying: whatever a
-        # detached .grad holds is exactly what zero_grad is meant to discard)
-        self._bind_grads(copy=False)
+        """One memset of the flat buffer; every ``.grad`` becomes None.  The backward kernels of the fcd ops then write
+        each parameter gradient STRAIGHT into its slice of the flat buffer (``grad_slot``) and hand autograd a view of
+        it, which AccumulateGrad adopts as ``.grad`` without a copy or an add -- no per-parameter accumulate kernel.
+        A parameter that collects a second gradient in the same epoch (used twice in one graph, or a second backward)
+        falls back to autograd's ordinary accumulation; ``_bind_grads`` moves whatever did not land in the flat
+        buffer there before the exchange / the update."""
+        self.epoch += 1
+        for p in self.params:
+            p.grad = None
         self.flat_g.zero_()
+
+    def gather_grads(self):
+        """Make ``flat_g`` hold every parameter's current gradient (call before reading it directly)."""
+        self._bind_grads()
+        return self.flat_g
+
+    def grad_slot(self, p):
+        """Fresh view of ``p``'s slice of the flat gradient buffer if it may be written directly (first gradient of this
+        epoch, nothing accumulated yet), else None."""
+        owner, off, used = p._fcd_slot
+        if p.grad is not None or used == self.epoch:
+            return None
+        p._fcd_slot = (owner, off, self.epoch)
+        return self.flat_g[off:off + p.numel()].view(p.shape)
 
     def _bind_grads(self, copy=True):
         """Make every ``p.grad`` the matching view of ``flat_g`` again.  A gradient that was detached from the
@@ -124,7 +146,6 @@ class _FlatOptimizer:
             return False
         if self._buckets is None:
             self._build_buckets()
-        self._bind_grads()
         self._group = group
         self._pending = [b[2] for b in self._buckets]
         self._next = 0
@@ -161,6 +182,7 @@ class _FlatOptimizer:
         backward pass are already in flight: flush the rest, then make the compute stream wait for all of them.
         Without it: one all-reduce of the whole buffer."""
         world = self._world(group)
+        self._bind_grads()
         if world <= 1:
             self._armed = False
             self.grad_scale = 1.0
@@ -176,7 +198,6 @@ class _FlatOptimizer:
             self._works = []
             self._armed = False
         else:
-            self._bind_grads()
             dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=group)
             self.last_exchange = dict(buckets=1, launched_during_backward=0, bytes=[4 * self.flat_g.numel()])
         self.grad_scale = 1.0 / world

@@ -235,6 +235,24 @@ int fcd_ssim_level_bwd(const float* X, const float* Y, const float* win, int win
                        const float* g_ssim, const float* g_cs, float* dX, float* dY, int NC, int H,
                        int W, float C1, float C2, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- fused Winograd F(2x2,3x3) convolution for 3x3 / stride-1 / pad-1 layers with 33..64 GEMM rows (output channels
+ * forward, input channels for the data gradient) and >= 32 reduction channels: input transform, 16 batched MFMA GEMMs
+ * and output transform in ONE kernel (csrc/conv_wino2.hip) -- 2.25x fewer multiplies than the direct kernel at the same
+ * HBM traffic, results within direct-kernel rounding (F(2x2) transforms are exact in fp32 up to a few ulp).
+ * fcd_conv_wino2_plan: 1 when the library runs the layer (mode 0 forward / 1 data gradient) on this kernel -- the
+ * caller then packs the filters with fcd_conv_wino2_pack (fcd_conv_wino2_filter_elems floats) instead of
+ * fcd_conv_pack_weights.  Forward: y = act(conv + bias) + residual (act / slope / residual as fcd_conv2d_fwd_ex), or,
+ * with pool_y != NULL, pool_y / code = maxpool2(relu(conv + bias)) as fcd_conv2d_fwd_relu_pool.  Data gradient:
+ * source gating as fcd_conv2d_bwd_data (relu_out) / fcd_conv2d_bwd_data_pooled (pool_code).  No workspace. */
+int fcd_conv_wino2_plan(const fcd_conv_desc* d, int mode);
+int64_t fcd_conv_wino2_filter_elems(int K, int C, int mode);
+int fcd_conv_wino2_pack(const float* w, float* U, int K, int C, int mode, void* stream);
+int fcd_conv2d_fwd_wino2(const fcd_conv_desc* d, const float* x, const float* U, const float* bias, float* y, int act,
+                         const float* slope_ptr, float slope_imm, const float* residual, float* pool_y,
+                         unsigned char* code, void* stream);
+int fcd_conv2d_bwd_data_wino2(const fcd_conv_desc* d, const float* dy, const float* relu_out,
+                              const unsigned char* pool_code, const float* U, float* dx, void* stream);
+
 /* ---- optimizers (torch.optim.Adam / RMSprop defaults; Demo_RSSS.py:151-158)
  * Flat fp32 buffers of n elements.  grad_scale multiplies the gradient first
  * (1/world_size after an all-reduce-sum).  step: 1-based step count. */

@@ -53,7 +53,7 @@ def _worker(rank, world, port, q):
         sd.update(dict(g.named_buffers()))
         opt.zero_grad()
         _loss(sd, x[shard], y[shard]).backward()
-        local = opt.flat_g.clone()
+        local = opt.gather_grads().clone()
         opt.allreduce_grads()
         assert abs(opt.grad_scale - 1.0 / world) < 1e-12
         avg = opt.flat_g * opt.grad_scale
@@ -94,7 +94,7 @@ def test_flat_allreduce_matches_full_batch_gradient():
     sd.update(dict(g.named_buffers()))
     opt.zero_grad()
     _loss(sd, x, y).backward()
-    full = opt.flat_g.numpy()
+    full = opt.gather_grads().numpy()
     for rank, local, avg, refused, counts in res:
         assert refused, 'optimizer.step() must refuse CPU tensors'
         np.testing.assert_allclose(avg, full, rtol=1e-4, atol=1e-5 * np.abs(full).max())

@@ -432,3 +432,85 @@ def test_thin_conv_relu_bitmask_path(case):
     dd = xg.grad.cpu().double() - xr.grad.double()
     assert (dd.norm() / xr.grad.double().norm()).item() < 1e-4, 'dx'       # kink flips only
     assert (dd.abs() > 1e-4 * xr.grad.abs().max().item()).double().mean().item() < 2e-3
+
+
+W2_CASES = [
+    # N, C, H, W, K   (3x3 / stride 1 / pad 1; 33..64 GEMM rows in at least one direction, >= 32 reduction channels)
+    (2, 64, 40, 64, 64),       # forward and data gradient on the fused kernel
+    (1, 64, 13, 27, 64),       # odd sizes: ragged 8 x 32 blocks, odd pooled extents
+    (3, 40, 9, 70, 48),        # 48 rows (padded to 64), 40 reduction channels, three column blocks
+    (2, 128, 20, 28, 64),      # forward fused (64 rows), data gradient on the three-kernel / direct path (128 rows)
+    (2, 64, 16, 36, 128),      # forward NOT fused (128 rows), data gradient fused (64 rows, 128 reduction channels)
+    (1, 34, 6, 5, 64),         # channel tail (34 = 8 chunks + 2), tiny map
+]
+
+
+@pytest.mark.parametrize('case', W2_CASES, ids=lambda c: 'x'.join(map(str, c)))
+def test_conv_wino2_fused_kernel(case):
+    """Fused Winograd F(2x2,3x3) kernel (csrc/conv_wino2.hip) vs torch fp64: forward with every epilogue (bias, ReLU,
+    PReLU + residual, ReLU + max-pool + code), data gradient with every source (plain, ReLU-gated, pooled-gradient
+    routed), weight gradient unchanged.  F(2x2) transforms only add / halve: error stays at direct-kernel level."""
+    import ctypes
+    ops = _ops()
+    lib = ops.lib
+    N, C, H, W, K = case
+    d = ops._desc((N, C, H, W), (K, C, 3, 3), 1, 1)
+    fused_f, fused_d = bool(lib.fcd_conv_wino2_plan(ctypes.byref(d), 0)), bool(lib.fcd_conv_wino2_plan(ctypes.byref(d), 1))
+    assert fused_f == (32 < K <= 64 and C >= 32) and fused_d == (32 < C <= 64 and K >= 32)
+    assert fused_f or fused_d
+    tol, flip_tol = 5e-6, 4e-3
+    x = rnd(N, C, H, W, seed=31)
+    w = rnd(K, C, 3, 3, seed=32, scale=(2.0 / (C * 9)) ** 0.5)
+    b = rnd(K, seed=33, scale=0.1)
+    g = rnd(N, K, H, W, seed=34)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    yr = F.conv2d(xr, wr, br, padding=1)
+    yr.backward(g.double())
+    xg, wg, bg = (t.cuda().requires_grad_(True) for t in (x, w, b))
+    y = ops.conv2d(xg, wg, bg, 1, 1)
+    y.backward(g.cuda())
+    assert_close(y, yr.float(), tol=tol, what='y')
+    assert_close(xg.grad, xr.grad.float(), tol=tol, what='dx')
+    assert_close(wg.grad, wr.grad.float(), tol=5e-5, what='dw')
+    assert torch.equal(ops.conv2d(xg, wg, bg, 1, 1), y)                     # bit-reproducible
+    # the direct kernels give the same numbers to rounding (A/B switch of the library)
+    prev = lib.fcd_conv_wino_set(0)
+    try:
+        assert not lib.fcd_conv_wino2_plan(ctypes.byref(d), 0)
+        with torch.no_grad():
+            y_direct = ops.conv2d(xg, wg, bg, 1, 1)
+    finally:
+        lib.fcd_conv_wino_set(prev)
+    assert (y_direct - y).abs().max().item() <= 5e-6 * y.abs().max().item()
+    # ReLU epilogue + mask-gated data gradient
+    xr3 = x.double().requires_grad_(True)
+    F.relu(F.conv2d(xr3, w.double(), b.double(), padding=1)).backward(g.double())
+    xg3 = x.cuda().requires_grad_(True)
+    y3 = ops.conv2d(xg3, w.cuda(), b.cuda(), 1, 1, relu=True)
+    y3.backward(g.cuda())
+    assert_close(y3, F.relu(yr).float(), tol=tol, what='relu y')
+    dd = xg3.grad.cpu().double() - xr3.grad
+    assert (dd.norm() / xr3.grad.norm()).item() < flip_tol, 'relu dx'
+    # ReLU + max-pool epilogue (ties: constant block; all-negative channels) + code-routed data gradient
+    if H >= 2 and W >= 2 and K > 32 and C > 32:
+        x2 = x.clone()
+        x2[:, :, : H // 2, : W // 2] = x2[:, :, :1, :1]
+        b2 = b.clone()
+        b2[: K // 4] = -50.0
+        xr2 = x2.double().requires_grad_(True)
+        ypr = F.max_pool2d(F.relu(F.conv2d(xr2, w.double(), b2.double(), padding=1)), 2)
+        gp = rnd(*ypr.shape, seed=35)
+        ypr.backward(gp.double())
+        xg2 = x2.cuda().requires_grad_(True)
+        yp = ops.conv2d_relu_maxpool2(xg2, w.cuda(), b2.cuda())
+        yp.backward(gp.cuda())
+        assert_close(yp, ypr.float(), tol=tol, what='pooled y')
+        dd = xg2.grad.cpu().double() - xr2.grad
+        assert (dd.norm() / xr2.grad.norm().clamp_min(1e-30)).item() < flip_tol, 'pooled dx'
+    # inference epilogue: PReLU + residual
+    res = rnd(N, K, H, W, seed=36)
+    slope = torch.tensor([0.25])
+    got = ops.conv2d_infer(x.cuda(), w.cuda(), b.cuda(), 1, 1, ops.ACT_PRELU, slope=slope.cuda(), residual=res.cuda())
+    ref = yr.detach()
+    ref = torch.where(ref > 0, ref, ref * 0.25) + res.double()
+    assert_close(got, ref.float(), tol=tol, what='prelu + residual')
