@@ -39,9 +39,14 @@ constexpr int W2_LP = 20;                   // floats per lane row in the filter
 constexpr int W2_SLAB = 4 * 64 * W2_LP;     // floats per chunk: [row group][lane][20]
 constexpr int W2_TH = 8, W2_TW = 32;        // output pixels per workgroup
 constexpr int W2_PH = W2_TH + 2, W2_PW = W2_TW + 2;
-constexpr int W2_RP = 36;                   // patch row pitch (floats): even => 8-B aligned ds_read_b64
-constexpr int W2_PL = 416;                  // patch plane pitch: >= 10 * 36 and == 32 (mod 64 banks)
-constexpr int W2_CB = 4;
+// LDS image of the input patch: PAIR rows.  Element (r, c) of pair row r holds (x[r][c], x[r + 2][c]) in two adjacent
+// floats: a wave's two tile rows (patch rows 4h + i and 4h + 2 + i, i = 0..3) then arrive as ready-made (tile row 0,
+// tile row 1) register pairs, four columns per two ds_read_b128, and every transform add is one v_pk_add_f32 serving
+// two MFMA operands.  (Each patch element is stored twice: as .x of pair row r and as .y of pair row r - 2.)
+constexpr int W2_RP = 72;                   // pair-row pitch (floats): 34 columns x 2, padded to a multiple of 4
+constexpr int W2_PL = 8 * W2_RP;            // 8 pair rows per channel plane
+constexpr int W2_KS = 2;                    // MFMA k-steps (4-channel chunks) per pipeline stage: one barrier per 8 channels
+constexpr int W2_CB = 4 * W2_KS;
 
 struct Wino2Args {
   const float* x;       // source (N, C, H, W) -- or the pooled gradient (N, C, Hp, Wp) when SRC == 2
@@ -95,12 +100,14 @@ __global__ void wino2_pack_kernel(const float* __restrict__ w, float* __restrict
 
 template <int SRC, int EPI>
 __global__ __launch_bounds__(512) void conv_wino2_kernel(Wino2Args a) {
-  constexpr int X_ELEMS = W2_CB * W2_PH * W2_PW;      // 1360
-  constexpr int X_PER_T = (X_ELEMS + 511) / 512;      // 3
+  constexpr int X_ELEMS = W2_CB * W2_PH * W2_PW;      // 2720
+  constexpr int X_PER_T = (X_ELEMS + 511) / 512;      // 6
   constexpr int XS_SZ = W2_CB * W2_PL;
-  constexpr int U_INSTR = W2_SLAB / 256;              // 20 wave-instructions of 1 KiB per slab
-  __shared__ __attribute__((aligned(16))) float su0[W2_SLAB];
-  __shared__ __attribute__((aligned(16))) float su1[W2_SLAB];
+  constexpr int U_STAGE = W2_KS * W2_SLAB;            // floats per stage of the filter pipeline
+  constexpr int U_INSTR = U_STAGE / 256;              // 40 wave-instructions of 1 KiB per stage
+  constexpr int U_PER_W = (U_INSTR + 7) / 8;
+  __shared__ __attribute__((aligned(16))) float su0[U_STAGE];
+  __shared__ __attribute__((aligned(16))) float su1[U_STAGE];
   __shared__ __attribute__((aligned(16))) float sx[2 * XS_SZ];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -134,11 +141,11 @@ __global__ __launch_bounds__(512) void conv_wino2_kernel(Wino2Args a) {
   const int aoff = (g * 64 + lane) * W2_LP;                         // A operands: 16 consecutive floats
   int boff[2];
 #pragma unroll
-  for (int gr = 0; gr < 2; ++gr) boff[gr] = kc * W2_PL + (2 * (2 * hrow + gr)) * W2_RP + 2 * ln;
+  for (int gr = 0; gr < 2; ++gr) boff[gr] = kc * W2_PL + (4 * hrow) * W2_RP + 4 * ln;   // (one address: pairs)
 
   float xr[X_PER_T], mr[X_PER_T];
   unsigned mcode[X_PER_T], x_want[X_PER_T], x_boff[X_PER_T];
-  int x_loff[X_PER_T], x_cc[X_PER_T];
+  int x_loff[X_PER_T], x_loff2[X_PER_T], x_cc[X_PER_T];      // LDS offsets of the .x / .y copy (-1: none)
   const int ih0 = p0 - 1, iw0 = q0 - 1;
 #pragma unroll
   for (int i = 0; i < X_PER_T; ++i) {
@@ -148,7 +155,8 @@ __global__ __launch_bounds__(512) void conv_wino2_kernel(Wino2Args a) {
     const int ih = ih0 + ph, iw = iw0 + pw;
     bool ok = idx < X_ELEMS && ih >= 0 && iw >= 0 && ih < a.H && iw < a.W;
     int goff = (cc * a.H + ih) * a.W + iw;
-    x_loff[i] = cc * W2_PL + ph * W2_RP + pw;
+    x_loff[i] = ph < 8 ? cc * W2_PL + ph * W2_RP + 2 * pw : -1;
+    x_loff2[i] = ph >= 2 ? cc * W2_PL + (ph - 2) * W2_RP + 2 * pw + 1 : -1;
     x_want[i] = 0;
     if (SRC == 2) {
       const int hp = ih >> 1, wq = iw >> 1;
@@ -167,10 +175,10 @@ __global__ __launch_bounds__(512) void conv_wino2_kernel(Wino2Args a) {
 
 #define W2_DMA(CH, DST)                                                                              \
   {                                                                                                  \
-    const float* usrc = a.U + (size_t)(CH) * W2_SLAB + lane * 4;                                     \
-    _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                                  \
+    const float* usrc = a.U + (size_t)(CH) * U_STAGE + lane * 4;                                     \
+    _Pragma("unroll") for (int j = 0; j < U_PER_W; ++j) {                                            \
       const int ins = wave + 8 * j;                                                                  \
-      if (ins < U_INSTR)                                                                             \
+      if (U_INSTR % 8 == 0 || ins < U_INSTR)                                                         \
         __builtin_amdgcn_global_load_lds((gbl_void_t*)(usrc + ins * 256), (lds_void_t*)((DST) + ins * 256), 16, 0, 0); \
     }                                                                                                \
   }
@@ -197,7 +205,9 @@ __global__ __launch_bounds__(512) void conv_wino2_kernel(Wino2Args a) {
         bool keep = (unsigned)x_cc[i] < (unsigned)cleft;                                             \
         if (SRC == 2) keep = keep && mcode[i] == x_want[i];                                          \
         if (SRC == 1) keep = keep && mr[i] > 0.f;                                                    \
-        sx[(BUF) * XS_SZ + x_loff[i]] = keep ? xr[i] : 0.f;                                          \
+        const float xv = keep ? xr[i] : 0.f;                                                         \
+        if (x_loff[i] >= 0) sx[(BUF) * XS_SZ + x_loff[i]] = xv;                                      \
+        if (x_loff2[i] >= 0) sx[(BUF) * XS_SZ + x_loff2[i]] = xv;                                    \
       }                                                                                              \
     }                                                                                                \
   }
@@ -210,31 +220,48 @@ __global__ __launch_bounds__(512) void conv_wino2_kernel(Wino2Args a) {
       W2_DMA(cch + 1, UNXT)                                                                           \
       W2_LOAD_X(cch + 1)                                                                              \
     }                                                                                                \
+    const float* xl = sx + xb * XS_SZ;                                                               \
+    _Pragma("unroll") for (int ks = 0; ks < W2_KS; ++ks) {                                           \
     float av[16];                                                                                    \
     _Pragma("unroll") for (int v4 = 0; v4 < 4; ++v4) {                                               \
-      const f32x4 t4 = *(const f32x4*)((UCUR) + aoff + 4 * v4);                                      \
+      const f32x4 t4 = *(const f32x4*)((UCUR) + ks * W2_SLAB + aoff + 4 * v4);                       \
       av[4 * v4] = t4[0]; av[4 * v4 + 1] = t4[1]; av[4 * v4 + 2] = t4[2]; av[4 * v4 + 3] = t4[3];    \
     }                                                                                                \
-    const float* xl = sx + xb * XS_SZ;                                                               \
-    _Pragma("unroll") for (int gr = 0; gr < 2; ++gr) {                                               \
-      float d[4][4];                                                                                 \
+    /* both tile rows of the wave at once: every quantity is a (tile row 0, tile row 1) pair in two adjacent VGPRs */ \
+    /* (ds_read2_b32 fills such a pair from two addresses), so each transform add is ONE v_pk_add_f32 for two MFMA */ \
+    /* operands -- 1 VALU op per MFMA instead of 2.8 */                                                \
+    {                                                                                                \
+      const float* xp = xl + ks * 4 * W2_PL + boff[0];                                               \
+      f32x2 d[4][4];                                                                                 \
       _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                \
-        const f32x2 lo = *(const f32x2*)(xl + boff[gr] + i * W2_RP);                                 \
-        const f32x2 hi = *(const f32x2*)(xl + boff[gr] + i * W2_RP + 2);                             \
-        d[i][0] = lo[0]; d[i][1] = lo[1]; d[i][2] = hi[0]; d[i][3] = hi[1];                          \
+        const f32x4 q0 = *(const f32x4*)(xp + i * W2_RP), q1 = *(const f32x4*)(xp + i * W2_RP + 4);  \
+        d[i][0] = __builtin_shufflevector(q0, q0, 0, 1); d[i][1] = __builtin_shufflevector(q0, q0, 2, 3); \
+        d[i][2] = __builtin_shufflevector(q1, q1, 0, 1); d[i][3] = __builtin_shufflevector(q1, q1, 2, 3); \
       }                                                                                              \
-      float t[4][4];   /* B^T d */                                                                   \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                \
-        t[0][j] = d[0][j] - d[2][j]; t[1][j] = d[1][j] + d[2][j];                                    \
-        t[2][j] = d[2][j] - d[1][j]; t[3][j] = d[1][j] - d[3][j];                                    \
+      f32x2 t[4][4];   /* B^T d */                                                                   \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)   /* t0 = d0 - d2, t1 = d1 + d2, t2 = d2 - d1, t3 = d1 - d3 */ \
+        asm("v_pk_add_f32 %0, %4, %6 neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_add_f32 %1, %5, %6\n\t"         \
+            "v_pk_add_f32 %2, %6, %5 neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_add_f32 %3, %5, %7 neg_lo:[0,1] neg_hi:[0,1]" \
+            : "=&v"(t[0][j]), "=&v"(t[1][j]), "=&v"(t[2][j]), "=&v"(t[3][j])                         \
+            : "v"(d[0][j]), "v"(d[1][j]), "v"(d[2][j]), "v"(d[3][j]));                               \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) {   /* (B^T d) B, then the 8 MFMAs of row i */  \
+        /* v0 = t0 - t2, v1 = t1 + t2, v2 = t2 - t1, v3 = t1 - t3 on (tile row 0, tile row 1) pairs.  Written as */ \
+        /* asm because LLVM scalarises a <2 x float> op whose lanes are only extracted (here: MFMA operands) into */ \
+        /* two v_add_f32; the trailing s_nop 1 = the 2 wait states a VALU result needs before an MFMA reads it */ \
+        f32x2 v0, v1, v2, v3;                                                                        \
+        asm("v_pk_add_f32 %0, %4, %6 neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_add_f32 %1, %5, %6\n\t"         \
+            "v_pk_add_f32 %2, %6, %5 neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_add_f32 %3, %5, %7 neg_lo:[0,1] neg_hi:[0,1]\n\ts_nop 1" \
+            : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(t[i][0]), "v"(t[i][1]), "v"(t[i][2]), "v"(t[i][3])); \
+        acc[4 * i + 0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * i + 0], v0[0], acc[4 * i + 0][0], 0, 0, 0); \
+        acc[4 * i + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * i + 1], v1[0], acc[4 * i + 1][0], 0, 0, 0); \
+        acc[4 * i + 2][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * i + 2], v2[0], acc[4 * i + 2][0], 0, 0, 0); \
+        acc[4 * i + 3][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * i + 3], v3[0], acc[4 * i + 3][0], 0, 0, 0); \
+        acc[4 * i + 0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * i + 0], v0[1], acc[4 * i + 0][1], 0, 0, 0); \
+        acc[4 * i + 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * i + 1], v1[1], acc[4 * i + 1][1], 0, 0, 0); \
+        acc[4 * i + 2][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * i + 2], v2[1], acc[4 * i + 2][1], 0, 0, 0); \
+        acc[4 * i + 3][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * i + 3], v3[1], acc[4 * i + 3][1], 0, 0, 0); \
       }                                                                                              \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i) {   /* (B^T d) B, then the 4 MFMAs of row i */  \
-        const float v0 = t[i][0] - t[i][2], v1 = t[i][1] + t[i][2], v2 = t[i][2] - t[i][1], v3 = t[i][1] - t[i][3]; \
-        acc[4 * i + 0][gr] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * i + 0], v0, acc[4 * i + 0][gr], 0, 0, 0); \
-        acc[4 * i + 1][gr] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * i + 1], v1, acc[4 * i + 1][gr], 0, 0, 0); \
-        acc[4 * i + 2][gr] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * i + 2], v2, acc[4 * i + 2][gr], 0, 0, 0); \
-        acc[4 * i + 3][gr] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * i + 3], v3, acc[4 * i + 3][gr], 0, 0, 0); \
-      }                                                                                              \
+    }                                                                                                \
     }                                                                                                \
     if (have_next) W2_STORE_X(xb ^ 1, cch + 1)                                                        \
     __syncthreads();                                                                                 \
@@ -244,9 +271,16 @@ __global__ __launch_bounds__(512) void conv_wino2_kernel(Wino2Args a) {
   W2_LOAD_X(0)
   W2_STORE_X(0, 0)
   __syncthreads();
-  for (int ch = 0; ch < a.nchunks; ch += 2) {
-    W2_STEP(ch, su0, su1)
-    if (ch + 1 < a.nchunks) W2_STEP(ch + 1, su1, su0)
+  // (loop peeled rather than "if (ch + 1 < n) STEP" inside the body: that form was MIScompiled by this toolchain --
+  // the second step's contributions vanished -- tools/debug/dbg_wino2*.py)
+  {
+    int ch = 0;
+#pragma unroll 1
+    for (; ch + 1 < a.nchunks; ch += 2) {
+      W2_STEP(ch, su0, su1)
+      W2_STEP(ch + 1, su1, su0)
+    }
+    if (ch < a.nchunks) W2_STEP(ch, su0, su1)
   }
 #undef W2_STEP
 #undef W2_STORE_X
@@ -342,7 +376,7 @@ extern "C" int fcd_conv_wino2_plan(const fcd_conv_desc* d, int mode) {
 
 extern "C" int64_t fcd_conv_wino2_filter_elems(int K, int C, int mode) {
   const int red = mode == 0 ? C : K;
-  return (int64_t)cdiv(red, W2_CB) * W2_SLAB;
+  return (int64_t)cdiv(red, W2_CB) * W2_KS * W2_SLAB;     // whole stages: the tail chunk is zero-filled by the packer
 }
 
 extern "C" int fcd_conv_wino2_pack(const float* w, float* U, int K, int C, int mode, void* stream) {

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Fused F(2x2,3x3) kernel vs the direct MFMA kernel on the 64-row layers of the headline workload (C-ABI calls)."""
+import ctypes
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fcd_gan_pytorch_amd import _ops as ops          # noqa: E402
+from fcd_gan_pytorch_amd._lib import lib, check       # noqa: E402
+
+SHAPES = [  # tag, N, C, HW, K
+    ('vgg conv1_2 64->64 @256 (N=208)', 208, 64, 256, 64),
+    ('vgg conv2_1 64->128 @128 dgrad (N=208)', 208, 64, 128, 128),
+    ('G 64->64 @256 (N=8)', 8, 64, 256, 64),
+    ('S inc 64->64 @256 (N=16)', 16, 64, 256, 64),
+]
+
+
+def timeit(fn, iters=5):
+    fn(); fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    s = ops._stream()
+    for tag, N, C, HW, K in (SHAPES[:1] if os.environ.get('W2_ONLY') else SHAPES):
+        x = torch.randn(N, C, HW, HW, device='cuda').relu_()
+        w = torch.randn(K, C, 3, 3, device='cuda') * 0.05
+        b = torch.zeros(K, device='cuda')
+        d = ops._desc(x.shape, w.shape, 1, 1)
+        y = torch.empty(N, K, HW, HW, device='cuda')
+        dy = torch.randn_like(y)
+        dx = torch.empty_like(x)
+        fl = 2.0 * N * K * HW * HW * C * 9
+        line = '%-40s' % tag
+        if lib.fcd_conv_wino2_plan(ctypes.byref(d), 0):
+            U = ops.wino2_weight(w, 0)
+            wp = ops.packed_weight(w, 0)
+            t2 = timeit(lambda: check(lib.fcd_conv2d_fwd_wino2(ctypes.byref(d), ops._p(x), ops._p(U), ops._p(b), ops._p(y), 1, None, 0.0,
+                                                               None, None, None, s)))
+            y2 = y.clone()
+            t1 = timeit(lambda: check(lib.fcd_conv2d_fwd(ctypes.byref(d), ops._p(x), ops._p(wp), ops._p(b), ops._p(y), 1, s)))
+            err = (y2 - y).abs().max().item() / y.abs().max().item()
+            line += ' fwd: fused %.3f ms (%.0f TF alg) direct %.3f ms (%.0f TF)  rel diff %.1e |' % (t2, fl / t2 / 1e9, t1, fl / t1 / 1e9, err)
+        if lib.fcd_conv_wino2_plan(ctypes.byref(d), 1):
+            U = ops.wino2_weight(w, 1)
+            wp = ops.packed_weight(w, 1)
+            t2 = timeit(lambda: check(lib.fcd_conv2d_bwd_data_wino2(ctypes.byref(d), ops._p(dy), ops._p(y), None, ops._p(U), ops._p(dx), s)))
+            d2 = dx.clone()
+            t1 = timeit(lambda: check(lib.fcd_conv2d_bwd_data(ctypes.byref(d), ops._p(dy), ops._p(y), ops._p(wp), ops._p(dx), s)))
+            err = (d2 - dx).abs().max().item() / dx.abs().max().item()
+            line += ' gated dgrad: fused %.3f ms (%.0f TF alg) direct %.3f ms (%.0f TF)  rel diff %.1e' % (t2, fl / t2 / 1e9, t1, fl / t1 / 1e9, err)
+        print(line)
+        del x, y, dy, dx
+
+
+if __name__ == '__main__':
+    main()
