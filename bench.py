@@ -143,6 +143,8 @@ def write_layer_tables(path, detail, psteps, args):
             tot_ms / psteps, tot_fl / (tot_ms * 1e-3) / 1e12, tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS)]
     for fam, title in (('conv_igemm_fwd', 'direct convolution, forward (algorithmic FLOPs)'),
                        ('conv_igemm_dgrad', 'direct convolution, data gradient (algorithmic FLOPs)'),
+                       ('conv_wino2_fwd', 'fused Winograd F(2x2,3x3) kernel, forward (algorithmic conv FLOPs; executed MFMA FLOPs = x 16/36)'),
+                       ('conv_wino2_dgrad', 'fused Winograd F(2x2,3x3) kernel, data gradient (algorithmic conv FLOPs; executed = x 16/36)'),
                        ('conv_wgrad', 'weight gradient, whole call incl. re-layout / transforms / reduce (algorithmic FLOPs, direct count)'),
                        ('conv_wino_fwd', 'Winograd layer calls, forward: three kernels (algorithmic conv FLOPs)'),
                        ('conv_wino_dgrad', 'Winograd layer calls, data gradient: three kernels (algorithmic conv FLOPs)')):
@@ -329,6 +331,7 @@ def main():
             fwd, dg, wg = prof['conv_igemm_fwd'], prof['conv_igemm_dgrad'], prof['conv_wgrad']
             zero = dict(ms=0.0, launches=0, flops=0.0, bytes=0.0)
             wf, wd = prof.get('conv_wino_fwd', zero), prof.get('conv_wino_dgrad', zero)
+            w2f, w2d = prof.get('conv_wino2_fwd', zero), prof.get('conv_wino2_dgrad', zero)
             wgemm, wxf = prof.get('wino_gemm', zero), prof.get('wino_transform', zero)
 
             def mfma_entry(name, ms, flops, launches, what):
@@ -353,6 +356,11 @@ def main():
                            '3x3 layers, the Winograd F(4x4,3x3) form (its GEMM launches are also part of wino_gemm_kernel above)',
                            wg['ms'], wg['flops'], wg['launches'], 'algorithmic weight-gradient FLOPs (direct count)'),
             ]
+            if w2f['launches'] + w2d['launches'] > 0:
+                cands.append(mfma_entry('conv_wino2_kernel (fused Winograd F(2x2,3x3): input transform + sixteen 16x16x4 fp32 MFMA GEMMs + output '
+                                        'transform in one kernel; the 64-row 3x3 layers, forward + data gradient)', w2f['ms'] + w2d['ms'],
+                                        (w2f['flops'] + w2d['flops']) * 16.0 / 36.0, w2f['launches'] + w2d['launches'],
+                                        'executed MFMA FLOPs (= algorithmic conv FLOPs x 16/36)'))
             cands.sort(key=lambda e: -(e['share_of_step_time'] or 0.0))
             res['roofline'] = cands[0]
             res['roofline']['other_mfma_kernels'] = cands[1:]
@@ -389,7 +397,7 @@ def main():
                     'transform_gbps': wxf['bytes'] / (wxf['ms'] * 1e-3) / 1e9 if wxf['ms'] > 0 else None,
                     'share_of_step_time': wms / (1e3 * dt_prof),
                 }
-                dms, dfl = fwd['ms'] + dg['ms'], fwd['flops'] + dg['flops']
+                dms, dfl = fwd['ms'] + dg['ms'] + w2f['ms'] + w2d['ms'], fwd['flops'] + dg['flops'] + w2f['flops'] + w2d['flops']
                 res['conv_fwd_dgrad_algorithmic_tflops'] = (dfl + wfl) / ((dms + wms) * 1e-3) / 1e12
             res['kernel_families'] = {
                 k: {'ms_per_step': v['ms'] / psteps, 'launches_per_step': v['launches'] / psteps,
@@ -405,8 +413,8 @@ def main():
             # executed = what the MFMA units are really asked to do (Winograd layers: the batched GEMM, 1/4 of the direct
             # count + tile padding); both over the HEADLINE step time (events off)
             wgw = prof.get('conv_wgrad_wino', zero)
-            alg = fwd['flops'] + dg['flops'] + wf['flops'] + wd['flops'] + wg['flops']
-            exe = fwd['flops'] + dg['flops'] + wgemm['flops'] + (wg['flops'] - wgw['flops'])
+            alg = fwd['flops'] + dg['flops'] + wf['flops'] + wd['flops'] + wg['flops'] + w2f['flops'] + w2d['flops']
+            exe = fwd['flops'] + dg['flops'] + wgemm['flops'] + (wg['flops'] - wgw['flops']) + (w2f['flops'] + w2d['flops']) * 16.0 / 36.0
             step_s = dt / args.steps
             res['whole_step'] = {'algorithmic_tflops': alg / psteps / step_s / 1e12,
                                  'executed_tflops': exe / psteps / step_s / 1e12,

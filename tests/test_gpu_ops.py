@@ -470,7 +470,8 @@ def test_conv_wino2_fused_kernel(case):
     y = ops.conv2d(xg, wg, bg, 1, 1)
     y.backward(g.cuda())
     assert_close(y, yr.float(), tol=tol, what='y')
-    assert_close(xg.grad, xr.grad.float(), tol=tol, what='dx')
+    # (a data gradient with > 64 GEMM rows runs on the three-kernel F(4x4) path: ~1e-5 transform rounding)
+    assert_close(xg.grad, xr.grad.float(), tol=tol if fused_d else 6e-5, what='dx')
     assert_close(wg.grad, wr.grad.float(), tol=5e-5, what='dw')
     assert torch.equal(ops.conv2d(xg, wg, bg, 1, 1), y)                     # bit-reproducible
     # the direct kernels give the same numbers to rounding (A/B switch of the library)
