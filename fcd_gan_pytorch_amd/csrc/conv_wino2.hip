@@ -37,16 +37,17 @@ namespace {
 constexpr int W2_ROWS = 64;                 // GEMM rows per workgroup (all of them)
 constexpr int W2_LP = 20;                   // floats per lane row in the filter slab: 16 xi + 4 pad (80-B pitch)
 constexpr int W2_SLAB = 4 * 64 * W2_LP;     // floats per chunk: [row group][lane][20]
-constexpr int W2_TH = 8, W2_TW = 32;        // output pixels per workgroup
-constexpr int W2_PH = W2_TH + 2, W2_PW = W2_TW + 2;
+constexpr int W2_TW = 32;                   // output columns per workgroup (rows: 4 per 4 waves)
+constexpr int W2_PW = W2_TW + 2;
 // LDS image of the input patch: PAIR rows.  Element (r, c) of pair row r holds (x[r][c], x[r + 2][c]) in two adjacent
 // floats: a wave's two tile rows (patch rows 4h + i and 4h + 2 + i, i = 0..3) then arrive as ready-made (tile row 0,
 // tile row 1) register pairs, four columns per two ds_read_b128, and every transform add is one v_pk_add_f32 serving
 // two MFMA operands.  (Each patch element is stored twice: as .x of pair row r and as .y of pair row r - 2.)
 constexpr int W2_RP = 72;                   // pair-row pitch (floats): 34 columns x 2, padded to a multiple of 4
-constexpr int W2_PL = 8 * W2_RP;            // 8 pair rows per channel plane
-constexpr int W2_KS = 2;                    // MFMA k-steps (4-channel chunks) per pipeline stage: one barrier per 8 channels
-constexpr int W2_CB = 4 * W2_KS;
+// Two workgroup shapes (template NW, KS):
+//   8 waves, 8 x 32 pixels, 8 channels per pipeline stage (KS = 2): one workgroup per CU, filters fetched once per 256 pixels
+//   4 waves, 4 x 32 pixels, 4 channels per stage (KS = 1): TWO independent workgroups per CU -- their barriers and LDS
+//   latency phases interleave on the SIMDs instead of lining up -- at twice the filter traffic from L2
 
 struct Wino2Args {
   const float* x;       // source (N, C, H, W) -- or the pooled gradient (N, C, Hp, Wp) when SRC == 2
@@ -98,14 +99,19 @@ __global__ void wino2_pack_kernel(const float* __restrict__ w, float* __restrict
   }
 }
 
-template <int SRC, int EPI>
-__global__ __launch_bounds__(512) void conv_wino2_kernel(Wino2Args a) {
-  constexpr int X_ELEMS = W2_CB * W2_PH * W2_PW;      // 2720
-  constexpr int X_PER_T = (X_ELEMS + 511) / 512;      // 6
+template <int SRC, int EPI, int NW, int W2_KS>
+__global__ __launch_bounds__(64 * NW) void conv_wino2_kernel(Wino2Args a) {
+  constexpr int NT = 64 * NW;                         // threads
+  constexpr int W2_CB = 4 * W2_KS;                    // channels per pipeline stage
+  constexpr int W2_TH = NW;                           // output rows per workgroup: 2 tile rows per 4 waves
+  constexpr int W2_PH = W2_TH + 2;
+  constexpr int W2_PL = W2_TH * W2_RP;                // pair rows per channel plane
+  constexpr int X_ELEMS = W2_CB * W2_PH * W2_PW;
+  constexpr int X_PER_T = (X_ELEMS + NT - 1) / NT;
   constexpr int XS_SZ = W2_CB * W2_PL;
   constexpr int U_STAGE = W2_KS * W2_SLAB;            // floats per stage of the filter pipeline
-  constexpr int U_INSTR = U_STAGE / 256;              // 40 wave-instructions of 1 KiB per stage
-  constexpr int U_PER_W = (U_INSTR + 7) / 8;
+  constexpr int U_INSTR = U_STAGE / 256;              // wave-instructions of 1 KiB per stage
+  constexpr int U_PER_W = (U_INSTR + NW - 1) / NW;
   __shared__ __attribute__((aligned(16))) float su0[U_STAGE];
   __shared__ __attribute__((aligned(16))) float su1[U_STAGE];
   __shared__ __attribute__((aligned(16))) float sx[2 * XS_SZ];
@@ -149,13 +155,13 @@ __global__ __launch_bounds__(512) void conv_wino2_kernel(Wino2Args a) {
   const int ih0 = p0 - 1, iw0 = q0 - 1;
 #pragma unroll
   for (int i = 0; i < X_PER_T; ++i) {
-    const int idx = tid + i * 512;
+    const int idx = tid + i * NT;
     const int cc = idx / (W2_PH * W2_PW), rem = idx % (W2_PH * W2_PW);
     const int ph = rem / W2_PW, pw = rem % W2_PW;
     const int ih = ih0 + ph, iw = iw0 + pw;
     bool ok = idx < X_ELEMS && ih >= 0 && iw >= 0 && ih < a.H && iw < a.W;
     int goff = (cc * a.H + ih) * a.W + iw;
-    x_loff[i] = ph < 8 ? cc * W2_PL + ph * W2_RP + 2 * pw : -1;
+    x_loff[i] = ph < W2_TH ? cc * W2_PL + ph * W2_RP + 2 * pw : -1;
     x_loff2[i] = ph >= 2 ? cc * W2_PL + (ph - 2) * W2_RP + 2 * pw + 1 : -1;
     x_want[i] = 0;
     if (SRC == 2) {
@@ -177,8 +183,8 @@ __global__ __launch_bounds__(512) void conv_wino2_kernel(Wino2Args a) {
   {                                                                                                  \
     const float* usrc = a.U + (size_t)(CH) * U_STAGE + lane * 4;                                     \
     _Pragma("unroll") for (int j = 0; j < U_PER_W; ++j) {                                            \
-      const int ins = wave + 8 * j;                                                                  \
-      if (U_INSTR % 8 == 0 || ins < U_INSTR)                                                         \
+      const int ins = wave + NW * j;                                                                 \
+      if (U_INSTR % NW == 0 || ins < U_INSTR)                                                        \
         __builtin_amdgcn_global_load_lds((gbl_void_t*)(usrc + ins * 256), (lds_void_t*)((DST) + ins * 256), 16, 0, 0); \
     }                                                                                                \
   }
@@ -201,7 +207,7 @@ __global__ __launch_bounds__(512) void conv_wino2_kernel(Wino2Args a) {
   {                                                                                                  \
     const int cleft = a.C - (CH) * W2_CB;                                                            \
     _Pragma("unroll") for (int i = 0; i < X_PER_T; ++i) {                                            \
-      if (tid + i * 512 < X_ELEMS) {                                                                 \
+      if (tid + i * NT < X_ELEMS) {                                                                  \
         bool keep = (unsigned)x_cc[i] < (unsigned)cleft;                                             \
         if (SRC == 2) keep = keep && mcode[i] == x_want[i];                                          \
         if (SRC == 1) keep = keep && mr[i] > 0.f;                                                    \
@@ -376,7 +382,7 @@ extern "C" int fcd_conv_wino2_plan(const fcd_conv_desc* d, int mode) {
 
 extern "C" int64_t fcd_conv_wino2_filter_elems(int K, int C, int mode) {
   const int red = mode == 0 ? C : K;
-  return (int64_t)cdiv(red, W2_CB) * W2_KS * W2_SLAB;     // whole stages: the tail chunk is zero-filled by the packer
+  return (int64_t)round_up(cdiv(red, 4), 2) * W2_SLAB;     // whole 8-channel stages: the tail chunk is zero-filled by the packer
 }
 
 extern "C" int fcd_conv_wino2_pack(const float* w, float* U, int K, int C, int mode, void* stream) {
@@ -399,12 +405,28 @@ static int w2_xcd() {
   return v;
 }
 
+static int w2_waves() {     // FCD_WINO2_WAVES = 8 (one 8 x 32 workgroup per CU) | 4 (two 4 x 32 workgroups per CU)
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("FCD_WINO2_WAVES");
+    v = (e && atoi(e) == 8) ? 8 : 4;
+  }
+  return v;
+}
+
 template <int SRC, int EPI>
-static void w2_launch(Wino2Args& a, hipStream_t st) {
-  a.tiles_p = cdiv(a.H, W2_TH);
+static void w2_launch(Wino2Args& a, int red, hipStream_t st) {
   a.tiles_q = cdiv(a.W, W2_TW);
   a.xcd_remap = w2_xcd();
-  hipLaunchKernelGGL((conv_wino2_kernel<SRC, EPI>), dim3((unsigned)(a.N * a.tiles_p * a.tiles_q)), dim3(512), 0, st, a);
+  if (w2_waves() == 8) {
+    a.tiles_p = cdiv(a.H, 8);
+    a.nchunks = cdiv(red, 8);
+    hipLaunchKernelGGL((conv_wino2_kernel<SRC, EPI, 8, 2>), dim3((unsigned)(a.N * a.tiles_p * a.tiles_q)), dim3(512), 0, st, a);
+  } else {
+    a.tiles_p = cdiv(a.H, 4);
+    a.nchunks = cdiv(red, 4);
+    hipLaunchKernelGGL((conv_wino2_kernel<SRC, EPI, 4, 1>), dim3((unsigned)(a.N * a.tiles_p * a.tiles_q)), dim3(256), 0, st, a);
+  }
 }
 
 // y = act(conv(x, w) + bias) + residual, or (pool_y, code) = maxpool2(relu(conv + bias)) when pool_y != NULL
@@ -419,12 +441,12 @@ extern "C" int fcd_conv2d_fwd_wino2(const fcd_conv_desc* d, const float* x, cons
   a.x = x; a.U = U; a.bias = bias; a.y = y; a.pool_y = pool_y; a.code_out = code; a.residual = residual;
   a.relu = act == FCD_ACT_RELU; a.act_slope = (act == FCD_ACT_LEAKY || act == FCD_ACT_PRELU) ? 1 : 0;
   a.slope_ptr = slope_ptr; a.slope_imm = slope_imm;
-  a.N = d->N; a.C = d->C; a.H = d->H; a.W = d->W; a.K = d->K; a.nchunks = cdiv(d->C, W2_CB);
+  a.N = d->N; a.C = d->C; a.H = d->H; a.W = d->W; a.K = d->K;
   const double flops = 2.0 * d->N * d->K * (double)d->P * d->Q * d->C * 9;
   const double bytes = 4.0 * ((double)d->N * d->C * d->H * d->W + (pool_y ? 0.3125 : 1.0) * d->N * d->K * d->P * d->Q +
                               (double)d->K * d->C * 16);
   FcdProfScope prof(FCD_K_WINO2_FWD, (hipStream_t)stream, flops, bytes, fcd_prof_tag_desc(pool_y ? "w2_fwd_pool" : "w2_fwd", d));
-  if (pool_y) w2_launch<0, 1>(a, (hipStream_t)stream); else w2_launch<0, 0>(a, (hipStream_t)stream);
+  if (pool_y) w2_launch<0, 1>(a, d->C, (hipStream_t)stream); else w2_launch<0, 0>(a, d->C, (hipStream_t)stream);
   FCD_LAUNCH_CHECK("conv2d_fwd_wino2");
   return FCD_OK;
 }
@@ -438,14 +460,13 @@ extern "C" int fcd_conv2d_bwd_data_wino2(const fcd_conv_desc* d, const float* dy
   memset(&a, 0, sizeof(a));
   a.x = dy; a.U = U; a.y = dx; a.mask = pool_code ? nullptr : relu_out; a.code_in = pool_code;
   a.N = d->N; a.C = d->K; a.H = d->P; a.W = d->Q; a.K = d->C; a.Hp = d->P / 2; a.Wp = d->Q / 2;
-  a.nchunks = cdiv(d->K, W2_CB);
   const double flops = 2.0 * d->N * d->K * (double)d->P * d->Q * d->C * 9;
   const double bytes = 4.0 * ((double)d->N * d->C * d->H * d->W + (pool_code ? 0.3125 : (relu_out ? 2.0 : 1.0)) * d->N * d->K * d->P * d->Q +
                               (double)d->K * d->C * 16);
   FcdProfScope prof(FCD_K_WINO2_DGRAD, (hipStream_t)stream, flops, bytes, fcd_prof_tag_desc("w2_dgrad", d));
-  if (pool_code) w2_launch<2, 0>(a, (hipStream_t)stream);
-  else if (relu_out) w2_launch<1, 0>(a, (hipStream_t)stream);
-  else w2_launch<0, 0>(a, (hipStream_t)stream);
+  if (pool_code) w2_launch<2, 0>(a, d->K, (hipStream_t)stream);
+  else if (relu_out) w2_launch<1, 0>(a, d->K, (hipStream_t)stream);
+  else w2_launch<0, 0>(a, d->K, (hipStream_t)stream);
   FCD_LAUNCH_CHECK("conv2d_bwd_data_wino2");
   return FCD_OK;
 }

@@ -459,6 +459,9 @@ def test_conv_wino2_fused_kernel(case):
     assert fused_f == (32 < K <= 64 and C >= 32) and fused_d == (32 < C <= 64 and K >= 32)
     assert fused_f or fused_d
     tol, flip_tol = 5e-6, 4e-3
+    tol_f = tol if fused_f else 6e-5        # a forward with > 64 rows runs on the three-kernel F(4x4) path
+    if not (fused_f and fused_d):
+        flip_tol = 2e-2
     x = rnd(N, C, H, W, seed=31)
     w = rnd(K, C, 3, 3, seed=32, scale=(2.0 / (C * 9)) ** 0.5)
     b = rnd(K, seed=33, scale=0.1)
@@ -469,7 +472,7 @@ def test_conv_wino2_fused_kernel(case):
     xg, wg, bg = (t.cuda().requires_grad_(True) for t in (x, w, b))
     y = ops.conv2d(xg, wg, bg, 1, 1)
     y.backward(g.cuda())
-    assert_close(y, yr.float(), tol=tol, what='y')
+    assert_close(y, yr.float(), tol=tol_f, what='y')
     # (a data gradient with > 64 GEMM rows runs on the three-kernel F(4x4) path: ~1e-5 transform rounding)
     assert_close(xg.grad, xr.grad.float(), tol=tol if fused_d else 6e-5, what='dx')
     assert_close(wg.grad, wr.grad.float(), tol=5e-5, what='dw')
@@ -482,14 +485,14 @@ def test_conv_wino2_fused_kernel(case):
             y_direct = ops.conv2d(xg, wg, bg, 1, 1)
     finally:
         lib.fcd_conv_wino_set(prev)
-    assert (y_direct - y).abs().max().item() <= 5e-6 * y.abs().max().item()
+    assert (y_direct - y).abs().max().item() <= 2 * tol_f * y.abs().max().item()
     # ReLU epilogue + mask-gated data gradient
     xr3 = x.double().requires_grad_(True)
     F.relu(F.conv2d(xr3, w.double(), b.double(), padding=1)).backward(g.double())
     xg3 = x.cuda().requires_grad_(True)
     y3 = ops.conv2d(xg3, w.cuda(), b.cuda(), 1, 1, relu=True)
     y3.backward(g.cuda())
-    assert_close(y3, F.relu(yr).float(), tol=tol, what='relu y')
+    assert_close(y3, F.relu(yr).float(), tol=tol_f, what='relu y')
     dd = xg3.grad.cpu().double() - xr3.grad
     assert (dd.norm() / xr3.grad.norm()).item() < flip_tol, 'relu dx'
     # ReLU + max-pool epilogue (ties: constant block; all-negative channels) + code-routed data gradient
@@ -505,7 +508,7 @@ def test_conv_wino2_fused_kernel(case):
         xg2 = x2.cuda().requires_grad_(True)
         yp = ops.conv2d_relu_maxpool2(xg2, w.cuda(), b2.cuda())
         yp.backward(gp.cuda())
-        assert_close(yp, ypr.float(), tol=tol, what='pooled y')
+        assert_close(yp, ypr.float(), tol=tol_f, what='pooled y')
         dd = xg2.grad.cpu().double() - xr2.grad
         assert (dd.norm() / xr2.grad.norm().clamp_min(1e-30)).item() < flip_tol, 'pooled dx'
     # inference epilogue: PReLU + residual
@@ -514,4 +517,4 @@ def test_conv_wino2_fused_kernel(case):
     got = ops.conv2d_infer(x.cuda(), w.cuda(), b.cuda(), 1, 1, ops.ACT_PRELU, slope=slope.cuda(), residual=res.cuda())
     ref = yr.detach()
     ref = torch.where(ref > 0, ref, ref * 0.25) + res.double()
-    assert_close(got, ref.float(), tol=tol, what='prelu + residual')
+    assert_close(got, ref.float(), tol=tol_f, what='prelu + residual')
