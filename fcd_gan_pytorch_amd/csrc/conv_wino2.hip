@@ -33,9 +33,15 @@ typedef __attribute__((address_space(1))) const void gbl_void_t;
 
 int fcd_wino_mode_now();   // conv_wino.hip: 0 = direct kernels only (tests' A/B switch), 2 / 4 otherwise
 
+// W2_EXP: diagnostic builds only (WRONG results): 1 = no filter DMA / patch loads / LDS stores in the loop, 2 = no barrier in the
+// loop, 4 = operands from registers instead of LDS, 8 = no transform adds
+#ifndef W2_EXP
+#define W2_EXP 0
+#endif
 namespace {
 constexpr int W2_ROWS = 64;                 // GEMM rows per workgroup (all of them)
-constexpr int W2_LP = 20;                   // floats per lane row in the filter slab: 16 xi + 4 pad (80-B pitch)
+constexpr int W2_LP = 12;                   // floats per lane row in the filter slab: the ROW-transformed filter G g (4 x 3),
+                                            // 48-B pitch (conflict-free ds_read_b128); the column transform (.) G^T runs in the kernel
 constexpr int W2_SLAB = 4 * 64 * W2_LP;     // floats per chunk: [row group][lane][20]
 constexpr int W2_TW = 32;                   // output columns per workgroup (rows: 4 per 4 waves)
 constexpr int W2_PW = W2_TW + 2;
@@ -44,10 +50,15 @@ constexpr int W2_PW = W2_TW + 2;
 // tile row 1) register pairs, four columns per two ds_read_b128, and every transform add is one v_pk_add_f32 serving
 // two MFMA operands.  (Each patch element is stored twice: as .x of pair row r and as .y of pair row r - 2.)
 constexpr int W2_RP = 72;                   // pair-row pitch (floats): 34 columns x 2, padded to a multiple of 4
-// Two workgroup shapes (template NW, KS):
-//   8 waves, 8 x 32 pixels, 8 channels per pipeline stage (KS = 2): one workgroup per CU, filters fetched once per 256 pixels
-//   4 waves, 4 x 32 pixels, 4 channels per stage (KS = 1): TWO independent workgroups per CU -- their barriers and LDS
-//   latency phases interleave on the SIMDs instead of lining up -- at twice the filter traffic from L2
+// Workgroup shapes (template NW, KS; FCD_WINO2_WAVES / FCD_WINO2_KS select them for A/B runs):
+//   8 waves, 8 x 32 pixels, 8 channels per pipeline stage (KS = 2)  <- default: 6.2 ms on VGG conv1_2 (N = 208) vs 8.2 direct
+//   8 waves, 4 channels per stage (KS = 1): 6.8 ms (twice the barriers)
+//   4 waves, 4 x 32 pixels (two or three independent workgroups per CU): 9.1 - 10.2 ms -- half the pixels per filter
+//   fetch and 1.5x halo rows; kept for the record
+// Where the 6.2 ms go (diagnostic builds, W2_EXP): pure MFMA floor 2.85 ms; MFMA + transforms + per-workgroup prologue /
+// epilogue with NO memory instruction in the loop 4.0 ms (one workgroup per CU: nothing hides the prologue's memory
+// round trip and the epilogue's stores); + LDS operand reads 0.9, + filter DMA / patch loads / LDS stores 0.9, + barrier
+// 0.3.  PMC: 47 % MFMA-busy, 32 % of wave cycles parked at s_waitcnt / s_barrier (profiles/r02_pmc_wino2.md).
 
 struct Wino2Args {
   const float* x;       // source (N, C, H, W) -- or the pooled gradient (N, C, Hp, Wp) when SRC == 2
@@ -65,7 +76,9 @@ struct Wino2Args {
   int N, C, H, W, K, Hp, Wp, nchunks, tiles_p, tiles_q, xcd_remap;
 };
 
-// U2 = G g G^T for F(2x2, 3x3), G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+// Row-transformed filters G g (4 x 3 per (row, channel)), G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]: 12 floats instead of the 16
+// of G g G^T -- the kernel is bound by the filter traffic from L2 (LDS-DMA ~9 B/cycle/CU), so 40 % fewer bytes beat 0.5 extra
+// VALU operations per MFMA
 __global__ void wino2_pack_kernel(const float* __restrict__ w, float* __restrict__ U, int K, int C, int mode,
                                   long long total) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -77,23 +90,22 @@ __global__ void wino2_pack_kernel(const float* __restrict__ w, float* __restrict
     const int row = 16 * g + (l & 15), red = 4 * q + (l >> 4);
     const int rows = mode == 0 ? K : C, reds = mode == 0 ? C : K;
     float v = 0.f;
-    if (e < 16 && row < rows && red < reds) {
-      float gk[3][3];
-#pragma unroll
-      for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int s = 0; s < 3; ++s)
-          gk[r][s] = mode == 0 ? w[(((size_t)row * C + red) * 3 + r) * 3 + s]
-                               : w[(((size_t)red * C + row) * 3 + (2 - r)) * 3 + (2 - s)];
-      const int a = e >> 2, b = e & 3;
-      // row a of G applied to the columns, then row b of G to the rows
-      float col[3];
-#pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        const float g0 = gk[0][s], g1 = gk[1][s], g2 = gk[2][s];
-        col[s] = a == 0 ? g0 : (a == 1 ? 0.5f * (g0 + g1 + g2) : (a == 2 ? 0.5f * (g0 - g1 + g2) : g2));
+    if (row < rows && red < reds) {
+      // element e = 3 a + s of the half-transformed filter: T[a][s] = sum_r G[a][r] g[r][s]; the middle column is stored
+      // halved (the kernel forms u1 = m + h, u2 = m - h with m = (T[a][0] + T[a][2]) / 2, h = T[a][1] / 2)
+      const int a = e / 3, sc = e % 3;
+      float g0, g1, g2;
+      if (mode == 0) {
+        g0 = w[(((size_t)row * C + red) * 3 + 0) * 3 + sc];
+        g1 = w[(((size_t)row * C + red) * 3 + 1) * 3 + sc];
+        g2 = w[(((size_t)row * C + red) * 3 + 2) * 3 + sc];
+      } else {
+        g0 = w[(((size_t)red * C + row) * 3 + 2) * 3 + (2 - sc)];
+        g1 = w[(((size_t)red * C + row) * 3 + 1) * 3 + (2 - sc)];
+        g2 = w[(((size_t)red * C + row) * 3 + 0) * 3 + (2 - sc)];
       }
-      v = b == 0 ? col[0] : (b == 1 ? 0.5f * (col[0] + col[1] + col[2]) : (b == 2 ? 0.5f * (col[0] - col[1] + col[2]) : col[2]));
+      v = a == 0 ? g0 : (a == 1 ? 0.5f * (g0 + g1 + g2) : (a == 2 ? 0.5f * (g0 - g1 + g2) : g2));
+      if (sc == 1) v *= 0.5f;
     }
     U[i] = v;
   }
@@ -105,7 +117,10 @@ __global__ __launch_bounds__(64 * NW) void conv_wino2_kernel(Wino2Args a) {
   constexpr int W2_CB = 4 * W2_KS;                    // channels per pipeline stage
   constexpr int W2_TH = NW;                           // output rows per workgroup: 2 tile rows per 4 waves
   constexpr int W2_PH = W2_TH + 2;
-  constexpr int W2_PL = W2_TH * W2_RP;                // pair rows per channel plane
+  // pair rows per channel plane, padded to a multiple of 64 floats: the four channel groups of a wave (lanes 16 kc ..)
+  // must start on the same bank, or the 16-lane groups in which ds_read_b128 is served (they mix lanes of two channel
+  // groups) collide two ways on every operand read
+  constexpr int W2_PL = (W2_TH * W2_RP + 63) / 64 * 64;
   constexpr int X_ELEMS = W2_CB * W2_PH * W2_PW;
   constexpr int X_PER_T = (X_ELEMS + NT - 1) / NT;
   constexpr int XS_SZ = W2_CB * W2_PL;
@@ -151,7 +166,9 @@ __global__ __launch_bounds__(64 * NW) void conv_wino2_kernel(Wino2Args a) {
 
   float xr[X_PER_T], mr[X_PER_T];
   unsigned mcode[X_PER_T], x_want[X_PER_T], x_boff[X_PER_T];
-  int x_loff[X_PER_T], x_loff2[X_PER_T], x_cc[X_PER_T];      // LDS offsets of the .x / .y copy (-1: none)
+  // per staged element: byte offset in the source chunk + ONE packed word {LDS offset of the .x copy : 16, channel : 4,
+  // .x copy exists : 1, .y copy exists : 1} -- staging registers are what pushes this kernel against the 256-VGPR limit
+  unsigned x_pk[X_PER_T];
   const int ih0 = p0 - 1, iw0 = q0 - 1;
 #pragma unroll
   for (int i = 0; i < X_PER_T; ++i) {
@@ -161,8 +178,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wino2_kernel(Wino2Args a) {
     const int ih = ih0 + ph, iw = iw0 + pw;
     bool ok = idx < X_ELEMS && ih >= 0 && iw >= 0 && ih < a.H && iw < a.W;
     int goff = (cc * a.H + ih) * a.W + iw;
-    x_loff[i] = ph < W2_TH ? cc * W2_PL + ph * W2_RP + 2 * pw : -1;
-    x_loff2[i] = ph >= 2 ? cc * W2_PL + (ph - 2) * W2_RP + 2 * pw + 1 : -1;
+    const unsigned lo = (unsigned)(cc * W2_PL + ph * W2_RP + 2 * pw);       // .y copy lives at lo - 2 * W2_RP + 1
     x_want[i] = 0;
     if (SRC == 2) {
       const int hp = ih >> 1, wq = iw >> 1;
@@ -170,7 +186,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wino2_kernel(Wino2Args a) {
       goff = (cc * a.Hp + hp) * a.Wp + wq;
       x_want[i] = (unsigned)((((ih & 1) << 1) | (iw & 1)) | 4);
     }
-    x_cc[i] = ok ? cc : -1;
+    x_pk[i] = lo | ((ok ? (unsigned)cc : 15u) << 16) | ((ph < W2_TH ? 1u : 0u) << 20) | ((ph >= 2 ? 1u : 0u) << 21);
     x_boff[i] = ok ? (unsigned)goff * 4u : 0u;
   }
   const int in_plane = (SRC == 2) ? a.Hp * a.Wp : a.H * a.W;
@@ -197,7 +213,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wino2_kernel(Wino2Args a) {
     const unsigned char* csrc = cin_ + (size_t)(CH) * chunk_elems;                                   \
     _Pragma("unroll") for (int i = 0; i < X_PER_T; ++i) {                                            \
       unsigned off = x_boff[i];                                                                      \
-      if (tail) off = (x_cc[i] < cleft) ? off : 0u;                                                  \
+      if (tail) off = ((int)((x_pk[i] >> 16) & 15u) < cleft) ? off : 0u;                             \
       xr[i] = *(const float*)(xsrc + off);                                                           \
       if (SRC == 1) mr[i] = *(const float*)(msrc + off);                                             \
       if (SRC == 2) mcode[i] = csrc[off >> 2];                                                       \
@@ -208,12 +224,13 @@ __global__ __launch_bounds__(64 * NW) void conv_wino2_kernel(Wino2Args a) {
     const int cleft = a.C - (CH) * W2_CB;                                                            \
     _Pragma("unroll") for (int i = 0; i < X_PER_T; ++i) {                                            \
       if (tid + i * NT < X_ELEMS) {                                                                  \
-        bool keep = (unsigned)x_cc[i] < (unsigned)cleft;                                             \
+        bool keep = ((x_pk[i] >> 16) & 15u) < (unsigned)min(cleft, 15);                              \
         if (SRC == 2) keep = keep && mcode[i] == x_want[i];                                          \
         if (SRC == 1) keep = keep && mr[i] > 0.f;                                                    \
         const float xv = keep ? xr[i] : 0.f;                                                         \
-        if (x_loff[i] >= 0) sx[(BUF) * XS_SZ + x_loff[i]] = xv;                                      \
-        if (x_loff2[i] >= 0) sx[(BUF) * XS_SZ + x_loff2[i]] = xv;                                    \
+        const int lo_ = (int)(x_pk[i] & 0xFFFFu);                                                    \
+        if (x_pk[i] & (1u << 20)) sx[(BUF) * XS_SZ + lo_] = xv;                                      \
+        if (x_pk[i] & (1u << 21)) sx[(BUF) * XS_SZ + lo_ - 2 * W2_RP + 1] = xv;                      \
       }                                                                                              \
     }                                                                                                \
   }
@@ -222,16 +239,24 @@ __global__ __launch_bounds__(64 * NW) void conv_wino2_kernel(Wino2Args a) {
     const int cch = (CH);                                                                             \
     const bool have_next = cch + 1 < a.nchunks;                                                       \
     const int xb = cch & 1;                                                                           \
-    if (have_next) {                                                                                 \
+    if (have_next && !(W2_EXP & 1)) {                                                                \
       W2_DMA(cch + 1, UNXT)                                                                           \
       W2_LOAD_X(cch + 1)                                                                              \
     }                                                                                                \
     const float* xl = sx + xb * XS_SZ;                                                               \
     _Pragma("unroll") for (int ks = 0; ks < W2_KS; ++ks) {                                           \
     float av[16];                                                                                    \
-    _Pragma("unroll") for (int v4 = 0; v4 < 4; ++v4) {                                               \
-      const f32x4 t4 = *(const f32x4*)((UCUR) + ks * W2_SLAB + aoff + 4 * v4);                       \
-      av[4 * v4] = t4[0]; av[4 * v4 + 1] = t4[1]; av[4 * v4 + 2] = t4[2]; av[4 * v4 + 3] = t4[3];    \
+    {                                                                                                \
+      const float* up = (UCUR) + ks * W2_SLAB + aoff;                                                \
+      const f32x4 r0 = (W2_EXP & 4) ? f32x4{(float)lane, 1.f, 2.f, (float)ks} : *(const f32x4*)up;    \
+      const f32x4 r1 = (W2_EXP & 4) ? f32x4{3.f, (float)lane, 2.f, 1.f} : *(const f32x4*)(up + 4);     \
+      const f32x4 r2 = (W2_EXP & 4) ? f32x4{1.f, 1.f, (float)lane, 4.f} : *(const f32x4*)(up + 8);     \
+      const float tt[12] = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3], r2[0], r2[1], r2[2], r2[3]}; \
+      _Pragma("unroll") for (int ar = 0; ar < 4; ++ar) {   /* (G g) G^T: u0 = x0, u1 = m + h, u2 = m - h, u3 = x2 */ \
+        const float x0 = tt[3 * ar], hh = tt[3 * ar + 1], x2 = tt[3 * ar + 2];                       \
+        const float mm = 0.5f * (x0 + x2);                                                           \
+        av[4 * ar] = x0; av[4 * ar + 1] = mm + hh; av[4 * ar + 2] = mm - hh; av[4 * ar + 3] = x2;     \
+      }                                                                                              \
     }                                                                                                \
     /* both tile rows of the wave at once: every quantity is a (tile row 0, tile row 1) pair in two adjacent VGPRs */ \
     /* (ds_read2_b32 fills such a pair from two addresses), so each transform add is ONE v_pk_add_f32 for two MFMA */ \
@@ -240,7 +265,8 @@ __global__ __launch_bounds__(64 * NW) void conv_wino2_kernel(Wino2Args a) {
       const float* xp = xl + ks * 4 * W2_PL + boff[0];                                               \
       f32x2 d[4][4];                                                                                 \
       _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                \
-        const f32x4 q0 = *(const f32x4*)(xp + i * W2_RP), q1 = *(const f32x4*)(xp + i * W2_RP + 4);  \
+        const f32x4 q0 = (W2_EXP & 4) ? f32x4{(float)lane, (float)i, 1.f, 2.f} : *(const f32x4*)(xp + i * W2_RP);      \
+        const f32x4 q1 = (W2_EXP & 4) ? f32x4{1.f, (float)lane, (float)i, 3.f} : *(const f32x4*)(xp + i * W2_RP + 4);  \
         d[i][0] = __builtin_shufflevector(q0, q0, 0, 1); d[i][1] = __builtin_shufflevector(q0, q0, 2, 3); \
         d[i][2] = __builtin_shufflevector(q1, q1, 0, 1); d[i][3] = __builtin_shufflevector(q1, q1, 2, 3); \
       }                                                                                              \
@@ -269,8 +295,8 @@ __global__ __launch_bounds__(64 * NW) void conv_wino2_kernel(Wino2Args a) {
       }                                                                                              \
     }                                                                                                \
     }                                                                                                \
-    if (have_next) W2_STORE_X(xb ^ 1, cch + 1)                                                        \
-    __syncthreads();                                                                                 \
+    if (have_next && !(W2_EXP & 1)) W2_STORE_X(xb ^ 1, cch + 1)                                       \
+    if (!(W2_EXP & 2)) __syncthreads();                                                                                 \
   }
 
   W2_DMA(0, su0)
@@ -409,7 +435,7 @@ static int w2_waves() {     // FCD_WINO2_WAVES = 8 (one 8 x 32 workgroup per CU)
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("FCD_WINO2_WAVES");
-    v = (e && atoi(e) == 8) ? 8 : 4;
+    v = (e && atoi(e) == 4) ? 4 : 8;
   }
   return v;
 }
@@ -418,10 +444,23 @@ template <int SRC, int EPI>
 static void w2_launch(Wino2Args& a, int red, hipStream_t st) {
   a.tiles_q = cdiv(a.W, W2_TW);
   a.xcd_remap = w2_xcd();
-  if (w2_waves() == 8) {
+  static int ks = -1;
+  if (ks < 0) {
+    const char* e = getenv("FCD_WINO2_KS");
+    ks = (e && atoi(e) == 1) ? 1 : 2;
+  }
+  if (w2_waves() == 8 && ks == 2) {
     a.tiles_p = cdiv(a.H, 8);
     a.nchunks = cdiv(red, 8);
     hipLaunchKernelGGL((conv_wino2_kernel<SRC, EPI, 8, 2>), dim3((unsigned)(a.N * a.tiles_p * a.tiles_q)), dim3(512), 0, st, a);
+  } else if (w2_waves() == 8) {
+    a.tiles_p = cdiv(a.H, 8);
+    a.nchunks = cdiv(red, 4);
+    hipLaunchKernelGGL((conv_wino2_kernel<SRC, EPI, 8, 1>), dim3((unsigned)(a.N * a.tiles_p * a.tiles_q)), dim3(512), 0, st, a);
+  } else if (ks == 2) {
+    a.tiles_p = cdiv(a.H, 4);
+    a.nchunks = cdiv(red, 8);
+    hipLaunchKernelGGL((conv_wino2_kernel<SRC, EPI, 4, 2>), dim3((unsigned)(a.N * a.tiles_p * a.tiles_q)), dim3(256), 0, st, a);
   } else {
     a.tiles_p = cdiv(a.H, 4);
     a.nchunks = cdiv(red, 4);
