@@ -984,6 +984,21 @@ __global__ __launch_bounds__(256) void wino_wg_final_kernel(const float* __restr
   for (int j = threadIdx.x; j < nout; j += 256) dw[i0 * 9 + j] = st9[j];
 }
 
+// Split partials of dU summed in fixed (ascending split) order, in place into split 0: one float4 of the 36 K C block per
+// thread => a grid of 9 K C / 256 workgroups streaming the partials coalesced.  (The final transform used to do this sum
+// itself with K C threads -- 64 workgroups for a 128 x 128 filter walking 43 x 36 strided reads each: 0.5 ms for 100 MB.)
+__global__ __launch_bounds__(256) void wino_wg_splitsum_kernel(float* __restrict__ dU, long long n4, long long ss4, int splits) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  float4* p = (float4*)dU;
+  float4 s = p[i];
+  for (int sp = 1; sp < splits; ++sp) {
+    const float4 v = p[(size_t)sp * ss4 + i];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  p[i] = s;
+}
+
 __global__ __launch_bounds__(256) void wino_psum_fin_kernel(const float* __restrict__ psum, float* __restrict__ out, int C,
                                                             int nblk) {
   __shared__ double red[16];
@@ -1082,8 +1097,15 @@ int fcd_wino_wgrad_run(const fcd_conv_desc* d, const float* x, const float* dy, 
   }
   {
     FcdProfScope p3(FCD_K_WINO_XFORM, st, 0.0, (double)pl.du_bytes + 4.0 * 9 * d->K * d->C, fcd_prof_tag_desc("wgrad_fin", d));
+    int fin_splits = pl.splits;
+    const long long n = 36LL * d->K * d->C;
+    if (pl.splits > 1 && (n & 3) == 0) {
+      hipLaunchKernelGGL(wino_wg_splitsum_kernel, dim3((unsigned)cdiv64(n >> 2, 256)), dim3(256), 0, st, dU, n >> 2, n >> 2,
+                         pl.splits);
+      fin_splits = 1;
+    }
     hipLaunchKernelGGL(wino_wg_final_kernel, dim3((unsigned)cdiv64((long long)d->K * d->C, 256)), dim3(256), 0, st,
-                       (const float*)dU, dw, d->K, d->C, pl.splits);
+                       (const float*)dU, dw, d->K, d->C, fin_splits);
   }
   return 0;
 }

@@ -162,6 +162,21 @@ __global__ void upsample2x_bwd_kernel(const float* __restrict__ dy, float* __res
     oh_lo = max(oh_lo - 1, 0); oh_hi = min(oh_hi + 1, OH - 1);
     ow_lo = max(ow_lo - 1, 0); ow_hi = min(ow_hi + 1, OW - 1);
     const float* g = dy + pl * OH * OW;
+    // column weights once per pixel (they do not depend on the output row): <= 8 candidate columns for a x2 grid
+    constexpr int MAXC = 8;
+    float ww[MAXC];
+    const int ncol = min(ow_hi - ow_lo + 1, MAXC);
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j) {
+      float v = 0.f;
+      if (j < ncol) {
+        int w0, w1; float lw;
+        ac_src(ow_lo + j, sw, W, &w0, &w1, &lw);
+        if (w0 == w) v += 1.f - lw;
+        if (w1 == w) v += lw;
+      }
+      ww[j] = v;
+    }
     float acc = 0.f;
     for (int oh = oh_lo; oh <= oh_hi; ++oh) {
       int h0, h1; float lh;
@@ -171,14 +186,9 @@ __global__ void upsample2x_bwd_kernel(const float* __restrict__ dy, float* __res
       if (h1 == h) wh += lh;
       if (wh == 0.f) continue;
       float rowacc = 0.f;
-      for (int ow = ow_lo; ow <= ow_hi; ++ow) {
-        int w0, w1; float lw;
-        ac_src(ow, sw, W, &w0, &w1, &lw);
-        float ww = 0.f;
-        if (w0 == w) ww += 1.f - lw;
-        if (w1 == w) ww += lw;
-        if (ww != 0.f) rowacc += ww * g[oh * OW + ow];
-      }
+#pragma unroll
+      for (int j = 0; j < MAXC; ++j)
+        if (j < ncol && ww[j] != 0.f) rowacc += ww[j] * g[oh * OW + ow_lo + j];
       acc += wh * rowacc;
     }
     dx[i] = acc;
