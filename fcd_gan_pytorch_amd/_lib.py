@@ -62,6 +62,10 @@ _SIGS = {
     'fcd_conv_wino_pack': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     'fcd_conv2d_fwd_wino': (c_int, [POINTER(ConvDesc), P, P, P, P, c_int, P, P, P, c_size_t, P]),
     'fcd_conv2d_bwd_data_wino': (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, c_size_t, P]),
+    'fcd_conv_s2_dgrad_plan': (c_int, [POINTER(ConvDesc)]),
+    'fcd_conv_s2_dgrad_packed_elems': (c_int64, [c_int, c_int]),
+    'fcd_conv_s2_dgrad_pack': (c_int, [P, P, c_int, c_int, P]),
+    'fcd_conv2d_bwd_data_s2': (c_int, [POINTER(ConvDesc), P, P, P, P, P]),
     'fcd_conv_wino2_plan': (c_int, [POINTER(ConvDesc), c_int]),
     'fcd_conv_wino2_filter_elems': (c_int64, [c_int, c_int, c_int]),
     'fcd_conv_wino2_pack': (c_int, [P, P, c_int, c_int, c_int, P]),

@@ -121,7 +121,25 @@ def _fwd_conv(d, x, weight, bias, y, relu, pool_y=None, code=None):
                                  _stream()), 'fcd_conv2d_fwd')
 
 
+def s2_weight(weight):
+    """Filters packed for the sub-pixel data gradient of a stride-2 layer (fcd_conv_s2_dgrad_pack), cached."""
+    cache = weight.__dict__.setdefault('_fcd_pack', {})
+    ver = weight._version
+    hit = cache.get('s2')
+    if hit is not None and hit[0] == ver and hit[1].device == weight.device:
+        return hit[1]
+    K, C = weight.shape[:2]
+    wp = torch.empty(lib.fcd_conv_s2_dgrad_packed_elems(K, C), dtype=torch.float32, device=weight.device)
+    check(lib.fcd_conv_s2_dgrad_pack(_p(weight.detach().contiguous()), _p(wp), K, C, _stream()), 'fcd_conv_s2_dgrad_pack')
+    cache['s2'] = (ver, wp)
+    return wp
+
+
 def _bwd_data_conv(d, dy, weight, dx, yrelu=None, code=None):
+    if code is None and lib.fcd_conv_s2_dgrad_plan(ctypes.byref(d)):
+        check(lib.fcd_conv2d_bwd_data_s2(ctypes.byref(d), _p(dy), _p(yrelu), _p(s2_weight(weight)), _p(dx), _stream()),
+              'fcd_conv2d_bwd_data_s2')
+        return
     if lib.fcd_conv_wino2_plan(ctypes.byref(d), 1):
         check(lib.fcd_conv2d_bwd_data_wino2(ctypes.byref(d), _p(dy), _p(yrelu), _p(code), _p(wino2_weight(weight, 1)), _p(dx),
                                             _stream()), 'fcd_conv2d_bwd_data_wino2')

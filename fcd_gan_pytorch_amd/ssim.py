@@ -5,6 +5,14 @@ tile, forms the five Gaussian-window statistics in LDS and reduces the ssim/cs
 maps per (n,c); the 2x2 padded average pool between levels is a second small
 kernel.  Only the O(levels*N*C) tail (relu, powers, product, mean) uses torch ops.
 2-D images (N,C,H,W), odd window <= 11 taps, CUDA/ROCm tensors only.
+
+Deliberate differences from the vendored pytorch-msssim (none is on a demo's path; each RAISES instead of
+silently computing something else):
+ * 5-D (N,C,T,H,W) inputs (``conv3d`` branch, ssim.py:120-137,171-186) -> ValueError: 4-d tensors only;
+ * ``gaussian_filter``'s "skip a spatial dimension shorter than the window, with a warning" (ssim.py:44-50): the
+   kernel needs H, W >= window size and reports smaller inputs as an error (MS-SSIM's own assert, ssim.py:194-197,
+   already requires min(H, W) > 160 for the default window);
+ * windows longer than 11 taps -> error.
 """
 import torch
 

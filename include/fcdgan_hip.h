@@ -235,6 +235,16 @@ int fcd_ssim_level_bwd(const float* X, const float* Y, const float* win, int win
                        const float* g_ssim, const float* g_cs, float* dX, float* dY, int NC, int H,
                        int W, float C1, float C2, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- data gradient of 3x3 / stride-2 / pad-1 convolutions by sub-pixel decomposition: one stride-1 pseudo-convolution with
+ * 2x2 taps over dy producing the four phases of dx (16 instead of 36 multiplies per input-pixel quad), rows scattered to
+ * their sub-pixel positions by the epilogue.  fcd_conv_s2_dgrad_plan: 1 when the layer takes this form; filters are then
+ * packed with fcd_conv_s2_dgrad_pack (fcd_conv_s2_dgrad_packed_elems floats).  relu_out as in fcd_conv2d_bwd_data. */
+int fcd_conv_s2_dgrad_plan(const fcd_conv_desc* d);
+int64_t fcd_conv_s2_dgrad_packed_elems(int K, int C);
+int fcd_conv_s2_dgrad_pack(const float* w, float* wp, int K, int C, void* stream);
+int fcd_conv2d_bwd_data_s2(const fcd_conv_desc* d, const float* dy, const float* relu_out, const float* wp_s2, float* dx,
+                           void* stream);
+
 /* ---- fused Winograd F(2x2,3x3) convolution for 3x3 / stride-1 / pad-1 layers with 33..64 GEMM rows (output channels
  * forward, input channels for the data gradient) and >= 32 reduction channels: input transform, 16 batched MFMA GEMMs
  * and output transform in ONE kernel (csrc/conv_wino2.hip) -- 2.25x fewer multiplies than the direct kernel at the same
