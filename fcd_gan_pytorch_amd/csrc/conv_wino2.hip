@@ -55,6 +55,8 @@ constexpr int W2_RP = 72;                   // pair-row pitch (floats): 34 colum
 //   8 waves, 4 channels per stage (KS = 1): 6.8 ms (twice the barriers)
 //   4 waves, 4 x 32 pixels (two or three independent workgroups per CU): 9.1 - 10.2 ms -- half the pixels per filter
 //   fetch and 1.5x halo rows; kept for the record
+//   4 waves x 4 tile rows each, 8 x 32 pixels (FCD_WINO2_WAVES=1: one wave per SIMD, 256 VGPRs + 256 AGPRs): 8.9 ms as
+//   the compiler schedules it -- a single wave per SIMD needs a hand-pipelined operand prefetch to hide its LDS reads
 // Where the 6.2 ms go (diagnostic builds, W2_EXP): pure MFMA floor 2.85 ms; MFMA + transforms + per-workgroup prologue /
 // epilogue with NO memory instruction in the loop 4.0 ms (one workgroup per CU: nothing hides the prologue's memory
 // round trip and the epilogue's stores); + LDS operand reads 0.9, + filter DMA / patch loads / LDS stores 0.9, + barrier
@@ -111,11 +113,11 @@ __global__ void wino2_pack_kernel(const float* __restrict__ w, float* __restrict
   }
 }
 
-template <int SRC, int EPI, int NW, int W2_KS>
+template <int SRC, int EPI, int NW, int W2_KS, int PG>     // PG: pairs of tile rows per wave (2 PG accumulators per xi)
 __global__ __launch_bounds__(64 * NW) void conv_wino2_kernel(Wino2Args a) {
   constexpr int NT = 64 * NW;                         // threads
   constexpr int W2_CB = 4 * W2_KS;                    // channels per pipeline stage
-  constexpr int W2_TH = NW;                           // output rows per workgroup: 2 tile rows per 4 waves
+  constexpr int W2_TH = NW * PG;                      // output rows per workgroup: 2 PG tile rows per 4 waves
   constexpr int W2_PH = W2_TH + 2;
   // pair rows per channel plane, padded to a multiple of 64 floats: the four channel groups of a wave (lanes 16 kc ..)
   // must start on the same bank, or the 16-lane groups in which ds_read_b128 is served (they mix lanes of two channel
@@ -152,17 +154,17 @@ __global__ __launch_bounds__(64 * NW) void conv_wino2_kernel(Wino2Args a) {
   const int n = bx / a.tiles_p;
   const int p0 = tp * W2_TH, q0 = tq * W2_TW;
 
-  f32x4 acc[16][2];
+  f32x4 acc[16][2 * PG];
 #pragma unroll
   for (int xi = 0; xi < 16; ++xi)
 #pragma unroll
-    for (int gr = 0; gr < 2; ++gr) acc[xi][gr] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int gr = 0; gr < 2 * PG; ++gr) acc[xi][gr] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ---- loop-invariant addresses
   const int aoff = (g * 64 + lane) * W2_LP;                         // A operands: 16 consecutive floats
-  int boff[2];
+  int boff[PG];
 #pragma unroll
-  for (int gr = 0; gr < 2; ++gr) boff[gr] = kc * W2_PL + (4 * hrow) * W2_RP + 4 * ln;   // (one address: pairs)
+  for (int pg = 0; pg < PG; ++pg) boff[pg] = kc * W2_PL + (4 * (hrow * PG + pg)) * W2_RP + 4 * ln;   // pair rows of group pg
 
   float xr[X_PER_T], mr[X_PER_T];
   unsigned mcode[X_PER_T], x_want[X_PER_T], x_boff[X_PER_T];
@@ -261,8 +263,8 @@ __global__ __launch_bounds__(64 * NW) void conv_wino2_kernel(Wino2Args a) {
     /* both tile rows of the wave at once: every quantity is a (tile row 0, tile row 1) pair in two adjacent VGPRs */ \
     /* (ds_read2_b32 fills such a pair from two addresses), so each transform add is ONE v_pk_add_f32 for two MFMA */ \
     /* operands -- 1 VALU op per MFMA instead of 2.8 */                                                \
-    {                                                                                                \
-      const float* xp = xl + ks * 4 * W2_PL + boff[0];                                               \
+    _Pragma("unroll") for (int pg = 0; pg < PG; ++pg) {                                               \
+      const float* xp = xl + ks * 4 * W2_PL + boff[pg];                                               \
       f32x2 d[4][4];                                                                                 \
       _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                \
         const f32x4 q0 = (W2_EXP & 4) ? f32x4{(float)lane, (float)i, 1.f, 2.f} : *(const f32x4*)(xp + i * W2_RP);      \
@@ -284,14 +286,14 @@ __global__ __launch_bounds__(64 * NW) void conv_wino2_kernel(Wino2Args a) {
         asm("v_pk_add_f32 %0, %4, %6 neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_add_f32 %1, %5, %6\n\t"         \
             "v_pk_add_f32 %2, %6, %5 neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_add_f32 %3, %5, %7 neg_lo:[0,1] neg_hi:[0,1]\n\ts_nop 1" \
             : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(t[i][0]), "v"(t[i][1]), "v"(t[i][2]), "v"(t[i][3])); \
-        acc[4 * i + 0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * i + 0], v0[0], acc[4 * i + 0][0], 0, 0, 0); \
-        acc[4 * i + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * i + 1], v1[0], acc[4 * i + 1][0], 0, 0, 0); \
-        acc[4 * i + 2][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * i + 2], v2[0], acc[4 * i + 2][0], 0, 0, 0); \
-        acc[4 * i + 3][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * i + 3], v3[0], acc[4 * i + 3][0], 0, 0, 0); \
-        acc[4 * i + 0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * i + 0], v0[1], acc[4 * i + 0][1], 0, 0, 0); \
-        acc[4 * i + 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * i + 1], v1[1], acc[4 * i + 1][1], 0, 0, 0); \
-        acc[4 * i + 2][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * i + 2], v2[1], acc[4 * i + 2][1], 0, 0, 0); \
-        acc[4 * i + 3][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * i + 3], v3[1], acc[4 * i + 3][1], 0, 0, 0); \
+        acc[4 * i + 0][2 * pg] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * i + 0], v0[0], acc[4 * i + 0][2 * pg], 0, 0, 0); \
+        acc[4 * i + 1][2 * pg] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * i + 1], v1[0], acc[4 * i + 1][2 * pg], 0, 0, 0); \
+        acc[4 * i + 2][2 * pg] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * i + 2], v2[0], acc[4 * i + 2][2 * pg], 0, 0, 0); \
+        acc[4 * i + 3][2 * pg] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * i + 3], v3[0], acc[4 * i + 3][2 * pg], 0, 0, 0); \
+        acc[4 * i + 0][2 * pg + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * i + 0], v0[1], acc[4 * i + 0][2 * pg + 1], 0, 0, 0); \
+        acc[4 * i + 1][2 * pg + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * i + 1], v1[1], acc[4 * i + 1][2 * pg + 1], 0, 0, 0); \
+        acc[4 * i + 2][2 * pg + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * i + 2], v2[1], acc[4 * i + 2][2 * pg + 1], 0, 0, 0); \
+        acc[4 * i + 3][2 * pg + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * i + 3], v3[1], acc[4 * i + 3][2 * pg + 1], 0, 0, 0); \
       }                                                                                              \
     }                                                                                                \
     }                                                                                                \
@@ -322,8 +324,8 @@ __global__ __launch_bounds__(64 * NW) void conv_wino2_kernel(Wino2Args a) {
   // ---- output transform + epilogue.  Lane: tile column ln, rows 16 g + 4 kc + reg; A^T = [[1,1,1,0],[0,1,-1,-1]]
   const int P = a.H, Q = a.W;          // stride 1 / pad 1: output extent == input extent
 #pragma unroll
-  for (int gr = 0; gr < 2; ++gr) {
-    const int trow = 2 * hrow + gr;
+  for (int gr = 0; gr < 2 * PG; ++gr) {
+    const int trow = 2 * hrow * PG + gr;
     const int p = p0 + 2 * trow, q = q0 + 2 * ln;
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
@@ -435,7 +437,8 @@ static int w2_waves() {     // FCD_WINO2_WAVES = 8 (one 8 x 32 workgroup per CU)
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("FCD_WINO2_WAVES");
-    v = (e && atoi(e) == 4) ? 4 : 8;
+    v = e ? atoi(e) : 8;
+    if (v != 1 && v != 4) v = 8;
   }
   return v;
 }
@@ -449,22 +452,26 @@ static void w2_launch(Wino2Args& a, int red, hipStream_t st) {
     const char* e = getenv("FCD_WINO2_KS");
     ks = (e && atoi(e) == 1) ? 1 : 2;
   }
-  if (w2_waves() == 8 && ks == 2) {
+  if (w2_waves() == 1) {          // one wave per SIMD: 4 waves x 4 tile rows, 512-register budget (accumulators in AGPRs)
     a.tiles_p = cdiv(a.H, 8);
     a.nchunks = cdiv(red, 8);
-    hipLaunchKernelGGL((conv_wino2_kernel<SRC, EPI, 8, 2>), dim3((unsigned)(a.N * a.tiles_p * a.tiles_q)), dim3(512), 0, st, a);
+    hipLaunchKernelGGL((conv_wino2_kernel<SRC, EPI, 4, 2, 2>), dim3((unsigned)(a.N * a.tiles_p * a.tiles_q)), dim3(256), 0, st, a);
+  } else if (w2_waves() == 8 && ks == 2) {
+    a.tiles_p = cdiv(a.H, 8);
+    a.nchunks = cdiv(red, 8);
+    hipLaunchKernelGGL((conv_wino2_kernel<SRC, EPI, 8, 2, 1>), dim3((unsigned)(a.N * a.tiles_p * a.tiles_q)), dim3(512), 0, st, a);
   } else if (w2_waves() == 8) {
     a.tiles_p = cdiv(a.H, 8);
     a.nchunks = cdiv(red, 4);
-    hipLaunchKernelGGL((conv_wino2_kernel<SRC, EPI, 8, 1>), dim3((unsigned)(a.N * a.tiles_p * a.tiles_q)), dim3(512), 0, st, a);
+    hipLaunchKernelGGL((conv_wino2_kernel<SRC, EPI, 8, 1, 1>), dim3((unsigned)(a.N * a.tiles_p * a.tiles_q)), dim3(512), 0, st, a);
   } else if (ks == 2) {
     a.tiles_p = cdiv(a.H, 4);
     a.nchunks = cdiv(red, 8);
-    hipLaunchKernelGGL((conv_wino2_kernel<SRC, EPI, 4, 2>), dim3((unsigned)(a.N * a.tiles_p * a.tiles_q)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv_wino2_kernel<SRC, EPI, 4, 2, 1>), dim3((unsigned)(a.N * a.tiles_p * a.tiles_q)), dim3(256), 0, st, a);
   } else {
     a.tiles_p = cdiv(a.H, 4);
     a.nchunks = cdiv(red, 4);
-    hipLaunchKernelGGL((conv_wino2_kernel<SRC, EPI, 4, 1>), dim3((unsigned)(a.N * a.tiles_p * a.tiles_q)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv_wino2_kernel<SRC, EPI, 4, 1, 1>), dim3((unsigned)(a.N * a.tiles_p * a.tiles_q)), dim3(256), 0, st, a);
   }
 }
 
