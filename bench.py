@@ -287,7 +287,7 @@ def main():
         out = step()
     barrier()
     dt = time.perf_counter() - t0
-    losses = {k: float(v) for k, v in out.items() if v.dim() == 0}
+    losses = {k: float(v.detach()) for k, v in out.items() if v.dim() == 0}
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
