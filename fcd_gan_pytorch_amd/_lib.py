@@ -57,6 +57,7 @@ _SIGS = {
     'fcd_conv2d_bwd_data_bits': (c_int, [POINTER(ConvDesc), P, P, P, P, P]),
     'fcd_conv_wino_plan': (c_int, [POINTER(ConvDesc), c_int]),
     'fcd_conv_wino_set': (c_int, [c_int]),
+    'fcd_conv_wino_split_set': (c_int, [c_int]),
     'fcd_conv_wino_ws_bytes': (c_size_t, [POINTER(ConvDesc), c_int]),
     'fcd_conv_wino_filter_elems': (c_int64, [c_int, c_int, c_int, c_int]),
     'fcd_conv_wino_pack': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),

@@ -64,9 +64,16 @@ template <> struct WinoMat<4> {
 // filter transform: U[xi][row][kc] = (G g G^T)[xi]
 //   mode 0: row = k (output channel), kc = c, g = w[k][c]
 //   mode 1: row = c (input channel),  kc = k, g = w[k][c] with both taps flipped
+// planes != NULL: additionally the exact three-way bf16 split u = h + m + l (see wino_gemm_split_kernel), plane p at
+// planes + p * 36 * rows * Kc, same [xi][row][kc] order
+__device__ __forceinline__ unsigned short bf16_rn_bits(float x) {
+  const __bf16 b = (__bf16)x;
+  return __builtin_bit_cast(unsigned short, b);
+}
+
 template <int MM>
 __global__ void wino_filter_kernel(const float* __restrict__ w, float* __restrict__ U, int K, int C, int rows, int Kc,
-                                   int mode) {
+                                   int mode, unsigned short* __restrict__ planes) {
   constexpr int A = WinoMat<MM>::A;
   const long long total = (long long)rows * Kc;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -96,7 +103,18 @@ __global__ void wino_filter_kernel(const float* __restrict__ w, float* __restric
 #pragma unroll
       for (int b = 0; b < A; ++b) {
         const float u = t[a][0] * WinoMat<MM>::G(b, 0) + t[a][1] * WinoMat<MM>::G(b, 1) + t[a][2] * WinoMat<MM>::G(b, 2);
-        U[((long long)(a * A + b) * rows + row) * Kc + kc] = u;
+        const long long o = ((long long)(a * A + b) * rows + row) * Kc + kc;
+        U[o] = u;
+        if (planes) {
+          const long long ps = (long long)A * A * total;
+          const unsigned short h = bf16_rn_bits(u);
+          const float r = u - __uint_as_float((unsigned)h << 16);
+          const unsigned short m = bf16_rn_bits(r);
+          const float q = r - __uint_as_float((unsigned)m << 16);
+          planes[o] = h;
+          planes[ps + o] = m;
+          planes[2 * ps + o] = bf16_rn_bits(q);
+        }
       }
   }
 }
@@ -113,7 +131,17 @@ struct WinoInArgs {
   float* V;                   // [xi][Q][T][32]
   int N, C, H, W, Hp, Wp, TH, TW, Q;
   long long T;
+  int exp;                    // diagnostics (FCD_WINO_IN_EXP): 2 = no V stores, 4 = no source loads
+  int xcd;                    // 1: blocks renumbered so that each XCD (own L2) walks a contiguous range
 };
+
+// Workgroups are handed to the 8 XCDs round-robin in launch order, so neighbouring strips of one plane --
+// which share their halo rows -- would land on 8 different L2s and fetch the shared rows from HBM again.
+// Renumber: XCD j (launch ids j, j+8, ...) takes the contiguous range of blocks [start_j, start_j + count_j).
+__device__ __forceinline__ unsigned xcd_contiguous_id(unsigned lin, unsigned total) {
+  const unsigned j = lin & 7u, i = lin >> 3, q8 = total >> 3, r8 = total & 7u;
+  return j * q8 + (j < r8 ? j : r8) + i;
+}
 
 // TRB x TWB tiles per block (16 tiles for m = 4, 32 for m = 2): 1 x 16 strips for wide maps, 2 x 8 / 4 x 4
 // patches for the 32- and 16-pixel maps deep in the nets, so that no thread idles on tiles outside
@@ -127,8 +155,15 @@ __global__ __launch_bounds__(256) void wino_input_kernel(WinoInArgs a) {
   constexpr int PL = (RH * CW) | 1;       // odd plane pitch: conflict-free across the 32 channel lanes
   __shared__ float tile[32 * PL];
   const int tid = threadIdx.x;
-  const int tx0 = blockIdx.x * TWB, ty0 = blockIdx.y * TRB;
-  const int n = blockIdx.z / a.Q, q = blockIdx.z % a.Q;
+  unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (a.xcd) {
+    const unsigned lin = xcd_contiguous_id(bx + gridDim.x * (by + gridDim.y * bz), gridDim.x * gridDim.y * gridDim.z);
+    bx = lin % gridDim.x;
+    by = (lin / gridDim.x) % gridDim.y;
+    bz = lin / (gridDim.x * gridDim.y);
+  }
+  const int tx0 = bx * TWB, ty0 = by * TRB;
+  const int n = bz / a.Q, q = bz % a.Q;
   const int ih0 = ty0 * MM - 1, iw0 = tx0 * MM - 1;
   const int plane = (SRC == 2) ? a.Hp * a.Wp : a.H * a.W;
   const size_t img = ((size_t)n * a.C + (size_t)q * 32) * plane;
@@ -153,7 +188,8 @@ __global__ __launch_bounds__(256) void wino_input_kernel(WinoInArgs a) {
     return v;
   };
 
-  if (VEC && SRC == 2) {
+  if (a.exp & 4) {
+  } else if (VEC && SRC == 2) {
     // pooled gradient: 4 strip columns = 2 pooled elements (one 8-B load + 2 code bytes), each routed to
     // the slot its argmax code names
     constexpr int V4 = (CW - 2) / 4;
@@ -256,7 +292,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(WinoInArgs a) {
 #pragma unroll
         for (int k = 0; k < A; ++k)
           if (WinoMat<MM>::BT(j, k) != 0.f) s += t1[i][k] * WinoMat<MM>::BT(j, k);
-        vout[(size_t)(i * A + j) * xi_stride] = s;
+        if (!(a.exp & 2) || s == 1.2345e-30f) vout[(size_t)(i * A + j) * xi_stride] = s;
       }
   }
 }
@@ -279,6 +315,8 @@ struct WinoGemmArgs {
   int M, N, Kc, m_tiles, n_tiles, xcd_remap;
   long long a_ld, a_batch, b_ld, b_adv, b_batch;
   int stages_per_split;   // blockIdx.z = split of the reduction: stages [z * sps, min((z + 1) * sps, Kc / 32))
+  const unsigned short* As;   // split kernel: bf16 planes (high, middle, low part) of A, plane p at As + p * as_plane,
+  long long as_plane;         // each laid out like A (a_ld, a_batch in elements)
   int batches, xb;        // blockIdx.y = group of xb consecutive batches (transform positions) run by ONE workgroup as a
                           // single software pipeline: the first slabs of batch b + 1 are in flight while batch b's last
                           // MFMAs run and its C tile is stored -- no pipeline refill per batch
@@ -423,6 +461,390 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void wino_gem
 #undef WG_DMA
 }
 
+// --------------------------------------------------------------------------------------------
+// The same batched GEMM on the bf16 matrix pipe (16x the fp32 MFMA rate) WITHOUT giving up fp32 arithmetic: every fp32
+// operand is split exactly into three bf16 parts x = h + m + l (round-to-nearest at each step; the residuals x - h and
+// x - h - m are exact in fp32 and the last one fits the 8-bit significand), a bf16 x bf16 product is exact in the fp32
+// accumulator, and the six partial products of weight >= 2^-16 are accumulated in fp32:
+//     a b  =  ah bh + (ah bm + am bh) + (am bm + ah bl + al bh)  +  [am bl + al bm + al bl  -- dropped, <= 2^-24 |a b|]
+// i.e. each product carries a relative error of ~2^-24, the size of ONE fp32 rounding, before the same fp32 accumulation
+// the v_mfma_f32_32x32x2_f32 chain performs.  A (the transformed filters) is split once per weight version by the pack
+// kernel (three bf16 planes); B (the transformed activations V, fp32 in HBM and in LDS) is split in registers right
+// before the MFMAs.  Lane (row, half) owns reduction elements half*16 .. half*16+15 of the 32-chunk, 8 per MFMA step.
+#ifndef FCD_SEXP
+#define FCD_SEXP 0   // diagnostic builds only (wrong results): 1 no operand split, 2 one MFMA of the six, 4 no barrier, 8 no DMA
+#endif
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  const bf16x2 hp = {(__bf16)x0, (__bf16)x1};
+  h = __builtin_bit_cast(unsigned, hp);
+  const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+  const bf16x2 mp = {(__bf16)r0, (__bf16)r1};
+  m = __builtin_bit_cast(unsigned, mp);
+  const float q0 = r0 - __uint_as_float(m << 16), q1 = r1 - __uint_as_float(m & 0xffff0000u);
+  const bf16x2 lp = {(__bf16)q0, (__bf16)q1};
+  l = __builtin_bit_cast(unsigned, lp);
+}
+
+template <int WM, int WN>      // waves along M / N, each 64 x 64
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void wino_gemm_split_kernel(WinoGemmArgs a) {
+  constexpr int KC = 32;
+  constexpr int NW = WM * WN;
+  constexpr int BM = 64 * WM, BN = 64 * WN;
+  constexpr int UH = KC / 8;                       // B: 16-B units (4 fp32) per lane half and row
+  constexpr int A_UNITS = 3 * 2 * BM * 2;          // A: [plane][half][row][2 units of 8 bf16]
+  constexpr int PPW_A = A_UNITS / 64 / NW;
+  constexpr int PPW_B = BN * UH * 2 / 64 / NW;
+  static_assert(PPW_A * NW * 64 == A_UNITS && PPW_B * NW * 64 == BN * UH * 2, "DMA split");
+  constexpr int SWS = 3;
+  __shared__ __attribute__((aligned(16))) unsigned short sa0[A_UNITS * 8];
+  __shared__ __attribute__((aligned(16))) unsigned short sa1[A_UNITS * 8];
+  __shared__ __attribute__((aligned(16))) float sb0[BN * KC];
+  __shared__ __attribute__((aligned(16))) float sb1[BN * KC];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wm = wave / WN, wn = wave % WN;
+  unsigned v;
+  {
+    const unsigned total = gridDim.x, b = blockIdx.x;
+    if (a.xcd_remap) {
+      const unsigned q8 = total >> 3, r8 = total & 7u, xcd = b & 7u;
+      v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
+    } else {
+      v = b;
+    }
+  }
+  const int mt = (int)(v % (unsigned)a.m_tiles), nt = (int)(v / (unsigned)a.m_tiles);
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int Q = a.Kc / KC;
+  const int b_first = (int)blockIdx.y * a.xb;
+  const int nb = min(a.xb, a.batches - b_first);
+  const unsigned short* Ab = a.As + (size_t)b_first * a.a_batch + (size_t)m0 * a.a_ld;
+  const float* Bb = a.B + (size_t)b_first * a.b_batch + (size_t)n0 * a.b_ld;
+
+  // A slab in LDS: unit u = ((plane * 2 + half) * BM + row) * 2 + pj, 32-B row pitch.  A 16-lane ds_read_b128 group
+  // ({0-3,12-15,20-27}, {4-11,16-19,28-31}) covers 16 distinct 16-B slots iff rows 16..31 take the other unit parity.
+  long long a_goff[PPW_A];
+  int b_goff[PPW_B];
+#pragma unroll
+  for (int j = 0; j < PPW_A; ++j) {
+    const int u = (wave + NW * j) * 64 + lane;
+    const int plane = u / (2 * BM * 2), rem = u % (2 * BM * 2);
+    const int h = rem / (BM * 2), row = (rem >> 1) % BM, pj = rem & 1;
+    const int jl = pj ^ ((row >> 4) & 1);
+    a_goff[j] = plane * a.as_plane + (long long)min(row, a.M - 1 - m0) * a.a_ld + h * (KC / 2) + jl * 8;
+  }
+#pragma unroll
+  for (int j = 0; j < PPW_B; ++j) {
+    const int u = (wave + NW * j) * 64 + lane;
+    const int h = u / (BN * UH), row = (u / UH) % BN, pj = u % UH;
+    const int jl = pj ^ ((row >> SWS) & (UH - 1));
+    b_goff[j] = (int)(min(row, a.N - 1 - n0) * a.b_ld) + h * (KC / 2) + jl * 4;
+  }
+
+  int aoff[2], boff[2];
+  const int swb = (l31 >> SWS) & (UH - 1), swa = (l31 >> 4) & 1;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    aoff[i] = ((half * BM + wm * 64 + i * 32 + l31) * 2) * 8;      // in bf16 elements, plane 0, unit 0
+    boff[i] = (half * BN + wn * 64 + i * 32 + l31) * (UH * 4);
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  int fq = 0, fb = 0;
+#define WS_DMA(SA, SB)                                                                           \
+  {                                                                                              \
+    const unsigned short* as_ = Ab + (size_t)fb * a.a_batch + (size_t)fq * KC;                   \
+    const float* bs_ = Bb + (size_t)fb * a.b_batch + (size_t)fq * a.b_adv;                       \
+    _Pragma("unroll") for (int j = 0; j < PPW_A; ++j)                                            \
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(as_ + a_goff[j]),                           \
+                                       (lds_void_t*)((SA) + (wave + NW * j) * 512), 16, 0, 0);   \
+    _Pragma("unroll") for (int j = 0; j < PPW_B; ++j)                                            \
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(bs_ + b_goff[j]),                           \
+                                       (lds_void_t*)((SB) + (wave + NW * j) * 256), 16, 0, 0);   \
+    if (++fq == Q) { fq = 0; ++fb; }                                                             \
+  }
+#define WS_MFMA(AV, BV)                                                                          \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                  \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, AV[i]),     \
+                                                          __builtin_bit_cast(bf16x8, BV[j]), acc[i][j], 0, 0, 0);
+#define WS_SPLIT(X0, X1, H, M, L)                                                                \
+  {                                                                                              \
+    unsigned th[4], tm[4], tl[4];                                                                \
+    if (FCD_SEXP & 1) {                                                                          \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                            \
+        th[e] = __float_as_uint(X0[e]); tm[e] = __float_as_uint(X1[e]); tl[e] = th[e] ^ tm[e]; } \
+    } else {                                                                                     \
+      split_pair(X0[0], X0[1], th[0], tm[0], tl[0]);                                             \
+      split_pair(X0[2], X0[3], th[1], tm[1], tl[1]);                                             \
+      split_pair(X1[0], X1[1], th[2], tm[2], tl[2]);                                             \
+      split_pair(X1[2], X1[3], th[3], tm[3], tl[3]);                                             \
+    }                                                                                            \
+    H = u32x4{th[0], th[1], th[2], th[3]};                                                       \
+    M = u32x4{tm[0], tm[1], tm[2], tm[3]};                                                       \
+    L = u32x4{tl[0], tl[1], tl[2], tl[3]};                                                       \
+  }
+#define WS_SIX(AH, AM, AL, BH, BM_, BL)                                                          \
+  if (!(FCD_SEXP & 2)) { WS_MFMA(AL, BH) WS_MFMA(AH, BL) WS_MFMA(AM, BM_) WS_MFMA(AM, BH) WS_MFMA(AH, BM_) } \
+  WS_MFMA(AH, BH)
+// One 32-element stage = two MFMA steps.  Program order = the software pipeline the scheduler is then pinned to with
+// sched_group_barrier: all LDS reads of the stage, the split of step 0, then the 24 MFMAs of step 0 with the split of
+// step 1 in their shadows (4 VALU per MFMA), then the 24 MFMAs of step 1.
+#define WS_STEP(SA, SB, SAN, SBN)                                                                \
+  {                                                                                              \
+    if (!(FCD_SEXP & 8)) if (fb < nb) WS_DMA(SAN, SBN)                                           \
+    f32x4 xr[2][2][2];                                                                           \
+    u32x4 ah[2][2], am[2][2], al[2][2], bh[2][2], bm[2][2], bl[2][2];                            \
+    _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                            \
+        xr[s][i][0] = (FCD_SEXP & 32) ? f32x4{(float)lane, 1.f, (float)s, 2.f} : *(const f32x4*)((SB) + boff[i] + (((2 * s) ^ swb) * 4));     \
+        xr[s][i][1] = (FCD_SEXP & 32) ? f32x4{(float)i, 3.f, (float)lane, 2.f} : *(const f32x4*)((SB) + boff[i] + (((2 * s + 1) ^ swb) * 4)); \
+      }                                                                                          \
+    _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                            \
+        const unsigned short* ap = (SA) + aoff[i] + ((s ^ swa) * 8);                             \
+        ah[s][i] = (FCD_SEXP & 32) ? u32x4{(unsigned)lane, 1u, (unsigned)s, 7u} : *(const u32x4*)(ap);                        \
+        am[s][i] = (FCD_SEXP & 32) ? u32x4{(unsigned)i, 1u, (unsigned)lane, 7u} : *(const u32x4*)(ap + 2 * BM * 2 * 8);       \
+        al[s][i] = (FCD_SEXP & 32) ? u32x4{(unsigned)lane, 3u, (unsigned)s, 9u} : *(const u32x4*)(ap + 2 * (2 * BM * 2 * 8)); \
+      }                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) WS_SPLIT(xr[0][i][0], xr[0][i][1], bh[0][i], bm[0][i], bl[0][i]) \
+    WS_SIX(ah[0], am[0], al[0], bh[0], bm[0], bl[0])                                             \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) WS_SPLIT(xr[1][i][0], xr[1][i][1], bh[1][i], bm[1][i], bl[1][i]) \
+    WS_SIX(ah[1], am[1], al[1], bh[1], bm[1], bl[1])                                             \
+    if (!(FCD_SEXP & 16)) {                                                                      \
+      __builtin_amdgcn_sched_group_barrier(0x100, 20, 0);                                        \
+      __builtin_amdgcn_sched_group_barrier(0x002, 88, 0);                                        \
+      _Pragma("unroll") for (int k = 0; k < 22; ++k) {                                           \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                       \
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                       \
+      }                                                                                          \
+      __builtin_amdgcn_sched_group_barrier(0x008, 26, 0);                                        \
+    }                                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    if (!(FCD_SEXP & 4)) __syncthreads();                                                        \
+  }
+
+  WS_DMA(sa0, sb0)
+  __syncthreads();
+#pragma unroll 1
+  for (int cb = 0; cb < nb; ++cb) {
+    for (int qc = 0; qc < Q; qc += 2) {
+      WS_STEP(sa0, sb0, sa1, sb1)
+      if (qc + 1 < Q) WS_STEP(sa1, sb1, sa0, sb0)
+    }
+    int ldc = a.N;
+    asm volatile("" : "+s"(ldc));
+    float* Cb = a.C + (size_t)(b_first + cb) * a.M * ldc;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int n = n0 + wn * 64 + j * 32 + l31;
+          if (m < a.M && n < ldc) Cb[(size_t)m * ldc + n] = acc[i][j][r];
+          acc[i][j][r] = 0.f;
+        }
+      }
+  }
+#undef WS_STEP
+#undef WS_MFMA
+#undef WS_DMA
+}
+
+// The split GEMM on 256 x 256 workgroup tiles.  With the matrix pipe 2.7x faster per fp32-equivalent FLOP the 128 x 128
+// kernel above is bound by the operand stream L2 -> LDS (40 KB and 40 LDS-DMA wave-instructions per 1 MFLOP stage); a
+// 256 x 256 tile halves both per FLOP.  8 waves (2 x 4), each 128 x 64 (4 x 2 MFMA blocks, 128 accumulator registers),
+// two 80-KB LDS stages of 32 reduction elements = the whole 160-KB LDS, one workgroup per CU.  A stage is 96 MFMAs per
+// wave in four groups of 24 (step 0 / 1 x upper / lower 64 rows of the wave tile); the A fragments of the next group
+// and the split of step 1's B fragments are issued in the shadow of the running group.
+template <int DUMMY>
+__global__ __launch_bounds__(512, 1) void wino_gemm_split256_kernel(WinoGemmArgs a) {
+  constexpr int KC = 32, BM = 256, BN = 256, NW = 8;
+  constexpr int UH = KC / 8;
+  constexpr int A_UNITS = 3 * 2 * BM * 2;          // [plane][half][row][2 units of 8 bf16]
+  constexpr int B_UNITS = 2 * BN * UH;             // [half][row][4 units of 4 fp32]
+  constexpr int PPW_A = A_UNITS / 64 / NW, PPW_B = B_UNITS / 64 / NW;     // 6, 4
+  static_assert(PPW_A * NW * 64 == A_UNITS && PPW_B * NW * 64 == B_UNITS, "DMA split");
+  constexpr int SWS = 3;
+  __shared__ __attribute__((aligned(16))) unsigned short sa0[A_UNITS * 8];
+  __shared__ __attribute__((aligned(16))) unsigned short sa1[A_UNITS * 8];
+  __shared__ __attribute__((aligned(16))) float sb0[BN * KC];
+  __shared__ __attribute__((aligned(16))) float sb1[BN * KC];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wm = wave >> 2, wn = wave & 3;
+  unsigned v;
+  {
+    const unsigned total = gridDim.x, b = blockIdx.x;
+    if (a.xcd_remap) {
+      const unsigned q8 = total >> 3, r8 = total & 7u, xcd = b & 7u;
+      v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
+    } else {
+      v = b;
+    }
+  }
+  const int mt = (int)(v % (unsigned)a.m_tiles), nt = (int)(v / (unsigned)a.m_tiles);
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int Q = a.Kc / KC;
+  const int b_first = (int)blockIdx.y * a.xb;
+  const int nb = min(a.xb, a.batches - b_first);
+  const unsigned short* Ab = a.As + (size_t)b_first * a.a_batch + (size_t)m0 * a.a_ld;
+  const float* Bb = a.B + (size_t)b_first * a.b_batch + (size_t)n0 * a.b_ld;
+
+  // (a wave-instruction of the A stream lies in ONE plane: 1024 units per plane, 64 per instruction, plane = j / 2)
+  int a_goff[2], b_goff[PPW_B];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int rem = (wave + NW * j) * 64 + lane;
+    const int h = rem / (BM * 2), row = (rem >> 1) % BM, pj = rem & 1;
+    const int jl = pj ^ ((row >> 4) & 1);
+    a_goff[j] = (int)(min(row, a.M - 1 - m0) * a.a_ld) + h * (KC / 2) + jl * 8;
+  }
+#pragma unroll
+  for (int j = 0; j < PPW_B; ++j) {
+    const int u = (wave + NW * j) * 64 + lane;
+    const int h = u / (BN * UH), row = (u / UH) % BN, pj = u % UH;
+    const int jl = pj ^ ((row >> SWS) & (UH - 1));
+    b_goff[j] = (int)(min(row, a.N - 1 - n0) * a.b_ld) + h * (KC / 2) + jl * 4;
+  }
+  int aoff[4], boff[2];
+  const int swb = (l31 >> SWS) & (UH - 1), swa = (l31 >> 4) & 1;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) aoff[i] = ((half * BM + wm * 128 + i * 32 + l31) * 2) * 8;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) boff[j] = (half * BN + wn * 64 + j * 32 + l31) * (UH * 4);
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  int fq = 0, fb = 0;
+#define Y_DMA(SA, SB)                                                                            \
+  {                                                                                              \
+    const unsigned short* as_ = Ab + (size_t)fb * a.a_batch + (size_t)fq * KC;                   \
+    const float* bs_ = Bb + (size_t)fb * a.b_batch + (size_t)fq * a.b_adv;                       \
+    _Pragma("unroll") for (int j = 0; j < PPW_A; ++j)                                            \
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(as_ + (size_t)(j >> 1) * a.as_plane + a_goff[j & 1]), \
+                                       (lds_void_t*)((SA) + (wave + NW * j) * 512), 16, 0, 0);   \
+    _Pragma("unroll") for (int j = 0; j < PPW_B; ++j)                                            \
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(bs_ + b_goff[j]),                           \
+                                       (lds_void_t*)((SB) + (wave + NW * j) * 256), 16, 0, 0);   \
+    if (++fq == Q) { fq = 0; ++fb; }                                                             \
+  }
+#define Y_LOADA(SA, S, IH, AH, AM, AL)                                                           \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                \
+    const unsigned short* ap = (SA) + aoff[2 * (IH) + i] + (((S) ^ swa) * 8);                    \
+    AH[i] = *(const u32x4*)(ap);                                                                 \
+    AM[i] = *(const u32x4*)(ap + 2 * BM * 2 * 8);                                                \
+    AL[i] = *(const u32x4*)(ap + 2 * (2 * BM * 2 * 8));                                          \
+  }
+#define Y_MFMA(IH, AV, BV)                                                                       \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                  \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                \
+      acc[2 * (IH) + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                            \
+          __builtin_bit_cast(bf16x8, AV[i]), __builtin_bit_cast(bf16x8, BV[j]), acc[2 * (IH) + i][j], 0, 0, 0);
+#define Y_SIX(IH, AH, AM, AL, BH, BM_, BL)                                                       \
+  Y_MFMA(IH, AL, BH) Y_MFMA(IH, AH, BL) Y_MFMA(IH, AM, BM_) Y_MFMA(IH, AM, BH) Y_MFMA(IH, AH, BM_) Y_MFMA(IH, AH, BH)
+#define Y_STEP(SA, SB, SAN, SBN)                                                                 \
+  {                                                                                              \
+    if (fb < nb) Y_DMA(SAN, SBN)                                                                 \
+    f32x4 xa[2][2];                                                                              \
+    u32x4 pah[2], pam[2], pal[2], qah[2], qam[2], qal[2];                                        \
+    u32x4 bh0[2], bm0[2], bl0[2], bh1[2], bm1[2], bl1[2];                                        \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                              \
+      xa[j][0] = *(const f32x4*)((SB) + boff[j] + ((0 ^ swb) * 4));                              \
+      xa[j][1] = *(const f32x4*)((SB) + boff[j] + ((1 ^ swb) * 4));                              \
+    }                                                                                            \
+    Y_LOADA(SA, 0, 0, pah, pam, pal)                                                             \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) WS_SPLIT(xa[j][0], xa[j][1], bh0[j], bm0[j], bl0[j]) \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                              \
+      xa[j][0] = *(const f32x4*)((SB) + boff[j] + ((2 ^ swb) * 4));                              \
+      xa[j][1] = *(const f32x4*)((SB) + boff[j] + ((3 ^ swb) * 4));                              \
+    }                                                                                            \
+    Y_SIX(0, pah, pam, pal, bh0, bm0, bl0)                                                       \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) WS_SPLIT(xa[j][0], xa[j][1], bh1[j], bm1[j], bl1[j]) \
+    Y_LOADA(SA, 0, 1, qah, qam, qal)                                                             \
+    Y_SIX(1, qah, qam, qal, bh0, bm0, bl0)                                                       \
+    Y_LOADA(SA, 1, 0, pah, pam, pal)                                                             \
+    Y_SIX(0, pah, pam, pal, bh1, bm1, bl1)                                                       \
+    Y_LOADA(SA, 1, 1, qah, qam, qal)                                                             \
+    Y_SIX(1, qah, qam, qal, bh1, bm1, bl1)                                                       \
+    __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);     /* B raw step 0, A (0, 0) */         \
+    __builtin_amdgcn_sched_group_barrier(0x002, 88, 0);     /* split step 0 */                   \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                           \
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);      /* B raw step 1 */                   \
+    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                           \
+    _Pragma("unroll") for (int k = 0; k < 14; ++k) {        /* group (0, 0) over the split of step 1 */ \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                         \
+      __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);                                         \
+    }                                                                                            \
+    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                           \
+    _Pragma("unroll") for (int k = 0; k < 6; ++k) {         /* ... and the A loads of (0, 1) */  \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                         \
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                         \
+    }                                                                                            \
+    _Pragma("unroll") for (int k = 0; k < 6; ++k) {         /* group (0, 1) over the A loads of (1, 0) */ \
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                         \
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                         \
+    }                                                                                            \
+    __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);                                          \
+    _Pragma("unroll") for (int k = 0; k < 6; ++k) {         /* group (1, 0) over the A loads of (1, 1) */ \
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                         \
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                         \
+    }                                                                                            \
+    __builtin_amdgcn_sched_group_barrier(0x008, 36, 0);                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    __syncthreads();                                                                             \
+  }
+
+  Y_DMA(sa0, sb0)
+  __syncthreads();
+#pragma unroll 1
+  for (int cb = 0; cb < nb; ++cb) {
+    for (int qc = 0; qc < Q; qc += 2) {
+      Y_STEP(sa0, sb0, sa1, sb1)
+      if (qc + 1 < Q) Y_STEP(sa1, sb1, sa0, sb0)
+    }
+    int ldc = a.N;
+    asm volatile("" : "+s"(ldc));
+    float* Cb = a.C + (size_t)(b_first + cb) * a.M * ldc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int n = n0 + wn * 64 + j * 32 + l31;
+          if (m < a.M && n < ldc) Cb[(size_t)m * ldc + n] = acc[i][j][r];
+          acc[i][j][r] = 0.f;
+        }
+      }
+  }
+#undef Y_STEP
+#undef Y_SIX
+#undef Y_MFMA
+#undef Y_LOADA
+#undef Y_DMA
+}
+
 static int wino_gemm_cfg() {     // FCD_WINO_TILE: 0 = 128x128 (4 waves), 1 = 256x128 (8 waves), 2 = 256x256 (16 waves)
   static int v = -1;
   if (v < 0) {
@@ -452,8 +874,41 @@ static int wino_gemm_xb(long long tiles, int batches, int splits, int q_stages) 
   return 1;
 }
 
+// FCD_WINO_SPLIT / fcd_conv_wino_split_set: 1 (default) = conv / data-gradient GEMMs on the bf16 matrix pipe with exact
+// three-way operand splitting (wino_gemm_split_kernel), 0 = v_mfma_f32_32x32x2_f32 (wino_gemm_kernel)
+static int g_wino_split = -1;
+static int wino_split() {
+  if (g_wino_split < 0) {
+    const char* e = getenv("FCD_WINO_SPLIT");
+    g_wino_split = e ? atoi(e) : 1;
+  }
+  return g_wino_split;
+}
+extern "C" int fcd_conv_wino_split_set(int on) {
+  const int old = wino_split();
+  if (on >= 0) g_wino_split = on ? 1 : 0;
+  return old;
+}
+
 static void wino_gemm_launch(WinoGemmArgs ga, int batches, int splits, hipStream_t st) {
   int cfg = wino_gemm_cfg();
+  if (ga.As && splits == 1 && ga.M > 64 && wino_split()) {
+    ga.batches = batches;
+    static int big = -1;
+    if (big < 0) { const char* e = getenv("FCD_WINO_SPLIT_BIG"); big = e ? atoi(e) : 1; }
+    if (big && ga.M >= 256 && (big == 2 || (long long)cdiv(ga.M, 256) * cdiv(ga.N, 256) * batches >= 1024)) {
+      ga.m_tiles = cdiv(ga.M, 256); ga.n_tiles = cdiv(ga.N, 256);
+      ga.xb = wino_gemm_xb((long long)ga.m_tiles * ga.n_tiles * 2, batches, 1, ga.Kc / 32);
+      hipLaunchKernelGGL((wino_gemm_split256_kernel<0>), dim3((unsigned)(ga.m_tiles * ga.n_tiles), (unsigned)cdiv(batches, ga.xb)),
+                         dim3(512), 0, st, ga);
+      return;
+    }
+    ga.m_tiles = cdiv(ga.M, 128); ga.n_tiles = cdiv(ga.N, 128);
+    ga.xb = wino_gemm_xb((long long)ga.m_tiles * ga.n_tiles, batches, 1, ga.Kc / 32);
+    hipLaunchKernelGGL((wino_gemm_split_kernel<2, 2>), dim3((unsigned)(ga.m_tiles * ga.n_tiles), (unsigned)cdiv(batches, ga.xb)),
+                       dim3(256), 0, st, ga);
+    return;
+  }
   if (cfg == 2 && (ga.M < 256 || ga.N < 256)) cfg = 1;
   if (cfg == 1 && ga.M < 256) cfg = 0;
   ga.batches = batches;
@@ -659,7 +1114,8 @@ extern "C" size_t fcd_conv_wino_ws_bytes(const fcd_conv_desc* d, int mode) {
 extern "C" int64_t fcd_conv_wino_filter_elems(int K, int C, int mode, int m) {
   if (m != 2 && m != 4) return 0;
   const int rows = mode == 0 ? K : C, red = mode == 0 ? C : K;
-  return (int64_t)(m + 2) * (m + 2) * rows * round_up(red, 32);
+  const int64_t elems = (int64_t)(m + 2) * (m + 2) * rows * round_up(red, 32);
+  return elems + elems / 2 * 3;      // fp32 U, then three bf16 planes (the split GEMM's A operand)
 }
 
 extern "C" int fcd_conv_wino_pack(const float* w, float* U, int K, int C, int mode, int m, void* stream) {
@@ -668,11 +1124,12 @@ extern "C" int fcd_conv_wino_pack(const float* w, float* U, int K, int C, int mo
   const int rows = mode == 0 ? K : C, Kc = round_up(mode == 0 ? C : K, 32);
   const long long total = (long long)rows * Kc;
   const int grid = (int)std::min<long long>(cdiv64(total, 256), 4096);
-  FcdProfScope prof(FCD_K_PACK, (hipStream_t)stream, 0.0, 4.0 * total * (9 + (m + 2) * (m + 2)));
+  FcdProfScope prof(FCD_K_PACK, (hipStream_t)stream, 0.0, 4.0 * total * (9 + 2.5 * (m + 2) * (m + 2)));
+  unsigned short* planes = (unsigned short*)(U + (long long)(m + 2) * (m + 2) * total);
   if (m == 2)
-    hipLaunchKernelGGL(wino_filter_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, U, K, C, rows, Kc, mode);
+    hipLaunchKernelGGL(wino_filter_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, U, K, C, rows, Kc, mode, planes);
   else
-    hipLaunchKernelGGL(wino_filter_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, U, K, C, rows, Kc, mode);
+    hipLaunchKernelGGL(wino_filter_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, U, K, C, rows, Kc, mode, planes);
   FCD_LAUNCH_CHECK("wino_pack");
   return FCD_OK;
 }
@@ -702,7 +1159,8 @@ static void wino_launch_input_cfg(const WinoInArgs& ia, int src, hipStream_t st)
 template <int MM>
 static void wino_launch_input(const WinoInArgs& ia, int src, hipStream_t st) {
   constexpr int NT = 64 / MM;             // tiles per block: 64 output pixels per patch row at 1 x NT
-  if (ia.TW > NT / 2) wino_launch_input_cfg<MM, 1, NT>(ia, src, st);
+  if (ia.TW > NT / 2 && (ia.exp & 1)) wino_launch_input_cfg<MM, 1, NT / 2>(ia, src, st);
+  else if (ia.TW > NT / 2) wino_launch_input_cfg<MM, 1, NT>(ia, src, st);
   else if (ia.TW > NT / 4) wino_launch_input_cfg<MM, 2, NT / 2>(ia, src, st);
   else wino_launch_input_cfg<MM, 4, NT / 4>(ia, src, st);
 }
@@ -720,6 +1178,12 @@ static int wino_run(const WinoPlan& pl, int N, int in_ch, int H, int W, const fl
   ia.N = N; ia.C = in_ch; ia.H = H; ia.W = W; ia.Hp = Hp; ia.Wp = Wp;
   ia.TH = pl.TH; ia.TW = pl.TW; ia.Q = pl.Q; ia.T = pl.T;
   const int srcmode = code_in ? 2 : (mask ? 1 : 0);
+  {
+    static int exp = -1;
+    if (exp < 0) { const char* e = getenv("FCD_WINO_IN_EXP"); exp = e ? atoi(e) : 0; }
+    ia.exp = exp;
+    ia.xcd = (wino_xcd() && !(exp & 8)) ? 1 : 0;
+  }
   const double in_elems = (double)N * in_ch * H * W, mm = pl.m * pl.m;
   {
     FcdProfScope p1(FCD_K_WINO_XFORM, st, 0.0, 4.0 * in_elems * (srcmode == 1 ? 2.0 : 1.0) + (double)pl.v_bytes,
@@ -734,6 +1198,8 @@ static int wino_run(const WinoPlan& pl, int N, int in_ch, int H, int W, const fl
   ga.m_tiles = cdiv(pl.rows, 128); ga.n_tiles = cdiv((int)pl.T, 128);
   ga.xcd_remap = wino_xcd();
   ga.a_ld = pl.Kc; ga.a_batch = (long long)pl.rows * pl.Kc;                 // U [xi][rows][Kc]
+  ga.as_plane = (long long)pl.A2 * pl.rows * pl.Kc;                          // bf16 planes behind the fp32 U
+  ga.As = (const unsigned short*)(U + ga.as_plane);
   ga.b_ld = 32; ga.b_adv = (long long)pl.T * 32; ga.b_batch = (long long)pl.Q * pl.T * 32;   // V [xi][Q][T][32]
   ga.stages_per_split = pl.Q;
   {

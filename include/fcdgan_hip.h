@@ -89,6 +89,10 @@ int fcd_conv2d_bwd_data_bits(const fcd_conv_desc* d, const float* dy, const unsi
 int fcd_conv_wino_plan(const fcd_conv_desc* d, int mode);
 /* tile-size policy: 0 = direct kernels only, 2 or 4 (default, env FCD_WINO); returns the previous value */
 int fcd_conv_wino_set(int m);
+/* matrix pipe of the batched GEMM of the three-kernel path: 1 (default, env FCD_WINO_SPLIT) = bf16 MFMA on exact
+ * three-way bf16 splits of the fp32 operands, six partial products accumulated in fp32 (fp32-equivalent result);
+ * 0 = v_mfma_f32_32x32x2_f32.  on < 0 only queries.  Returns the previous value. */
+int fcd_conv_wino_split_set(int on);
 size_t fcd_conv_wino_ws_bytes(const fcd_conv_desc* d, int mode);
 int64_t fcd_conv_wino_filter_elems(int K, int C, int mode, int m);
 int fcd_conv_wino_pack(const float* w, float* U, int K, int C, int mode, int m, void* stream);

@@ -71,7 +71,12 @@ def main():
         if cmp_:
             ref = torch.load(os.path.join(cmp_, tag.replace(' ', '_').replace('>', '') + '.pt'))
             extra = '  bit-equal=%s' % bool(torch.equal(ref, y.cpu()))
-        print('%-22s gemm %7.3f ms  %6.1f TF (%.2f)   transforms %7.3f ms%s' % (tag, tg, fl / tg / 1e9, fl / tg / 1e9 / 157.3, tx, extra))
+        ti = sum(e['ms'] for e in xf if e['tag'].startswith('in ')) / 5
+        to = sum(e['ms'] for e in xf if e['tag'].startswith('out ')) / 5
+        bi = sum(e['bytes'] for e in xf if e['tag'].startswith('in ')) / 5
+        bo = sum(e['bytes'] for e in xf if e['tag'].startswith('out ')) / 5
+        print('%-22s gemm %7.3f ms  %6.1f TF (%.2f)   in %7.3f ms %5.0f GB/s   out %7.3f ms %5.0f GB/s%s'
+              % (tag, tg, fl / tg / 1e9, fl / tg / 1e9 / 157.3, ti, bi / ti / 1e6, to, bo / to / 1e6, extra))
         del x, y, ws
     print('sum: gemm %.2f ms, transforms %.2f ms' % (tot['gemm'], tot['xf']))
 
