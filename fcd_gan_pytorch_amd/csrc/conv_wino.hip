@@ -751,9 +751,9 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split256_kernel(WinoGemmArgs
 #define Y_LOADA(SA, S, IH, AH, AM, AL)                                                           \
   _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                \
     const unsigned short* ap = (SA) + aoff[2 * (IH) + i] + (((S) ^ swa) * 8);                    \
-    AH[i] = *(const u32x4*)(ap);                                                                 \
-    AM[i] = *(const u32x4*)(ap + 2 * BM * 2 * 8);                                                \
-    AL[i] = *(const u32x4*)(ap + 2 * (2 * BM * 2 * 8));                                          \
+    AH[i] = (FCD_SEXP & 32) ? u32x4{(unsigned)lane, 1u, (unsigned)(S), 7u} : *(const u32x4*)(ap);                        \
+    AM[i] = (FCD_SEXP & 32) ? u32x4{(unsigned)i, 1u, (unsigned)lane, 7u} : *(const u32x4*)(ap + 2 * BM * 2 * 8);         \
+    AL[i] = (FCD_SEXP & 32) ? u32x4{(unsigned)lane, 3u, (unsigned)(IH), 9u} : *(const u32x4*)(ap + 2 * (2 * BM * 2 * 8)); \
   }
 #define Y_MFMA(IH, AV, BV)                                                                       \
   _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                  \
@@ -764,19 +764,19 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split256_kernel(WinoGemmArgs
   Y_MFMA(IH, AL, BH) Y_MFMA(IH, AH, BL) Y_MFMA(IH, AM, BM_) Y_MFMA(IH, AM, BH) Y_MFMA(IH, AH, BM_) Y_MFMA(IH, AH, BH)
 #define Y_STEP(SA, SB, SAN, SBN)                                                                 \
   {                                                                                              \
-    if (fb < nb) Y_DMA(SAN, SBN)                                                                 \
+    if (!(FCD_SEXP & 8)) if (fb < nb) Y_DMA(SAN, SBN)                                            \
     f32x4 xa[2][2];                                                                              \
     u32x4 pah[2], pam[2], pal[2], qah[2], qam[2], qal[2];                                        \
     u32x4 bh0[2], bm0[2], bl0[2], bh1[2], bm1[2], bl1[2];                                        \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                              \
-      xa[j][0] = *(const f32x4*)((SB) + boff[j] + ((0 ^ swb) * 4));                              \
-      xa[j][1] = *(const f32x4*)((SB) + boff[j] + ((1 ^ swb) * 4));                              \
+      xa[j][0] = (FCD_SEXP & 32) ? f32x4{(float)lane, 1.f, 0.f, 2.f} : *(const f32x4*)((SB) + boff[j] + ((0 ^ swb) * 4)); \
+      xa[j][1] = (FCD_SEXP & 32) ? f32x4{(float)j, 3.f, (float)lane, 2.f} : *(const f32x4*)((SB) + boff[j] + ((1 ^ swb) * 4)); \
     }                                                                                            \
     Y_LOADA(SA, 0, 0, pah, pam, pal)                                                             \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) WS_SPLIT(xa[j][0], xa[j][1], bh0[j], bm0[j], bl0[j]) \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                              \
-      xa[j][0] = *(const f32x4*)((SB) + boff[j] + ((2 ^ swb) * 4));                              \
-      xa[j][1] = *(const f32x4*)((SB) + boff[j] + ((3 ^ swb) * 4));                              \
+      xa[j][0] = (FCD_SEXP & 32) ? f32x4{(float)lane, 1.f, 2.f, 2.f} : *(const f32x4*)((SB) + boff[j] + ((2 ^ swb) * 4)); \
+      xa[j][1] = (FCD_SEXP & 32) ? f32x4{(float)j, 3.f, (float)lane, 2.f} : *(const f32x4*)((SB) + boff[j] + ((3 ^ swb) * 4)); \
     }                                                                                            \
     Y_SIX(0, pah, pam, pal, bh0, bm0, bl0)                                                       \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) WS_SPLIT(xa[j][0], xa[j][1], bh1[j], bm1[j], bl1[j]) \
@@ -845,6 +845,180 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split256_kernel(WinoGemmArgs
 #undef Y_DMA
 }
 
+// The same 256 x 256 tile as a two-group ping-pong (MI355X_MICROARCH.md, "Two waves per SIMD"): waves 0-3 (upper 128
+// rows, group A) and their SIMD partners 4-7 (lower 128 rows, group B) run the same stage loop ONE barrier interval
+// apart, so that in every interval each SIMD has one wave in its compute segment (48 MFMAs of a 16-element reduction
+// step, the second half's A fragments read from LDS in their shadow) beside one in its load segment (B fragments and the
+// first A fragments LDS -> registers, exact bf16 split of B, then the wave's 5 of the 40 LDS-DMA wave-instructions of
+// the stage two ahead).  The matrix pipe never waits for a split or an LDS round trip of its own wave.  Ring of four
+// 40-KB LDS stages = the whole LDS:
+//   interval 2n  : A load(n), A's half of DMA(n+2)    | B compute(n-1)
+//   interval 2n+1: A compute(n)                        | B load(n), B's half of DMA(n+2)
+// Slot (n+2) % 4 held stage n-2, last read in B's compute(n-2) = interval 2n-2; stage n+2 is first read in interval
+// 2n+4, after each group waited for its own half (vmcnt) before a barrier that precedes it.
+template <int DUMMY>
+__global__ __launch_bounds__(512, 1) void wino_gemm_split_pp_kernel(WinoGemmArgs a) {
+  constexpr int BM = 256, BN = 256;
+  constexpr int A_UNITS = 3 * 2 * BM;              // [plane][half][row] x 16 B (8 bf16)
+  constexpr int B_UNITS = 2 * BN * 2;              // [half][row][2 units of 4 fp32]
+    __shared__ __attribute__((aligned(16))) unsigned short sa0[A_UNITS * 8];
+  __shared__ __attribute__((aligned(16))) unsigned short sa1[A_UNITS * 8];
+  __shared__ __attribute__((aligned(16))) unsigned short sa2[A_UNITS * 8];
+  __shared__ __attribute__((aligned(16))) unsigned short sa3[A_UNITS * 8];
+  __shared__ __attribute__((aligned(16))) float sb0[B_UNITS * 4];
+  __shared__ __attribute__((aligned(16))) float sb1[B_UNITS * 4];
+  __shared__ __attribute__((aligned(16))) float sb2[B_UNITS * 4];
+  __shared__ __attribute__((aligned(16))) float sb3[B_UNITS * 4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wm = wave >> 2, wn = wave & 3;
+  unsigned v;
+  {
+    const unsigned total = gridDim.x, b = blockIdx.x;
+    if (a.xcd_remap) {
+      const unsigned q8 = total >> 3, r8 = total & 7u, xcd = b & 7u;
+      v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
+    } else {
+      v = b;
+    }
+  }
+  const int mt = (int)(v % (unsigned)a.m_tiles), nt = (int)(v / (unsigned)a.m_tiles);
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int Q = a.Kc / 16;                         // stages per batch (even)
+  const int b_first = (int)blockIdx.y * a.xb;
+  const int nb = min(a.xb, a.batches - b_first);
+  const int S = nb * Q;
+  const unsigned short* Ab = a.As + (size_t)b_first * a.a_batch + (size_t)m0 * a.a_ld;
+  const float* Bb = a.B + (size_t)b_first * a.b_batch + (size_t)n0 * a.b_ld;
+
+  // DMA (group B only; wave-instruction p of wave wn covers units (wn + 4 p) * 64 + lane).  A: 512 units per plane,
+  // so instruction p lies in plane p / 2.
+  // every wave issues 5 of the 40 wave-instructions of a stage: its group's half of each A plane and of the B slab
+  int a_goff[1], b_goff[2];
+  {
+    const int rem = (wn + 4 * wm) * 64 + lane;     // unit inside the plane: half * 256 + row
+    const int h = rem / BM, row = rem % BM;
+    a_goff[0] = (int)(min(row, a.M - 1 - m0) * a.a_ld) + h * 8;
+  }
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int u = (wn + 4 * (2 * p + wm)) * 64 + lane;
+    const int h = u / (BN * 2), row = (u >> 1) % BN, pj = u & 1;
+    const int jl = pj ^ ((row >> 4) & 1);          // 32-B row pitch: rows 16..31 of a block take the other unit parity
+    b_goff[p] = (int)(min(row, a.N - 1 - n0) * a.b_ld) + h * 8 + jl * 4;
+  }
+  int aoff[4], boff[2];
+  const int swb = (l31 >> 4) & 1;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) aoff[i] = (half * BM + wm * 128 + i * 32 + l31) * 8;        // bf16 elements, plane 0
+#pragma unroll
+  for (int j = 0; j < 2; ++j) boff[j] = (half * BN + wn * 64 + j * 32 + l31) * 8;         // floats, unit 0
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  int fq = 0, fb = 0;        // stage / batch of the next slab pair to fetch (group B)
+  int cq = 0, cb = 0;        // stage / batch being multiplied
+#define P_DMA(SA, SB)                                                                            \
+  {                                                                                              \
+    const unsigned short* as_ = Ab + (size_t)fb * a.a_batch + (size_t)fq * 16;                   \
+    const float* bs_ = Bb + (size_t)fb * a.b_batch + (size_t)(fq >> 1) * a.b_adv + (fq & 1) * 16; \
+    _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)       /* half `wm` of plane pl */             \
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(as_ + (size_t)pl * a.as_plane + a_goff[0]),  \
+                                       (lds_void_t*)((SA) + (pl * 8 + wn + 4 * wm) * 512), 16, 0, 0); \
+    _Pragma("unroll") for (int p = 0; p < 2; ++p)                                                \
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(bs_ + b_goff[p]),                           \
+                                       (lds_void_t*)((SB) + (wn + 4 * (2 * p + wm)) * 256), 16, 0, 0); \
+    /* past the last stage the last slabs are fetched again into a slot nobody reads any more: the number of DMA */ \
+    /* instructions of this wave in flight behind the stage being waited for is 5 on every path                              */ \
+    if (!(fb == nb - 1 && fq == Q - 1)) { if (++fq == Q) { fq = 0; ++fb; } }                     \
+  }
+#define P_LOADA(SA, IH, AH, AM, AL)                                                              \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                \
+    const unsigned short* ap = (SA) + aoff[2 * (IH) + i];                                        \
+    AH[i] = *(const u32x4*)(ap);                                                                 \
+    AM[i] = *(const u32x4*)(ap + 2 * BM * 8);                                                    \
+    AL[i] = *(const u32x4*)(ap + 2 * (2 * BM * 8));                                              \
+  }
+#define P_MFMA(IH, AV, BV)                                                                       \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                  \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                \
+      acc[2 * (IH) + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                            \
+          __builtin_bit_cast(bf16x8, AV[i]), __builtin_bit_cast(bf16x8, BV[j]), acc[2 * (IH) + i][j], 0, 0, 0);
+#define P_SIX(IH, AH, AM, AL)                                                                    \
+  P_MFMA(IH, AL, bh) P_MFMA(IH, AH, bl) P_MFMA(IH, AM, bm) P_MFMA(IH, AM, bh) P_MFMA(IH, AH, bm) P_MFMA(IH, AH, bh)
+// one stage of one wave: load segment, barrier, compute segment, barrier
+#define P_STAGE(SA, SB, FA, FB)                                                                  \
+  {                                                                                              \
+    u32x4 bh[2], bm[2], bl[2], pah[2], pam[2], pal[2], qah[2], qam[2], qal[2];                   \
+    {                                                                                            \
+      f32x4 xa[2][2];                                                                            \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                            \
+        xa[j][0] = *(const f32x4*)((SB) + boff[j] + ((0 ^ swb) * 4));                            \
+        xa[j][1] = *(const f32x4*)((SB) + boff[j] + ((1 ^ swb) * 4));                            \
+      }                                                                                          \
+      P_LOADA(SA, 0, pah, pam, pal)                                                              \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) WS_SPLIT(xa[j][0], xa[j][1], bh[j], bm[j], bl[j]) \
+    }                                                                                            \
+    if (!(FCD_SEXP & 8)) {                                                                       \
+      P_DMA(FA, FB)                                                                              \
+      __builtin_amdgcn_s_waitcnt(0x0F75);                                /* vmcnt(5) */          \
+    }                                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    __builtin_amdgcn_s_barrier();                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    P_LOADA(SA, 1, qah, qam, qal)                                                                \
+    P_SIX(0, pah, pam, pal)                                                                      \
+    P_SIX(1, qah, qam, qal)                                                                      \
+    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);                                           \
+    __builtin_amdgcn_sched_group_barrier(0x008, 48, 0);                                          \
+    if (++cq == Q) {                                                                             \
+      cq = 0;                                                                                    \
+      int ldc = a.N;                                                                             \
+      asm volatile("" : "+s"(ldc));                                                              \
+      float* Cb = a.C + (size_t)(b_first + cb) * a.M * ldc;                                      \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                              \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                         \
+          const int m = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;              \
+          _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                        \
+            const int n = n0 + wn * 64 + j * 32 + l31;                                           \
+            if (m < a.M && n < ldc) Cb[(size_t)m * ldc + n] = acc[i][j][r];                      \
+            acc[i][j][r] = 0.f;                                                                  \
+          }                                                                                      \
+        }                                                                                        \
+      ++cb;                                                                                      \
+    }                                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    __builtin_amdgcn_s_barrier();                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+  }
+
+  P_DMA(sa0, sb0)
+  P_DMA(sa1, sb1)              // (S >= 2: reductions of >= 32 elements only)
+  __builtin_amdgcn_s_waitcnt(0x0F75);            // vmcnt(5): this wave's part of stage 0 has landed
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();     // group B runs one interval behind
+#pragma unroll 1
+  for (int g = 0; g < S; g += 4) {
+    P_STAGE(sa0, sb0, sa2, sb2)
+    if (g + 1 < S) P_STAGE(sa1, sb1, sa3, sb3)
+    if (g + 2 < S) P_STAGE(sa2, sb2, sa0, sb0)
+    if (g + 3 < S) P_STAGE(sa3, sb3, sa1, sb1)
+  }
+  if (wm == 0) __builtin_amdgcn_s_barrier();     // ... and group A waits for it at the end
+  __builtin_amdgcn_s_waitcnt(0x0F70);            // the surplus prefetches must land before the LDS allocation is released
+#undef P_STAGE
+#undef P_SIX
+#undef P_MFMA
+#undef P_LOADA
+#undef P_DMA
+}
+
 static int wino_gemm_cfg() {     // FCD_WINO_TILE: 0 = 128x128 (4 waves), 1 = 256x128 (8 waves), 2 = 256x256 (16 waves)
   static int v = -1;
   if (v < 0) {
@@ -894,13 +1068,18 @@ static void wino_gemm_launch(WinoGemmArgs ga, int batches, int splits, hipStream
   int cfg = wino_gemm_cfg();
   if (ga.As && splits == 1 && ga.M > 64 && wino_split()) {
     ga.batches = batches;
+    // FCD_WINO_SPLIT_BIG: 0 = 128 x 128 tiles only; 1 (default) = 256 x 256 two-stage kernel for GEMMs with >= 256
+    // rows and enough tiles to fill the chip; 2 = ... for every GEMM with >= 256 rows (tests); 4 / 5 = the same two
+    // policies with the ping-pong kernel (measured slower: DESIGN.md)
     static int big = -1;
     if (big < 0) { const char* e = getenv("FCD_WINO_SPLIT_BIG"); big = e ? atoi(e) : 1; }
-    if (big && ga.M >= 256 && (big == 2 || (long long)cdiv(ga.M, 256) * cdiv(ga.N, 256) * batches >= 1024)) {
+    const bool force = big == 2 || big == 5;
+    if (big && ga.M >= 256 && (force || (long long)cdiv(ga.M, 256) * cdiv(ga.N, 256) * batches >= 1024)) {
       ga.m_tiles = cdiv(ga.M, 256); ga.n_tiles = cdiv(ga.N, 256);
       ga.xb = wino_gemm_xb((long long)ga.m_tiles * ga.n_tiles * 2, batches, 1, ga.Kc / 32);
-      hipLaunchKernelGGL((wino_gemm_split256_kernel<0>), dim3((unsigned)(ga.m_tiles * ga.n_tiles), (unsigned)cdiv(batches, ga.xb)),
-                         dim3(512), 0, st, ga);
+      const dim3 grid((unsigned)(ga.m_tiles * ga.n_tiles), (unsigned)cdiv(batches, ga.xb));
+      if (big >= 4) hipLaunchKernelGGL((wino_gemm_split_pp_kernel<0>), grid, dim3(512), 0, st, ga);
+      else hipLaunchKernelGGL((wino_gemm_split256_kernel<0>), grid, dim3(512), 0, st, ga);
       return;
     }
     ga.m_tiles = cdiv(ga.M, 128); ga.n_tiles = cdiv(ga.N, 128);
