@@ -31,6 +31,7 @@ import torch
 import torch.distributed as dist
 
 PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 MFMA (MI355X_MICROARCH.md); the split GEMM executes 6 bf16 FLOPs per fp32-equivalent FLOP
 
 
 WORKLOADS = {
@@ -141,6 +142,24 @@ def write_layer_tables(path, detail, psteps, args):
     if tot_ms > 0:
         L += ['', 'all launches: %.2f ms/step, %.1f TFLOP/s = %.3f of peak' % (
             tot_ms / psteps, tot_fl / (tot_ms * 1e-3) / 1e12, tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS)]
+    rr = rows('wino_gemm_bf16x6')
+    if rr:
+        L += ['', '## wino_gemm_split kernels: the same batched GEMM on the bf16 matrix pipe, fp32 operands split exactly into three '
+              'bf16 parts, six partial products accumulated in fp32', '',
+              'GFLOP = fp32-equivalent GEMM FLOPs (2 x batch x M x N x Kc); the MFMAs execute 6x that in bf16; bf16 dense peak %.0f TFLOP/s' % PEAK_BF16_MFMA_TFLOPS, '',
+              '| launch | /step | avg us | ms/step | GFLOP (fp32-equiv) | TFLOP/s fp32-equiv | x of the fp32 MFMA peak | bf16 TFLOP/s executed | of bf16 peak |',
+              '|---|---|---|---|---|---|---|---|---|']
+        tms = tfl = 0.0
+        for tag, g in rr:
+            us = 1e3 * g['ms'] / g['n']
+            tf = g['flops'] / (g['ms'] * 1e-3) / 1e12 if g['ms'] > 0 else 0.0
+            tms += g['ms']; tfl += g['flops']
+            L.append('| %s | %.1f | %.1f | %.3f | %.2f | %.1f | %.2f | %.0f | %.2f |' % (
+                tag, g['n'] / float(psteps), us, g['ms'] / psteps, g['flops'] / g['n'] / 1e9, tf, tf / PEAK_F32_MFMA_TFLOPS,
+                6 * tf, 6 * tf / PEAK_BF16_MFMA_TFLOPS))
+        tf = tfl / (tms * 1e-3) / 1e12
+        L += ['', 'all launches: %.2f ms/step, %.1f TFLOP/s fp32-equivalent (%.2fx the fp32 MFMA peak), %.0f TFLOP/s bf16 executed = %.3f of the bf16 peak'
+              % (tms / psteps, tf, tf / PEAK_F32_MFMA_TFLOPS, 6 * tf, 6 * tf / PEAK_BF16_MFMA_TFLOPS)]
     for fam, title in (('conv_igemm_fwd', 'direct convolution, forward (algorithmic FLOPs)'),
                        ('conv_igemm_dgrad', 'direct convolution, data gradient (algorithmic FLOPs)'),
                        ('conv_wino2_fwd', 'fused Winograd F(2x2,3x3) kernel, forward (algorithmic conv FLOPs; executed MFMA FLOPs = x 16/36)'),
@@ -243,6 +262,7 @@ def main():
     ap.add_argument('--size', type=int, default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prof', action='store_true', help='skip the second (profiled) pass')
+    ap.add_argument('--no-alt', action='store_true', help='skip the extra pass with the Winograd GEMMs on the fp32 matrix pipe')
     ap.add_argument('--prof-steps', type=int, default=3, help='steps of the profiled pass (HIP events around every launch)')
     ap.add_argument('--layers-md', default=None, help='write per-layer tables of the profiled pass to this markdown file')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend: 'nccl' (= RCCL over xGMI); "
@@ -292,6 +312,26 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # ---- the same K' steps with the Winograd GEMMs on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32) instead of the
+    #      split-bf16 one: reported next to `value`, never as `value`
+    alt = None
+    if not args.no_alt and _lib.lib.fcd_conv_wino_split_set(-1) == 1:
+        _lib.lib.fcd_conv_wino_split_set(0)
+        ksteps = max(1, min(args.steps, 3))
+        step()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(ksteps):
+            step()
+        barrier()
+        dta = time.perf_counter() - t1
+        _lib.lib.fcd_conv_wino_split_set(1)
+        if world > 1:
+            t = torch.tensor([dta], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dta = float(t.item())
+        alt = {'what': 'same workload with FCD_WINO_SPLIT=0: the Winograd batched GEMMs on v_mfma_f32_32x32x2_f32 (round-1/2 path)',
+               'value': args.batch * n_gpus * ksteps / dta, 'unit': 'tile-pairs/s', 'ms_per_step': 1e3 * dta / ksteps, 'steps': ksteps}
     # ---- profiled pass (not part of `value`): every launch bracketed by HIP events on its stream
     prof, detail, dt_prof, psteps = {}, [], None, 0
     if not args.no_prof:
@@ -322,17 +362,27 @@ def main():
                        'baseline_config': 'BASELINE.json configs[%d]' % WORKLOADS[args.workload][0],
                        'tile_pairs_per_gpu': args.batch, 'global_batch': args.batch * n_gpus,
                        'parallelism': 'dp%d' % n_gpus, 'bn': 'per-replica statistics',
+                       'arithmetic': 'fp32 tensors, fp32 accumulation everywhere.  Matrix pipes: v_mfma_f32_* for the direct / '
+                                     'F(2x2) / weight-gradient kernels; the batched GEMMs of the Winograd F(4x4,3x3) layers run on '
+                                     'v_mfma_f32_32x32x16_bf16 with every fp32 operand split EXACTLY into three bf16 parts and six partial '
+                                     'products per multiply summed in fp32 (dropped terms <= 2^-24 relative: fp32-equivalent, measured '
+                                     'error vs fp64 <= that of the fp32 MFMA path, tests/test_gpu_ops.py); `fp32_mfma_only` below is the '
+                                     'same step with those GEMMs on the fp32 pipe' if _lib.lib.fcd_conv_wino_split_set(-1) == 1 else
+                                     'fp32 tensors, fp32 MFMA (v_mfma_f32_*), fp32 accumulation',
                        'world_size': dist.get_world_size() if world > 1 else 1,
                        'backend': (dist.get_backend() if world > 1 else 'none'),
                        'grad_exchange': 'bucketed all-reduce overlapped with backward' if world > 1 else 'none (1 rank)'},
             'losses_last_step': losses,
         }
+        if alt:
+            res['fp32_mfma_only'] = alt
         if prof:
             fwd, dg, wg = prof['conv_igemm_fwd'], prof['conv_igemm_dgrad'], prof['conv_wgrad']
             zero = dict(ms=0.0, launches=0, flops=0.0, bytes=0.0)
             wf, wd = prof.get('conv_wino_fwd', zero), prof.get('conv_wino_dgrad', zero)
             w2f, w2d = prof.get('conv_wino2_fwd', zero), prof.get('conv_wino2_dgrad', zero)
             wgemm, wxf = prof.get('wino_gemm', zero), prof.get('wino_transform', zero)
+            wsplit = prof.get('wino_gemm_bf16x6', zero)
 
             def mfma_entry(name, ms, flops, launches, what):
                 ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
@@ -356,6 +406,18 @@ def main():
                            '3x3 layers, the Winograd F(4x4,3x3) form (its GEMM launches are also part of wino_gemm_kernel above)',
                            wg['ms'], wg['flops'], wg['launches'], 'algorithmic weight-gradient FLOPs (direct count)'),
             ]
+            if wsplit['launches'] > 0:
+                e = mfma_entry('wino_gemm_split256_kernel / wino_gemm_split_kernel (batched GEMM of the Winograd F(4x4,3x3) path, forward + '
+                               'data-gradient launches, on the bf16 matrix pipe: every fp32 operand split exactly into three bf16 parts, six '
+                               'partial products per multiply accumulated in fp32 -- fp32-equivalent results, tests/test_gpu_ops.py)',
+                               wsplit['ms'], 6.0 * wsplit['flops'], wsplit['launches'],
+                               'executed bf16 MFMA FLOPs = 6 x the fp32-equivalent GEMM FLOPs')
+                e['peak'] = PEAK_BF16_MFMA_TFLOPS
+                e['frac'] = e['achieved'] / PEAK_BF16_MFMA_TFLOPS
+                e['fp32_equivalent_tflops'] = e['achieved'] / 6.0
+                e['fp32_equivalent_over_fp32_mfma_peak'] = e['achieved'] / 6.0 / PEAK_F32_MFMA_TFLOPS
+                e['gflop_per_launch_fp32_equivalent'] = e['gflop_per_launch'] / 6.0
+                cands.append(e)
             if w2f['launches'] + w2d['launches'] > 0:
                 cands.append(mfma_entry('conv_wino2_kernel (fused Winograd F(2x2,3x3): input transform + sixteen 16x16x4 fp32 MFMA GEMMs + output '
                                         'transform in one kernel; the 64-row 3x3 layers, forward + data gradient)', w2f['ms'] + w2d['ms'],
@@ -372,9 +434,12 @@ def main():
                 with open(tpath) as f:
                     tj = json.load(f).get('families', {})
                 alg = {'wino_gemm': wgemm['bytes'] / max(wgemm['launches'], 1),
+                       'wino_gemm_split': wsplit['bytes'] / max(wsplit['launches'], 1),
                        'conv_igemm': (fwd['bytes'] + dg['bytes']) / max(fwd['launches'] + dg['launches'], 1)}
                 for e in cands:
-                    key = 'wino_gemm' if e['kernel'].startswith('wino_gemm') else ('conv_igemm' if e['kernel'].startswith('conv_igemm') else None)
+                    key = ('wino_gemm_split' if e['kernel'].startswith('wino_gemm_split') else
+                           'wino_gemm' if e['kernel'].startswith('wino_gemm') else
+                           'conv_igemm' if e['kernel'].startswith('conv_igemm') else None)
                     if key and key in tj:
                         e['traffic'] = tj[key]['hbm_bytes_per_launch']
                         e['traffic_unit'] = ('HBM bytes per launch: PMC FETCH_SIZE x %.2f + WRITE_SIZE x %.2f (factors calibrated in the same '
@@ -393,7 +458,7 @@ def main():
                             'tests/test_gpu_ops.py)' % (mt, mt),
                     'layer_calls_per_step': (wf['launches'] + wd['launches']) / psteps, 'ms_per_step': wms / psteps,
                     'algorithmic_conv_tflops': wfl / (wms * 1e-3) / 1e12,
-                    'gemm_ms_per_step': wgemm['ms'] / psteps, 'transform_ms_per_step': wxf['ms'] / psteps,
+                    'gemm_ms_per_step': (wgemm['ms'] + wsplit['ms']) / psteps, 'transform_ms_per_step': wxf['ms'] / psteps,
                     'transform_gbps': wxf['bytes'] / (wxf['ms'] * 1e-3) / 1e9 if wxf['ms'] > 0 else None,
                     'share_of_step_time': wms / (1e3 * dt_prof),
                 }
@@ -404,7 +469,7 @@ def main():
                     'tflops': (v['flops'] / (v['ms'] * 1e-3) / 1e12) if v['ms'] > 0 and v['flops'] > 0 else None,
                     'gbps': (v['bytes'] / (v['ms'] * 1e-3) / 1e9) if v['ms'] > 0 and v['bytes'] > 0 else None}
                 for k, v in prof.items() if v['launches'] > 0}
-            for k in ('wino_gemm', 'wino_transform'):
+            for k in ('wino_gemm', 'wino_gemm_bf16x6', 'wino_transform'):
                 if k in res['kernel_families']:
                     res['kernel_families'][k]['nested_in'] = 'conv_wino_fwd + conv_wino_dgrad + conv_wgrad_wino'
             if 'conv_wgrad_wino' in res['kernel_families']:
@@ -414,7 +479,7 @@ def main():
             # count + tile padding); both over the HEADLINE step time (events off)
             wgw = prof.get('conv_wgrad_wino', zero)
             alg = fwd['flops'] + dg['flops'] + wf['flops'] + wd['flops'] + wg['flops'] + w2f['flops'] + w2d['flops']
-            exe = fwd['flops'] + dg['flops'] + wgemm['flops'] + (wg['flops'] - wgw['flops']) + (w2f['flops'] + w2d['flops']) * 16.0 / 36.0
+            exe = fwd['flops'] + dg['flops'] + wgemm['flops'] + wsplit['flops'] + (wg['flops'] - wgw['flops']) + (w2f['flops'] + w2d['flops']) * 16.0 / 36.0
             step_s = dt / args.steps
             res['whole_step'] = {'algorithmic_tflops': alg / psteps / step_s / 1e12,
                                  'executed_tflops': exe / psteps / step_s / 1e12,

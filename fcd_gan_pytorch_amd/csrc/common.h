@@ -49,7 +49,9 @@ enum {
   FCD_K_WGRAD_WINO = 13,// nested in 2: weight-gradient calls that take the Winograd form (FLOPs = direct count)
   FCD_K_WINO2_FWD = 14, // fused Winograd F(2x2,3x3) kernel (64-row layers), forward; FLOPs = direct count (executed: x 16/36)
   FCD_K_WINO2_DGRAD = 15,
-  FCD_K_COUNT = 16
+  FCD_K_WINO_GEMM_SPLIT = 16, // nested in 9/10: the batched GEMM on the bf16 matrix pipe (exact three-way operand split);
+                              // FLOPs = fp32-equivalent GEMM FLOPs (the bf16 MFMAs execute 6x that)
+  FCD_K_COUNT = 17
 };
 
 struct FcdProfScope {

@@ -41,7 +41,7 @@ double g_ms[FCD_K_COUNT], g_launches[FCD_K_COUNT], g_flops[FCD_K_COUNT], g_bytes
 const char* kNames[FCD_K_COUNT] = {"conv_igemm_fwd", "conv_igemm_dgrad", "conv_wgrad", "pack_weights",
                                    "norm_act",       "pool_resize",      "loss",       "optim",
                                    "misc", "conv_wino_fwd", "conv_wino_dgrad", "wino_gemm", "wino_transform",
-                                   "conv_wgrad_wino", "conv_wino2_fwd", "conv_wino2_dgrad"};
+                                   "conv_wgrad_wino", "conv_wino2_fwd", "conv_wino2_dgrad", "wino_gemm_bf16x6"};
 
 hipEvent_t get_event() {
   if (!g_free_events.empty()) {

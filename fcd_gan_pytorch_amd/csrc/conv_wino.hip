@@ -1060,7 +1060,7 @@ static int wino_split() {
 }
 extern "C" int fcd_conv_wino_split_set(int on) {
   const int old = wino_split();
-  if (on >= 0) g_wino_split = on ? 1 : 0;
+  if (on >= 0) g_wino_split = on > 2 ? 1 : on;      // 2: as 1, and the 256 x 256 kernel for every GEMM with >= 256 rows (tests)
   return old;
 }
 
@@ -1073,7 +1073,7 @@ static void wino_gemm_launch(WinoGemmArgs ga, int batches, int splits, hipStream
     // policies with the ping-pong kernel (measured slower: DESIGN.md)
     static int big = -1;
     if (big < 0) { const char* e = getenv("FCD_WINO_SPLIT_BIG"); big = e ? atoi(e) : 1; }
-    const bool force = big == 2 || big == 5;
+    const bool force = big == 2 || big == 5 || wino_split() == 2;
     if (big && ga.M >= 256 && (force || (long long)cdiv(ga.M, 256) * cdiv(ga.N, 256) * batches >= 1024)) {
       ga.m_tiles = cdiv(ga.M, 256); ga.n_tiles = cdiv(ga.N, 256);
       ga.xb = wino_gemm_xb((long long)ga.m_tiles * ga.n_tiles * 2, batches, 1, ga.Kc / 32);
@@ -1382,8 +1382,9 @@ static int wino_run(const WinoPlan& pl, int N, int in_ch, int H, int W, const fl
   ga.b_ld = 32; ga.b_adv = (long long)pl.T * 32; ga.b_batch = (long long)pl.Q * pl.T * 32;   // V [xi][Q][T][32]
   ga.stages_per_split = pl.Q;
   {
-    FcdProfScope p2(FCD_K_WINO_GEMM, st, 2.0 * pl.A2 * pl.rows * (double)pl.Kc * (double)pl.T,
-                    (double)pl.v_bytes + (double)pl.m_bytes + 4.0 * pl.A2 * pl.rows * pl.Kc,
+    const bool split = pl.rows > 64 && wino_split();
+    FcdProfScope p2(split ? FCD_K_WINO_GEMM_SPLIT : FCD_K_WINO_GEMM, st, 2.0 * pl.A2 * pl.rows * (double)pl.Kc * (double)pl.T,
+                    (double)pl.v_bytes + (double)pl.m_bytes + (split ? 6.0 : 4.0) * pl.A2 * pl.rows * pl.Kc,
                     fcd_prof_tagf("conv M=%d N=%lld Kc=%d batch=%d img=%dx%dx%d", pl.rows, pl.T, pl.Kc, pl.A2, N, H, W));
     wino_gemm_launch(ga, pl.A2, 1, st);
   }

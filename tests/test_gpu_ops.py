@@ -385,6 +385,44 @@ def test_conv_winograd_path(case, m):
         lib.fcd_conv_wino_set(prev)
 
 
+@pytest.mark.parametrize('case', [(2, 256, 32, 32, 256), (1, 512, 36, 20, 384), (3, 128, 24, 40, 320), (1, 1024, 16, 16, 512)],
+                         ids=lambda c: 'x'.join(map(str, c)))
+def test_wino_gemm_matrix_pipes(case):
+    """The batched GEMM of the F(4x4,3x3) path on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32) and on the bf16 pipe with
+    exact three-way operand splitting (128 x 128 and 256 x 256 tile kernels): forward and data gradient vs torch fp64.
+    The split path is fp32-equivalent: same bound as the fp32 pipe, and its error may not exceed the fp32 pipe's by
+    more than a rounding's worth."""
+    ops = _ops()
+    lib = ops.lib
+    N, C, H, W, K = case
+    x = rnd(N, C, H, W, seed=31)
+    w = rnd(K, C, 3, 3, seed=32, scale=(2.0 / (C * 9)) ** 0.5)
+    b = rnd(K, seed=33, scale=0.1)
+    g = rnd(N, K, H, W, seed=34)
+    xr = x.double().requires_grad_(True)
+    yr = F.conv2d(xr, w.double(), b.double(), padding=1)
+    yr.backward(g.double())
+    ys, ds = yr.abs().max().item(), xr.grad.abs().max().item()
+    err = {}
+    prev = lib.fcd_conv_wino_split_set(-1)
+    try:
+        for mode in (0, 1, 2):
+            lib.fcd_conv_wino_split_set(mode)
+            xg = x.cuda().requires_grad_(True)
+            y = ops.conv2d(xg, w.cuda(), b.cuda(), 1, 1)
+            y.backward(g.cuda())
+            ey = (y.detach().cpu().double() - yr.detach())
+            ed = (xg.grad.cpu().double() - xr.grad)
+            err[mode] = (ey.abs().max().item() / ys, ey.pow(2).mean().sqrt().item() / ys,
+                         ed.abs().max().item() / ds, ed.pow(2).mean().sqrt().item() / ds)
+            assert err[mode][0] < 6e-5 and err[mode][2] < 6e-5, (mode, err[mode])
+    finally:
+        lib.fcd_conv_wino_split_set(prev)
+    for mode in (1, 2):
+        for q in (1, 3):      # rms error of y and of dx (the F(4x4) transforms' own rounding dominates both)
+            assert err[mode][q] <= 1.15 * err[0][q] + 1e-8, (mode, q, err)
+
+
 def test_conv_winograd_matches_direct_kernels():
     """Same layer through the direct MFMA kernel and both Winograd tile sizes."""
     ops = _ops()
