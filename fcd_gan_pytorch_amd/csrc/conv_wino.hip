@@ -297,6 +297,175 @@ __global__ __launch_bounds__(256) void wino_input_kernel(WinoInArgs a) {
   }
 }
 
+// The same transform for the plain source on wide maps (1 x TWB strips, W % 4 == 0), one block walking ROLL
+// consecutive tile rows of its 32-channel chunk: while the strip in LDS is transformed and its 36 V planes are stored,
+// the next strip's rows are already in flight into registers (12 float4 + 2 halo scalars per thread) -- the load,
+// transform and store phases of the one-strip kernel run back to back (measured: load + compute 0.86 ms, compute +
+// store 0.65 ms of a 1.42 ms launch), here they overlap inside the block as well as across blocks.
+template <int MM, int SRC, int TRB, int TWB>      // SRC 0 plain, 1 gated by the ReLU output `mask` (kept raw in registers too),
+                                                  // 2 pooled gradient + argmax codes (routed when the strip is written to LDS)
+__global__ __launch_bounds__(256) void wino_input_roll_kernel(WinoInArgs a, int roll) {
+  constexpr int A = WinoMat<MM>::A;
+  constexpr int RH = TRB * MM + 2, CW = TWB * MM + 2;
+  constexpr int PL = (RH * CW) | 1;
+  constexpr int V4 = (CW - 2) / 4;
+  constexpr int NV = (32 * RH * V4 + 255) / 256, NH = (32 * RH * 2 + 255) / 256;
+  __shared__ float tile[32 * PL];
+  const int tid = threadIdx.x;
+  unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (a.xcd) {
+    const unsigned lin = xcd_contiguous_id(bx + gridDim.x * (by + gridDim.y * bz), gridDim.x * gridDim.y * gridDim.z);
+    bx = lin % gridDim.x;
+    by = (lin / gridDim.x) % gridDim.y;
+    bz = lin / (gridDim.x * gridDim.y);
+  }
+  const int tx0 = bx * TWB;
+  const int n = bz / a.Q, q = bz % a.Q;
+  const int iw0 = tx0 * MM - 1;
+  const int plane = (SRC == 2) ? a.Hp * a.Wp : a.H * a.W;
+  const size_t img = ((size_t)n * a.C + (size_t)q * 32) * plane;
+  const int ty_beg = by * roll * TRB, ty_end = min(a.TH, ty_beg + roll * TRB);      // tile rows [ty_beg, ty_end), TRB per strip
+
+  f32x4 pre[NV], msk[SRC == 1 ? NV : 1];
+  float preh[NH], mskh[SRC != 0 ? NH : 1];
+  auto issue = [&](int ty) {
+    const int ih0 = ty * MM - 1;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int idx = tid + 256 * k;
+      const int c = idx / (RH * V4), rem = idx % (RH * V4);
+      const int r = rem / V4, v4 = rem % V4;
+      const int ih = ih0 + r, iw = iw0 + 1 + v4 * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f}, m = {1.f, 1.f, 1.f, 1.f};
+      if (SRC == 2) {
+        // 4 strip columns = 2 pooled elements: {g0, g1, code0 | code1 << 8 (as bits), -}
+        const int hp = ih >> 1, wq = iw >> 1;
+        unsigned cc = 0;
+        if (idx < 32 * RH * V4 && q * 32 + c < a.C && ih >= 0 && ih < a.H && iw < a.W && hp < a.Hp && wq < a.Wp) {
+          const size_t off = img + (size_t)c * plane + (size_t)hp * a.Wp + wq;
+          if (wq + 1 < a.Wp) {
+            const f32x2 g2 = *(const f32x2*)(a.x + off);
+            v[0] = g2[0]; v[1] = g2[1];
+            cc = (unsigned)a.code[off] | ((unsigned)a.code[off + 1] << 8);
+          } else {
+            v[0] = a.x[off];
+            cc = (unsigned)a.code[off];
+          }
+        }
+        v[2] = __uint_as_float(cc);
+      } else if (idx < 32 * RH * V4 && q * 32 + c < a.C && ih >= 0 && ih < a.H && iw < a.W) {
+        const size_t off = img + (size_t)c * plane + (size_t)ih * a.W + iw;
+        v = *(const f32x4*)(a.x + off);
+        if (SRC == 1) m = *(const f32x4*)(a.mask + off);
+      }
+      pre[k] = v;
+      if (SRC == 1) msk[k] = m;
+    }
+#pragma unroll
+    for (int k = 0; k < NH; ++k) {
+      const int idx = tid + 256 * k;
+      const int c = idx / (RH * 2), rem = idx % (RH * 2);
+      const int r = rem >> 1, col = (rem & 1) ? CW - 1 : 0;
+      const int ih = ih0 + r, iw = iw0 + col;
+      float v = 0.f, m = 1.f;
+      if (idx < 32 * RH * 2 && q * 32 + c < a.C && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) {
+        if (SRC == 2) {
+          const int hp = ih >> 1, wq = iw >> 1;
+          if (hp < a.Hp && wq < a.Wp) {
+            const size_t off = img + (size_t)c * plane + (size_t)hp * a.Wp + wq;
+            v = a.x[off];
+            m = ((unsigned)a.code[off] == (unsigned)((((ih & 1) << 1) | (iw & 1)) | 4)) ? 1.f : 0.f;
+          }
+        } else {
+          const size_t off = img + (size_t)c * plane + (size_t)ih * a.W + iw;
+          v = a.x[off];
+          if (SRC == 1) m = a.mask[off];
+        }
+      }
+      preh[k] = v;
+      if (SRC != 0) mskh[k] = m;
+    }
+  };
+  auto commit = [&](int ty) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int idx = tid + 256 * k;
+      if (idx >= 32 * RH * V4) continue;
+      const int c = idx / (RH * V4), rem = idx % (RH * V4);
+      const int r = rem / V4, v4 = rem % V4;
+      float* t = tile + c * PL + r * CW + 1 + v4 * 4;
+      if (SRC == 2) {
+        const unsigned cc = __float_as_uint(pre[k][2]), c0 = cc & 0xffu, c1 = cc >> 8;
+        const unsigned rowbit = (unsigned)(((ty * MM - 1 + r) & 1) << 1) | 4u;
+        t[0] = c0 == rowbit ? pre[k][0] : 0.f;
+        t[1] = c0 == (rowbit | 1u) ? pre[k][0] : 0.f;
+        t[2] = c1 == rowbit ? pre[k][1] : 0.f;
+        t[3] = c1 == (rowbit | 1u) ? pre[k][1] : 0.f;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[e] = (SRC == 1 && !(msk[k][e] > 0.f)) ? 0.f : pre[k][e];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NH; ++k) {
+      const int idx = tid + 256 * k;
+      if (idx >= 32 * RH * 2) continue;
+      const int c = idx / (RH * 2), rem = idx % (RH * 2);
+      const int r = rem >> 1, col = (rem & 1) ? CW - 1 : 0;
+      tile[c * PL + r * CW + col] = (SRC != 0 && !(mskh[k] > 0.f)) ? 0.f : preh[k];
+    }
+  };
+
+  const size_t xi_stride = (size_t)a.Q * a.T * 32;
+  issue(ty_beg);
+  commit(ty_beg);
+  __syncthreads();
+#pragma unroll 1
+  for (int ty0 = ty_beg; ty0 < ty_end; ty0 += TRB) {
+    if (ty0 + TRB < ty_end) issue(ty0 + TRB);
+#pragma unroll 1
+    for (int it = tid; it < TRB * TWB * 32; it += 256) {
+      const int c = it & 31, tl = it >> 5;
+      const int tr = tl / TWB, tc = tl % TWB;
+      const int tx = tx0 + tc, ty = ty0 + tr;
+      if (tx >= a.TW || ty >= a.TH) continue;
+      float d[A][A];
+#pragma unroll
+      for (int i = 0; i < A; ++i)
+#pragma unroll
+        for (int j = 0; j < A; ++j) d[i][j] = tile[c * PL + (tr * MM + i) * CW + tc * MM + j];
+      float t1[A][A];
+#pragma unroll
+      for (int i = 0; i < A; ++i)
+#pragma unroll
+        for (int j = 0; j < A; ++j) {
+          float s = 0.f;
+#pragma unroll
+          for (int k = 0; k < A; ++k)
+            if (WinoMat<MM>::BT(i, k) != 0.f) s += WinoMat<MM>::BT(i, k) * d[k][j];
+          t1[i][j] = s;
+        }
+      const size_t t = ((size_t)n * a.TH + ty) * a.TW + tx;
+      float* vout = a.V + ((size_t)q * a.T + t) * 32 + c;
+#pragma unroll
+      for (int i = 0; i < A; ++i)
+#pragma unroll
+        for (int j = 0; j < A; ++j) {
+          float s = 0.f;
+#pragma unroll
+          for (int k = 0; k < A; ++k)
+            if (WinoMat<MM>::BT(j, k) != 0.f) s += t1[i][k] * WinoMat<MM>::BT(j, k);
+          vout[(size_t)(i * A + j) * xi_stride] = s;
+        }
+    }
+    if (ty0 + TRB < ty_end) {
+      __syncthreads();       // every thread is done reading this strip
+      commit(ty0 + TRB);
+      __syncthreads();
+    }
+  }
+}
+
 // --------------------------------------------------------------------------------------------
 // batched TN GEMM:  C[b][m][n] = sum_k A[b][m][k] * B[b][k / 32][n][k % 32]
 // 128 x 128 block tile, 4 waves of 64 x 64 (2 x 2 MFMA 32x32x2 tiles), 32-channel chunks.  Both
@@ -1338,6 +1507,22 @@ static void wino_launch_input_cfg(const WinoInArgs& ia, int src, hipStream_t st)
 template <int MM>
 static void wino_launch_input(const WinoInArgs& ia, int src, hipStream_t st) {
   constexpr int NT = 64 / MM;             // tiles per block: 64 output pixels per patch row at 1 x NT
+  static int roll = -1;
+  if (roll < 0) { const char* e = getenv("FCD_WINO_IN_ROLL"); roll = e ? atoi(e) : 4; }
+  // maps >= 2 strips high: the rolling kernel (next strip prefetched into registers)
+  if ((ia.W & 3) == 0 && (src != 2 || (ia.Wp & 1) == 0) && roll > 1 && ia.TW > NT / 4) {
+    const int trb = ia.TW > NT / 2 ? 1 : 2, strips = cdiv(ia.TH, trb);
+    if (strips >= 2) {
+      const int r = std::min(roll, strips);
+      dim3 grid((unsigned)cdiv(ia.TW, NT / trb), (unsigned)cdiv(strips, r), (unsigned)(ia.N * ia.Q));
+#define WINO_ROLL(SRC_, TRB_) hipLaunchKernelGGL((wino_input_roll_kernel<MM, SRC_, TRB_, NT / TRB_>), grid, dim3(256), 0, st, ia, r)
+      if (src == 0) { if (trb == 1) WINO_ROLL(0, 1); else WINO_ROLL(0, 2); }
+      else if (src == 1) { if (trb == 1) WINO_ROLL(1, 1); else WINO_ROLL(1, 2); }
+      else { if (trb == 1) WINO_ROLL(2, 1); else WINO_ROLL(2, 2); }
+#undef WINO_ROLL
+      return;
+    }
+  }
   if (ia.TW > NT / 2 && (ia.exp & 1)) wino_launch_input_cfg<MM, 1, NT / 2>(ia, src, st);
   else if (ia.TW > NT / 2) wino_launch_input_cfg<MM, 1, NT>(ia, src, st);
   else if (ia.TW > NT / 4) wino_launch_input_cfg<MM, 2, NT / 2>(ia, src, st);

@@ -35,6 +35,10 @@ def main():
             continue
         g = torch.Generator(device='cuda').manual_seed(1)
         x = torch.randn(N, C, HW, HW, device='cuda', generator=g)
+        if os.environ.get('ZERO_X'):
+            x.zero_()
+        if os.environ.get('SMALL_X'):
+            x.mul_(0).add_(1.0)
         w = torch.randn(K, C, 3, 3, device='cuda', generator=g) * 0.05
         b = torch.zeros(K, device='cuda')
         d = ops._desc(x.shape, w.shape, 1, 1)
@@ -59,7 +63,7 @@ def main():
         lib.fcd_prof_enable(0)
         _lib.prof_read(reset=True)
         det = _lib.prof_detail(reset=True)
-        gm = [e for e in det if e['family'] == 'wino_gemm']
+        gm = [e for e in det if e['family'] in ('wino_gemm', 'wino_gemm_bf16x6')]
         xf = [e for e in det if e['family'] == 'wino_transform']
         tg = sum(e['ms'] for e in gm) / 5
         tx = sum(e['ms'] for e in xf) / 5
