@@ -5,7 +5,7 @@ for pass in FETCH_SIZE WRITE_SIZE; do
   OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_bench_$pass
   rm -rf $OUT && mkdir -p $OUT
   ( cd $GRAFT_REPO_ROOT && timeout 900 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $OUT -o pmc -- \
-      python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof > $OUT/run.log 2>&1 )
+      python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof --no-alt > $OUT/run.log 2>&1 )
   tail -1 $OUT/run.log | cut -c1-200
   # the raw CSVs are large: keep only the per-kernel aggregate
   python3 - "$OUT" "$pass" <<'PY'
