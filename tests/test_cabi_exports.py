@@ -47,8 +47,8 @@ def test_argument_validation_without_gpu():
         assert lib.fcd_conv_wino_plan(ctypes.byref(wide), 0) == 4 and lib.fcd_conv_wino_plan(ctypes.byref(wide), 1) == 4
         T = 2 * 8 * 8
         assert lib.fcd_conv_wino_ws_bytes(ctypes.byref(wide), 0) == 36 * (256 // 32) * T * 32 * 4 + 36 * 512 * T * 4 + 256
-        assert lib.fcd_conv_wino_filter_elems(512, 256, 0, 4) == 36 * 512 * 256
-        assert lib.fcd_conv_wino_filter_elems(512, 256, 1, 2) == 16 * 256 * 512
+        assert lib.fcd_conv_wino_filter_elems(512, 256, 0, 4) == 36 * 512 * 256 * 5 // 2     # fp32 U + three bf16 planes
+        assert lib.fcd_conv_wino_filter_elems(512, 256, 1, 2) == 16 * 256 * 512 * 5 // 2
         for d in (_lib.ConvDesc(2, 64, 32, 32, 64, 3, 3, 1, 1, 32, 32),        # 64 GEMM rows
                   _lib.ConvDesc(2, 256, 32, 32, 512, 3, 3, 2, 1, 16, 16),      # stride 2
                   _lib.ConvDesc(2, 256, 32, 32, 512, 1, 1, 1, 0, 32, 32),      # 1x1
