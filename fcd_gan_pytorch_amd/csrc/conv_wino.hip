@@ -688,11 +688,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void wino_gem
   }
   const int mt = (int)(v % (unsigned)a.m_tiles), nt = (int)(v / (unsigned)a.m_tiles);
   const int m0 = mt * BM, n0 = nt * BN;
-  const int Q = a.Kc / KC;
+  const int q_all = a.Kc / KC;
+  const int q_beg = (int)blockIdx.z * a.stages_per_split;      // split of the reduction (weight gradient)
+  const int Q = min(a.stages_per_split, q_all - q_beg);
   const int b_first = (int)blockIdx.y * a.xb;
   const int nb = min(a.xb, a.batches - b_first);
-  const unsigned short* Ab = a.As + (size_t)b_first * a.a_batch + (size_t)m0 * a.a_ld;
-  const float* Bb = a.B + (size_t)b_first * a.b_batch + (size_t)n0 * a.b_ld;
+  const unsigned short* Ab = a.As + (size_t)b_first * a.a_batch + (size_t)q_beg * KC + (size_t)m0 * a.a_ld;
+  const float* Bb = a.B + (size_t)b_first * a.b_batch + (size_t)q_beg * a.b_adv + (size_t)n0 * a.b_ld;
 
   // A slab in LDS: unit u = ((plane * 2 + half) * BM + row) * 2 + pj, 32-B row pitch.  A 16-lane ds_read_b128 group
   // ({0-3,12-15,20-27}, {4-11,16-19,28-31}) covers 16 distinct 16-B slots iff rows 16..31 take the other unit parity.
@@ -814,7 +816,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void wino_gem
     }
     int ldc = a.N;
     asm volatile("" : "+s"(ldc));
-    float* Cb = a.C + (size_t)(b_first + cb) * a.M * ldc;
+    float* Cb = a.C + ((size_t)blockIdx.z * a.batches + (b_first + cb)) * a.M * ldc;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1235,8 +1237,15 @@ extern "C" int fcd_conv_wino_split_set(int on) {
 
 static void wino_gemm_launch(WinoGemmArgs ga, int batches, int splits, hipStream_t st) {
   int cfg = wino_gemm_cfg();
-  if (ga.As && splits == 1 && ga.M > 64 && wino_split()) {
+  if (ga.As && ga.M > 64 && wino_split()) {
     ga.batches = batches;
+    if (splits > 1) {          // weight gradient: split reduction, one transform position per workgroup
+      ga.m_tiles = cdiv(ga.M, 128); ga.n_tiles = cdiv(ga.N, 128);
+      ga.xb = 1;
+      hipLaunchKernelGGL((wino_gemm_split_kernel<2, 2>), dim3((unsigned)(ga.m_tiles * ga.n_tiles), (unsigned)batches, (unsigned)splits),
+                         dim3(256), 0, st, ga);
+      return;
+    }
     // FCD_WINO_SPLIT_BIG: 0 = 128 x 128 tiles only; 1 (default) = 256 x 256 two-stage kernel for GEMMs with >= 256
     // rows and enough tiles to fill the chip; 2 = ... for every GEMM with >= 256 rows (tests); 4 / 5 = the same two
     // policies with the ping-pong kernel (measured slower: DESIGN.md)
@@ -1648,6 +1657,7 @@ struct WinoWgArgs {
   const float* mask;     // dy only: ReLU output of the layer (NULL: none)
   float* dst;            // [36][ch][Tpad]
   float* psum;           // dy only: [gridDim.x][ch] per-block channel sums (NULL: none)
+  unsigned short* planes;  // dy only, split GEMM: the three bf16 parts [3][36][ch][Tpad] INSTEAD of dst (NULL: fp32 dst)
   int N, CH, H, W, TH, TW;
   long long T, Tpad;
 };
@@ -1742,9 +1752,14 @@ __global__ __launch_bounds__(256) void wino_wg_dy_kernel(WinoWgArgs a) {
   if (t >= a.Tpad) return;
   float* wout = a.dst + (size_t)k * a.Tpad + t;
   const size_t xs = (size_t)a.CH * a.Tpad;
+  unsigned short* pout = a.planes ? a.planes + (size_t)k * a.Tpad + t : nullptr;
+  const size_t ps = 36 * xs;
   if (!live) {
 #pragma unroll
-    for (int i = 0; i < A * A; ++i) wout[(size_t)i * xs] = 0.f;
+    for (int i = 0; i < A * A; ++i) {
+      if (pout) { pout[(size_t)i * xs] = 0; pout[ps + (size_t)i * xs] = 0; pout[2 * ps + (size_t)i * xs] = 0; }
+      else wout[(size_t)i * xs] = 0.f;
+    }
     return;
   }
   float t1[A][4];   // A dY : A[q][i] = AT(i, q)
@@ -1766,7 +1781,17 @@ __global__ __launch_bounds__(256) void wino_wg_dy_kernel(WinoWgArgs a) {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         if (WinoMat<4>::AT(j, p2) != 0.f) s += t1[q][j] * WinoMat<4>::AT(j, p2);
-      wout[(size_t)(q * A + p2) * xs] = s;
+      const size_t o = (size_t)(q * A + p2) * xs;
+      if (pout) {      // exact three-way split, as wino_filter_kernel does for U
+        const unsigned short h = bf16_rn_bits(s);
+        const float r = s - __uint_as_float((unsigned)h << 16);
+        const unsigned short m = bf16_rn_bits(r);
+        pout[o] = h;
+        pout[ps + o] = m;
+        pout[2 * ps + o] = bf16_rn_bits(r - __uint_as_float((unsigned)m << 16));
+      } else {
+        wout[o] = s;
+      }
     }
 }
 
@@ -1870,7 +1895,7 @@ int fcd_wino_wgrad_plan(const fcd_conv_desc* d, WinoWgPlan* pl) {
   if (splits < 1) splits = 1;
   pl->sps = cdiv(pl->stages, splits);
   pl->splits = cdiv(pl->stages, pl->sps);
-  pl->w_bytes = (size_t)36 * d->K * pl->Tpad * sizeof(float);
+  pl->w_bytes = (size_t)36 * d->K * pl->Tpad * 6;      // fp32, or three bf16 planes for the split GEMM
   pl->v_bytes = (size_t)36 * d->C * pl->Tpad * sizeof(float);
   pl->du_bytes = (size_t)pl->splits * 36 * d->K * d->C * sizeof(float);
   pl->psum_bytes = (size_t)cdiv64(pl->Tpad, 256) * d->K * sizeof(float);
@@ -1896,9 +1921,10 @@ int fcd_wino_wgrad_run(const fcd_conv_desc* d, const float* x, const float* dy, 
   float* dU = (float*)wsp; wsp += (pl.du_bytes + 255) & ~(size_t)255;
   float* psum = (float*)wsp;
   const unsigned tb = (unsigned)cdiv64(pl.Tpad, 256);
+  const bool split = wino_split() != 0;      // dY~ written as three bf16 planes, GEMM on the bf16 matrix pipe
   {
     FcdProfScope p1(FCD_K_WINO_XFORM, st, 0.0,
-                    4.0 * ((double)d->N * d->C * d->H * d->W + (double)d->N * d->K * d->P * d->Q) + (double)pl.w_bytes +
+                    4.0 * ((double)d->N * d->C * d->H * d->W + (double)d->N * d->K * d->P * d->Q) + (double)pl.w_bytes / 6 * (split ? 6 : 4) +
                         (double)pl.v_bytes, fcd_prof_tag_desc("wgrad_in", d));
     WinoWgArgs ia;
     memset(&ia, 0, sizeof(ia));
@@ -1907,12 +1933,14 @@ int fcd_wino_wgrad_run(const fcd_conv_desc* d, const float* x, const float* dy, 
     hipLaunchKernelGGL(wino_wg_input_kernel, dim3(tb, (unsigned)d->C), dim3(256), 0, st, ia);
     WinoWgArgs ya = ia;
     ya.src = dy; ya.mask = relu_out; ya.dst = Wb; ya.CH = d->K; ya.psum = db ? psum : nullptr;
+    ya.planes = split ? (unsigned short*)Wb : nullptr;
     hipLaunchKernelGGL(wino_wg_dy_kernel, dim3(tb, (unsigned)d->K), dim3(256), 0, st, ya);
     if (db) hipLaunchKernelGGL(wino_psum_fin_kernel, dim3((unsigned)d->K), dim3(256), 0, st, (const float*)psum, db, d->K, (int)tb);
   }
   WinoGemmArgs ga;
   memset(&ga, 0, sizeof(ga));
   ga.A = Wb; ga.B = Vb; ga.C = dU;
+  if (split) { ga.As = (const unsigned short*)Wb; ga.as_plane = 36LL * d->K * pl.Tpad; }
   ga.M = d->K; ga.N = d->C; ga.Kc = (int)pl.Tpad;
   ga.m_tiles = cdiv(d->K, 128); ga.n_tiles = cdiv(d->C, 128);
   ga.xcd_remap = 0;
@@ -1920,8 +1948,8 @@ int fcd_wino_wgrad_run(const fcd_conv_desc* d, const float* x, const float* dy, 
   ga.b_ld = pl.Tpad; ga.b_adv = 32; ga.b_batch = (long long)d->C * pl.Tpad;
   ga.stages_per_split = pl.sps;
   {
-    FcdProfScope p2(FCD_K_WINO_GEMM, st, 2.0 * 36 * d->K * (double)d->C * (double)pl.Tpad,
-                    (double)pl.w_bytes + (double)pl.v_bytes + (double)pl.du_bytes,
+    FcdProfScope p2(split ? FCD_K_WINO_GEMM_SPLIT : FCD_K_WINO_GEMM, st, 2.0 * 36 * d->K * (double)d->C * (double)pl.Tpad,
+                    (double)pl.w_bytes / 6 * (split ? 6 : 4) + (double)pl.v_bytes + (double)pl.du_bytes,
                     fcd_prof_tagf("wgrad M=%d N=%d Kc=%lld batch=36 splits=%d img=%dx%dx%d", d->K, d->C, pl.Tpad, pl.splits,
                                   d->N, d->H, d->W));
     wino_gemm_launch(ga, 36, pl.splits, st);
