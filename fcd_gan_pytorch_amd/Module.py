@@ -52,6 +52,16 @@ class DoubleConv(nn.Module):
         x = ops.bn_act(_conv(s[0], x), s[1], ops.ACT_RELU, groups=groups)
         return ops.bn_act(_conv(s[3], x), s[4], ops.ACT_RELU, groups=groups)
 
+    def forward_pair_cat(self, f2n, up):
+        """``forward(torch.cat([f2n[:n], f2n[n:], up], dim=1))`` with the first convolution reading the three tensors in
+        place (``ops.conv3x3_pair_cat``; caller checked ``ops.conv3x3_pair_cat_ok``)."""
+        s = self.double_conv
+        if not self.training and not torch.is_grad_enabled():
+            (w0, b0), (w1, b1) = self._folded_params()
+            return ops.conv2d(ops.conv3x3_pair_cat(f2n, up, w0, b0, relu=True), w1, b1, 1, 1, relu=True)
+        x = ops.bn_act(ops.conv3x3_pair_cat(f2n, up, s[0].weight, s[0].bias), s[1], ops.ACT_RELU)
+        return ops.bn_act(_conv(s[3], x), s[4], ops.ACT_RELU)
+
     def _folded_params(self):
         s = self.double_conv
         # key: storage + version of every tensor that enters the fold (load_state_dict / in-place
@@ -116,6 +126,23 @@ class Up(nn.Module):
         if dy or dx:
             x1 = F.pad(x1, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])
         return self.conv(torch.cat([x2, x1], dim=1))
+
+    def forward_pair(self, x1, f2n):
+        """``forward(x1, cat([f2n[:n], f2n[n:]], dim=1))`` for the Segmentor, whose skip tensor is the channel pair of the two
+        temporal branches living in ONE (2N, C, h, w) batch (reference Module.py:116-132): neither concatenation is
+        materialised when the first convolution takes tensor lists; otherwise this is ``forward``."""
+        n = x1.shape[0]
+        if self.bilinear:
+            u = ops.upsample2x(x1)
+        else:
+            u = ops.conv_transpose2x2(x1, self.up.weight, self.up.bias)
+        w0 = self.conv.double_conv[0].weight
+        if tuple(u.shape[2:]) == tuple(f2n.shape[2:]) and ops.conv3x3_pair_cat_ok(f2n, u, w0):
+            return self.conv.forward_pair_cat(f2n, u)
+        dy, dx = f2n.shape[2] - u.shape[2], f2n.shape[3] - u.shape[3]
+        if dy or dx:
+            u = F.pad(u, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])
+        return self.conv(torch.cat([f2n[:n], f2n[n:], u], dim=1))
 
 
 class OutConv(nn.Module):
@@ -188,14 +215,16 @@ class Segmentor(nn.Module):
         return self._after_inc(f, n)
 
     def _after_inc(self, f, n):
-        skips = [self._pair(f, n)]
+        # f: both temporal branches in one (2N, C, h, w) batch; the reference's skip tensor is cat([branch1, branch2], 1)
+        # (Module.py:116-132) -- kept as the un-paired batch and read in place by the decoder's first convolutions
+        feats = [f]
         for stage in (self.down1, self.down2, self.down3, self.down4):
             f = stage(f, groups=2)
-            skips.append(self._pair(f, n))
-        x = self.up1(skips[4], skips[3])
-        x = self.up2(x, skips[2])
-        x = self.up3(x, skips[1])
-        x = self.up4(x, skips[0])
+            feats.append(f)
+        x = self.up1.forward_pair(self._pair(feats[4], n), feats[3])
+        x = self.up2.forward_pair(x, feats[2])
+        x = self.up3.forward_pair(x, feats[1])
+        x = self.up4.forward_pair(x, feats[0])
         return self.outc(x)
 
 

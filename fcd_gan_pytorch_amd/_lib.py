@@ -58,6 +58,10 @@ _SIGS = {
     'fcd_conv_wino_plan': (c_int, [POINTER(ConvDesc), c_int]),
     'fcd_conv_wino_set': (c_int, [c_int]),
     'fcd_conv_wino_split_set': (c_int, [c_int]),
+    'fcd_conv_wino_cat_ok': (c_int, [P]),
+    'fcd_conv2d_fwd_wino_cat': (c_int, [P, P, P, c_int, P, P, P, c_int, P, c_size_t, P]),
+    'fcd_conv2d_bwd_data_wino_cat': (c_int, [P, P, P, P, P, P, c_int, P, c_size_t, P]),
+    'fcd_conv2d_bwd_weight_bias_cat': (c_int, [P, P, P, c_int, P, P, P, P, P, c_size_t, P]),
     'fcd_conv_wino_ws_bytes': (c_size_t, [POINTER(ConvDesc), c_int]),
     'fcd_conv_wino_filter_elems': (c_int64, [c_int, c_int, c_int, c_int]),
     'fcd_conv_wino_pack': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),

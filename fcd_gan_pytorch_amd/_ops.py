@@ -230,6 +230,90 @@ class _Conv2d(torch.autograd.Function):
         return dx, dw, db, None, None, None
 
 
+def _ptr_list(ptrs):
+    return (ctypes.c_void_p * len(ptrs))(*ptrs)
+
+
+class _ConvPairCat(torch.autograd.Function):
+    """3x3 / stride-1 / pad-1 convolution of ``cat([f2n[:n], f2n[n:], up], dim=1)`` -- the U-Net decoder input (reference
+    Module.py:78 fed with the Siamese skip pair of Module.py:116-132) -- WITHOUT the concatenated tensor: the F(4x4)
+    input transform reads the three tensors chunk by chunk, the data gradient's output transform writes ``df2n`` (both
+    temporal halves in place) and ``dup``, the weight-gradient transform reads them again.  Same kernels and summation
+    order as ``conv2d(torch.cat(...))`` => bit-identical results."""
+
+    @staticmethod
+    def forward(ctx, f2n, up, weight, bias, relu):
+        f2n, up = _dev(f2n, 'skip pair'), _dev(up, 'upsampled input')
+        n, cu, H, W = up.shape
+        c = f2n.shape[1]
+        d = _desc((n, 2 * c + cu, H, W), weight.shape, 1, 1)
+        y = torch.empty((d.N, d.K, d.P, d.Q), dtype=torch.float32, device=up.device)
+        half = n * c * H * W * 4
+        srcs = _ptr_list([f2n.data_ptr(), f2n.data_ptr() + half, up.data_ptr()])
+        chans = (ctypes.c_int * 3)(c, c, cu)
+        ws = _ws(lib.fcd_conv_wino_ws_bytes(ctypes.byref(d), 0), up.device)
+        b = _dev(bias, 'conv bias') if bias is not None else None
+        check(lib.fcd_conv2d_fwd_wino_cat(ctypes.byref(d), srcs, chans, 3, _p(wino_weight(weight, 0, 4)), _p(b), _p(y),
+                                          1 if relu else 0, _p(ws), ws.numel(), _stream()), 'fcd_conv2d_fwd_wino_cat')
+        ctx.save_for_backward(f2n if weight.requires_grad else None, up if weight.requires_grad else None, weight,
+                              y if relu else None)
+        ctx.geom = (tuple(f2n.shape), tuple(up.shape), bias is not None)
+        ctx.bias_param = bias
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        f2n, up, weight, yrelu = ctx.saved_tensors
+        fshape, ushape, has_bias = ctx.geom
+        dy = _dev(dy, 'conv grad')
+        n, cu, H, W = ushape
+        c = fshape[1]
+        d = _desc((n, 2 * c + cu, H, W), weight.shape, 1, 1)
+        chans = (ctypes.c_int * 3)(c, c, cu)
+        half = n * c * H * W * 4
+        df = du = dw = db = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            df = torch.empty(fshape, dtype=torch.float32, device=dy.device)
+            du = torch.empty(ushape, dtype=torch.float32, device=dy.device)
+            ws = _ws(lib.fcd_conv_wino_ws_bytes(ctypes.byref(d), 1), dy.device)
+            check(lib.fcd_conv2d_bwd_data_wino_cat(ctypes.byref(d), _p(dy), _p(yrelu), _p(wino_weight(weight, 1, 4)),
+                                                   _ptr_list([df.data_ptr(), df.data_ptr() + half, du.data_ptr()]), chans, 3,
+                                                   _p(ws), ws.numel(), _stream()), 'fcd_conv2d_bwd_data_wino_cat')
+        want_db = has_bias and ctx.needs_input_grad[3]
+        if ctx.needs_input_grad[2]:
+            dw = _grad_out(weight, weight.shape, dy.device)
+            if want_db:
+                db = _grad_out(ctx.bias_param, (d.K,), dy.device)
+            ws = _ws(lib.fcd_conv2d_bwd_weight_ws_bytes(ctypes.byref(d)), dy.device)
+            check(lib.fcd_conv2d_bwd_weight_bias_cat(ctypes.byref(d), _ptr_list([f2n.data_ptr(), f2n.data_ptr() + half,
+                                                                                  up.data_ptr()]), chans, 3, _p(dy), _p(yrelu),
+                                                     _p(dw), _p(db), _p(ws), ws.numel(), _stream()),
+                  'fcd_conv2d_bwd_weight_bias_cat')
+        elif want_db:
+            db = _channel_sum(dy, yrelu, d.N, d.K, d.P * d.Q)
+        return df, du, dw, db, None
+
+
+def conv3x3_pair_cat_ok(f2n, up, weight):
+    """True when :func:`conv3x3_pair_cat` can run this layer without the concatenated copy."""
+    if f2n.dim() != 4 or up.dim() != 4 or tuple(weight.shape[2:]) != (3, 3) or os.environ.get('FCD_PAIR_CAT') == '0':
+        return False
+    n, cu, H, W = up.shape
+    c = f2n.shape[1]
+    if f2n.shape[0] != 2 * n or tuple(f2n.shape[2:]) != (H, W) or (c % 32) or (cu % 32) or weight.shape[1] != 2 * c + cu:
+        return False
+    if not (f2n.is_cuda and up.is_cuda and f2n.is_contiguous() and up.is_contiguous()):
+        return False
+    d = _desc((n, 2 * c + cu, H, W), weight.shape, 1, 1)
+    return bool(lib.fcd_conv_wino_cat_ok(ctypes.byref(d)))
+
+
+def conv3x3_pair_cat(f2n, up, weight, bias=None, relu=False):
+    """conv3x3(cat([f2n[:n], f2n[n:], up], dim=1)) (+bias, + fused ReLU) without building the concatenation; check with
+    :func:`conv3x3_pair_cat_ok` first."""
+    return _ConvPairCat.apply(f2n, up, weight, bias, bool(relu))
+
+
 def conv2d(x, weight, bias=None, stride=1, padding=0, relu=False):
     """conv2d (+bias) (+fused ReLU epilogue when ``relu``)."""
     return _Conv2d.apply(x, weight, bias, int(stride), int(padding), bool(relu))

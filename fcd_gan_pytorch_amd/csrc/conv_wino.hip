@@ -124,6 +124,21 @@ __global__ void wino_filter_kernel(const float* __restrict__ w, float* __restric
 // The raw (m+2)-row strip is staged in LDS with coalesced row reads (source gating applied here),
 // then every thread transforms (tile, channel) items with the channel fastest across lanes, so
 // that each V row [t][32 ch] is written as one 128-B segment.
+// Virtual channel concatenation (the U-Net decoder's cat([branch-1 skip, branch-2 skip, upsampled], dim=1)): up to three
+// (N, c[i], H, W) tensors stand for ONE (N, sum c[i], H, W) operand, c[i] % 32 == 0.  n == 0: plain single tensor.
+struct WinoCat {
+  const float* p[3];
+  int c[3];
+  int n;
+};
+// tensor and its channel count holding concatenated channel ch; ch becomes the channel inside that tensor
+__device__ __forceinline__ const float* wino_cat_pick(const WinoCat& k, int& ch, int& chans) {
+  int s = 0;
+  if (k.n > 1 && ch >= k.c[0]) { ch -= k.c[0]; s = 1; if (k.n > 2 && ch >= k.c[1]) { ch -= k.c[1]; s = 2; } }
+  chans = k.c[s];
+  return k.p[s];
+}
+
 struct WinoInArgs {
   const float* x;             // SRC 0/1: (N, C, H, W); SRC 2: pooled gradient (N, C, Hp, Wp)
   const float* mask;          // SRC 1: ReLU output, same shape as x
@@ -133,6 +148,7 @@ struct WinoInArgs {
   long long T;
   int exp;                    // diagnostics (FCD_WINO_IN_EXP): 2 = no V stores, 4 = no source loads
   int xcd;                    // 1: blocks renumbered so that each XCD (own L2) walks a contiguous range
+  WinoCat cat;                // plain source of the rolling kernel only: x = cat(cat.p[...]) (cat.n > 0)
 };
 
 // Workgroups are handed to the 8 XCDs round-robin in launch order, so neighbouring strips of one plane --
@@ -323,7 +339,13 @@ __global__ __launch_bounds__(256) void wino_input_roll_kernel(WinoInArgs a, int 
   const int n = bz / a.Q, q = bz % a.Q;
   const int iw0 = tx0 * MM - 1;
   const int plane = (SRC == 2) ? a.Hp * a.Wp : a.H * a.W;
-  const size_t img = ((size_t)n * a.C + (size_t)q * 32) * plane;
+  const float* xsrc = a.x;
+  size_t img = ((size_t)n * a.C + (size_t)q * 32) * plane;
+  if (SRC == 0 && a.cat.n > 0) {          // chunk q lies in ONE of the concatenated tensors (32 | their channel counts)
+    int ch = q * 32, chans;
+    xsrc = wino_cat_pick(a.cat, ch, chans);
+    img = ((size_t)n * chans + ch) * plane;
+  }
   const int ty_beg = by * roll * TRB, ty_end = min(a.TH, ty_beg + roll * TRB);      // tile rows [ty_beg, ty_end), TRB per strip
 
   f32x4 pre[NV], msk[SRC == 1 ? NV : 1];
@@ -355,7 +377,7 @@ __global__ __launch_bounds__(256) void wino_input_roll_kernel(WinoInArgs a, int 
         v[2] = __uint_as_float(cc);
       } else if (idx < 32 * RH * V4 && q * 32 + c < a.C && ih >= 0 && ih < a.H && iw < a.W) {
         const size_t off = img + (size_t)c * plane + (size_t)ih * a.W + iw;
-        v = *(const f32x4*)(a.x + off);
+        v = *(const f32x4*)(xsrc + off);
         if (SRC == 1) m = *(const f32x4*)(a.mask + off);
       }
       pre[k] = v;
@@ -378,7 +400,7 @@ __global__ __launch_bounds__(256) void wino_input_roll_kernel(WinoInArgs a, int 
           }
         } else {
           const size_t off = img + (size_t)c * plane + (size_t)ih * a.W + iw;
-          v = a.x[off];
+          v = xsrc[off];
           if (SRC == 1) m = a.mask[off];
         }
       }
@@ -1299,6 +1321,7 @@ struct WinoOutArgs {
   unsigned char* code;
   int K, P, Q, TH, TW, relu;
   long long T;
+  WinoCat cat;          // data gradient of a virtually concatenated input: channel k of dx goes to its own tensor (cat.n > 0)
 };
 
 template <int MM>
@@ -1372,6 +1395,11 @@ __global__ __launch_bounds__(256) void wino_output_kernel(WinoOutArgs a) {
     return;
   }
   float* yo = a.y + (((size_t)n * a.K + k) * a.P + p0) * a.Q + q0;
+  if (a.cat.n > 0) {
+    int ch = k, chans;
+    float* base = const_cast<float*>(wino_cat_pick(a.cat, ch, chans));
+    yo = base + (((size_t)n * chans + ch) * a.P + p0) * a.Q + q0;
+  }
   const bool vec = (MM == 4) ? ((a.Q & 3) == 0) : ((a.Q & 1) == 0);
 #pragma unroll
   for (int i = 0; i < MM; ++i) {
@@ -1538,15 +1566,25 @@ static void wino_launch_input(const WinoInArgs& ia, int src, hipStream_t st) {
   else wino_launch_input_cfg<MM, 4, NT / 4>(ia, src, st);
 }
 
+// a virtually concatenated input needs the rolling input kernel (the only one that takes source lists): m = 4, W % 4 == 0,
+// map at least two strips high and more than 4 tiles wide
+static bool wino_cat_input_ok(const WinoPlan& pl, int W) {
+  if (pl.m != 4 || (W & 3) != 0 || pl.TW <= 4) return false;
+  const int trb = pl.TW > 8 ? 1 : 2;
+  return cdiv(pl.TH, trb) >= 2;
+}
+
 // shared by forward and data gradient: src tensor (in_ch channels, H x W logical extent) -> out tensor
 // (rows channels, H x W)
 static int wino_run(const WinoPlan& pl, int N, int in_ch, int H, int W, const float* src, const float* mask,
                     const unsigned char* code_in, int Hp, int Wp, const float* U, const float* bias, int relu, float* y,
-                    float* pool_y, unsigned char* code_out, void* ws, hipStream_t st) {
+                    float* pool_y, unsigned char* code_out, void* ws, hipStream_t st,
+                    const WinoCat* in_cat = nullptr, const WinoCat* out_cat = nullptr) {
   float* V = (float*)ws;
   float* Mb = (float*)((char*)ws + ((pl.v_bytes + 255) & ~(size_t)255));
   WinoInArgs ia;
   memset(&ia, 0, sizeof(ia));
+  if (in_cat) ia.cat = *in_cat;
   ia.x = src; ia.mask = mask; ia.code = code_in; ia.V = V;
   ia.N = N; ia.C = in_ch; ia.H = H; ia.W = W; ia.Hp = Hp; ia.Wp = Wp;
   ia.TH = pl.TH; ia.TW = pl.TW; ia.Q = pl.Q; ia.T = pl.T;
@@ -1585,6 +1623,7 @@ static int wino_run(const WinoPlan& pl, int N, int in_ch, int H, int W, const fl
 
   WinoOutArgs oa;
   memset(&oa, 0, sizeof(oa));
+  if (out_cat) oa.cat = *out_cat;
   oa.Mb = Mb; oa.bias = bias; oa.y = y; oa.pool_y = pool_y; oa.code = code_out;
   oa.K = pl.rows; oa.P = H; oa.Q = W; oa.TH = pl.TH; oa.TW = pl.TW; oa.relu = relu; oa.T = pl.T;
   dim3 og((unsigned)cdiv64(pl.T, 256), (unsigned)pl.rows);
@@ -1658,6 +1697,7 @@ struct WinoWgArgs {
   float* dst;            // [36][ch][Tpad]
   float* psum;           // dy only: [gridDim.x][ch] per-block channel sums (NULL: none)
   unsigned short* planes;  // dy only, split GEMM: the three bf16 parts [3][36][ch][Tpad] INSTEAD of dst (NULL: fp32 dst)
+  WinoCat cat;             // x only: src = cat(cat.p[...]) (cat.n > 0)
   int N, CH, H, W, TH, TW;
   long long T, Tpad;
 };
@@ -1679,6 +1719,11 @@ __global__ __launch_bounds__(256) void wino_wg_input_kernel(WinoWgArgs a) {
   const long long r2 = t / a.TW;
   const int ty = (int)(r2 % a.TH), n = (int)(r2 / a.TH);
   const float* xp = a.src + ((size_t)n * a.CH + c) * a.H * a.W;
+  if (a.cat.n > 0) {
+    int ch = c, chans;
+    const float* base = wino_cat_pick(a.cat, ch, chans);
+    xp = base + ((size_t)n * chans + ch) * a.H * a.W;
+  }
   const int ih0 = ty * 4 - 1, iw0 = tx * 4 - 1;
   float d[A][A];
 #pragma unroll
@@ -1909,8 +1954,14 @@ size_t fcd_wino_wgrad_ws_bytes(const fcd_conv_desc* d) {
 }
 
 // called by fcd_conv2d_bwd_weight_bias (conv_wgrad.hip) when the plan says so; ws holds fcd_wino_wgrad_ws_bytes
+static int wino_wgrad_run_impl(const fcd_conv_desc* d, const float* x, const WinoCat* xcat, const float* dy,
+                               const float* relu_out, float* dw, float* db, void* ws, hipStream_t st);
 int fcd_wino_wgrad_run(const fcd_conv_desc* d, const float* x, const float* dy, const float* relu_out, float* dw,
                        float* db, void* ws, hipStream_t st) {
+  return wino_wgrad_run_impl(d, x, nullptr, dy, relu_out, dw, db, ws, st);
+}
+static int wino_wgrad_run_impl(const fcd_conv_desc* d, const float* x, const WinoCat* xcat, const float* dy,
+                               const float* relu_out, float* dw, float* db, void* ws, hipStream_t st) {
   WinoWgPlan pl;
   if (!fcd_wino_wgrad_plan(d, &pl)) return 1;
   FcdProfScope pw(FCD_K_WGRAD_WINO, st, 2.0 * d->N * d->K * (double)d->P * d->Q * d->C * 9, 0.0,
@@ -1928,10 +1979,12 @@ int fcd_wino_wgrad_run(const fcd_conv_desc* d, const float* x, const float* dy, 
                         (double)pl.v_bytes, fcd_prof_tag_desc("wgrad_in", d));
     WinoWgArgs ia;
     memset(&ia, 0, sizeof(ia));
+    if (xcat) ia.cat = *xcat;
     ia.src = x; ia.dst = Vb; ia.N = d->N; ia.CH = d->C; ia.H = d->H; ia.W = d->W;
     ia.TH = pl.TH; ia.TW = pl.TW; ia.T = pl.T; ia.Tpad = pl.Tpad;
     hipLaunchKernelGGL(wino_wg_input_kernel, dim3(tb, (unsigned)d->C), dim3(256), 0, st, ia);
     WinoWgArgs ya = ia;
+    memset(&ya.cat, 0, sizeof(ya.cat));
     ya.src = dy; ya.mask = relu_out; ya.dst = Wb; ya.CH = d->K; ya.psum = db ? psum : nullptr;
     ya.planes = split ? (unsigned short*)Wb : nullptr;
     hipLaunchKernelGGL(wino_wg_dy_kernel, dim3(tb, (unsigned)d->K), dim3(256), 0, st, ya);
@@ -1967,4 +2020,91 @@ int fcd_wino_wgrad_run(const fcd_conv_desc* d, const float* x, const float* dy, 
                        (const float*)dU, dw, d->K, d->C, fin_splits);
   }
   return 0;
+}
+
+// =============================================================================================
+// Virtual channel concatenation: entry points
+static bool wino_cat_fill(WinoCat* k, const float* const* ptrs, const int* chans, int n, int total) {
+  memset(k, 0, sizeof(*k));
+  if (!ptrs || !chans || n < 1 || n > 3) return false;
+  int sum = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!ptrs[i] || chans[i] <= 0 || (chans[i] & 31)) return false;
+    k->p[i] = ptrs[i]; k->c[i] = chans[i]; sum += chans[i];
+  }
+  k->n = n;
+  return sum == total;
+}
+
+// 1 = forward, data gradient and weight gradient of this layer all run on kernels that take tensor lists
+extern "C" int fcd_conv_wino_cat_ok(const fcd_conv_desc* d) {
+  WinoPlan pf, pd;
+  WinoWgPlan pw;
+  if (!d || !wino_plan(d, 0, &pf) || !wino_plan(d, 1, &pd) || !fcd_wino_wgrad_plan(d, &pw)) return 0;
+  if (getenv("FCD_WINO_IN_ROLL") && atoi(getenv("FCD_WINO_IN_ROLL")) <= 1) return 0;
+  return wino_cat_input_ok(pf, d->W) ? 1 : 0;
+}
+
+extern "C" int fcd_conv2d_fwd_wino_cat(const fcd_conv_desc* d, const float* const* src, const int* chans, int nsrc,
+                                       const float* U, const float* bias, float* y, int fuse_relu, void* ws, size_t ws_bytes,
+                                       void* stream) {
+  FCD_CHECK_ARG(d && U && y, "fcd_conv2d_fwd_wino_cat: null pointer");
+  WinoCat cat;
+  FCD_CHECK_ARG(wino_cat_fill(&cat, src, chans, nsrc, d->C),
+                "fcd_conv2d_fwd_wino_cat: 1..3 tensors, channel counts multiples of 32 that add up to C");
+  FCD_CHECK_ARG(fcd_conv_wino_cat_ok(d), "fcd_conv2d_fwd_wino_cat: layer does not take tensor lists (fcd_conv_wino_cat_ok)");
+  WinoPlan pl;
+  wino_plan(d, 0, &pl);
+  if (!ws || ws_bytes < fcd_conv_wino_ws_bytes(d, 0)) {
+    fcd_set_error("fcd_conv2d_fwd_wino_cat: workspace %zu < %zu bytes", ws_bytes, fcd_conv_wino_ws_bytes(d, 0));
+    return FCD_ERR_WORKSPACE;
+  }
+  FcdProfScope prof(FCD_K_WINO_FWD, (hipStream_t)stream, conv_flops(d), wino_bytes(pl), fcd_prof_tag_desc("wino_fwd", d));
+  wino_run(pl, d->N, d->C, d->H, d->W, cat.p[0], nullptr, nullptr, 0, 0, U, bias, fuse_relu ? 1 : 0, y, nullptr, nullptr, ws,
+           (hipStream_t)stream, &cat, nullptr);
+  FCD_LAUNCH_CHECK("conv2d_fwd_wino_cat");
+  return FCD_OK;
+}
+
+extern "C" int fcd_conv2d_bwd_data_wino_cat(const fcd_conv_desc* d, const float* dy, const float* relu_out, const float* U,
+                                            float* const* dsrc, const int* chans, int nsrc, void* ws, size_t ws_bytes,
+                                            void* stream) {
+  FCD_CHECK_ARG(d && dy && U, "fcd_conv2d_bwd_data_wino_cat: null pointer");
+  WinoCat cat;
+  FCD_CHECK_ARG(wino_cat_fill(&cat, (const float* const*)dsrc, chans, nsrc, d->C),
+                "fcd_conv2d_bwd_data_wino_cat: 1..3 tensors, channel counts multiples of 32 that add up to C");
+  WinoPlan pl;
+  FCD_CHECK_ARG(wino_plan(d, 1, &pl), "fcd_conv2d_bwd_data_wino_cat: layer is not planned for the Winograd path");
+  if (!ws || ws_bytes < fcd_conv_wino_ws_bytes(d, 1)) {
+    fcd_set_error("fcd_conv2d_bwd_data_wino_cat: workspace %zu < %zu bytes", ws_bytes, fcd_conv_wino_ws_bytes(d, 1));
+    return FCD_ERR_WORKSPACE;
+  }
+  FcdProfScope prof(FCD_K_WINO_DGRAD, (hipStream_t)stream, conv_flops(d), wino_bytes(pl), fcd_prof_tag_desc("wino_dgrad", d));
+  wino_run(pl, d->N, d->K, d->P, d->Q, dy, relu_out, nullptr, 0, 0, U, nullptr, 0, const_cast<float*>(cat.p[0]), nullptr, nullptr,
+           ws, (hipStream_t)stream, nullptr, &cat);
+  FCD_LAUNCH_CHECK("conv2d_bwd_data_wino_cat");
+  return FCD_OK;
+}
+
+
+// weight (+ bias) gradient of a layer whose input is the virtual concatenation of src[...]
+extern "C" int fcd_conv2d_bwd_weight_bias_cat(const fcd_conv_desc* d, const float* const* src, const int* chans, int nsrc,
+                                              const float* dy, const float* relu_out, float* dw, float* db, void* ws,
+                                              size_t ws_bytes, void* stream) {
+  FCD_CHECK_ARG(d && dy && dw, "fcd_conv2d_bwd_weight_bias_cat: null pointer");
+  WinoCat cat;
+  FCD_CHECK_ARG(wino_cat_fill(&cat, src, chans, nsrc, d->C),
+                "fcd_conv2d_bwd_weight_bias_cat: 1..3 tensors, channel counts multiples of 32 that add up to C");
+  const size_t need = fcd_wino_wgrad_ws_bytes(d);
+  FCD_CHECK_ARG(need > 0, "fcd_conv2d_bwd_weight_bias_cat: layer does not take the Winograd weight-gradient form");
+  if (!ws || ws_bytes < need) {
+    fcd_set_error("fcd_conv2d_bwd_weight_bias_cat: workspace %zu < %zu bytes", ws_bytes, need);
+    return FCD_ERR_WORKSPACE;
+  }
+  FcdProfScope prof(FCD_K_CONV_WGRAD, (hipStream_t)stream, conv_flops(d),
+                    4.0 * ((double)d->N * d->C * d->H * d->W + (double)d->N * d->K * d->P * d->Q + (double)d->K * d->C * 9),
+                    fcd_prof_tag_desc("wgrad", d));
+  wino_wgrad_run_impl(d, cat.p[0], &cat, dy, relu_out, dw, db, ws, (hipStream_t)stream);
+  FCD_LAUNCH_CHECK("conv2d_bwd_weight_bias_cat");
+  return FCD_OK;
 }

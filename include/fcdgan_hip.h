@@ -101,6 +101,20 @@ int fcd_conv_wino_pack(const float* w, float* U, int K, int C, int mode, int m, 
 int fcd_conv2d_fwd_wino(const fcd_conv_desc* d, const float* x, const float* U, const float* bias, float* y,
                         int fuse_relu, float* pool_y, unsigned char* code, void* ws, size_t ws_bytes,
                         void* stream);
+/* ---- virtual channel concatenation (the U-Net decoder: Module.py:78 `torch.cat([x2, x1], dim=1)` feeding DoubleConv, and the
+ * Siamese skip pairs Module.py:116-132) -- the convolution reads / its data gradient writes up to three (N, chans[i], H, W)
+ * tensors as if they were ONE (N, C, H, W) tensor; no concatenated copy exists.  chans[i] % 32 == 0, sum == d->C.
+ * fcd_conv_wino_cat_ok(): 1 when forward, data gradient and weight gradient of the layer all take tensor lists (wide 3x3
+ * layers on the F(4x4) path); otherwise concatenate and use the plain calls.  Workspaces as for the plain calls
+ * (fcd_conv_wino_ws_bytes / fcd_conv2d_bwd_weight_ws_bytes). */
+int fcd_conv_wino_cat_ok(const fcd_conv_desc* d);
+int fcd_conv2d_fwd_wino_cat(const fcd_conv_desc* d, const float* const* src, const int* chans, int nsrc, const float* U,
+                            const float* bias, float* y, int fuse_relu, void* ws, size_t ws_bytes, void* stream);
+int fcd_conv2d_bwd_data_wino_cat(const fcd_conv_desc* d, const float* dy, const float* relu_out, const float* U,
+                                 float* const* dsrc, const int* chans, int nsrc, void* ws, size_t ws_bytes, void* stream);
+int fcd_conv2d_bwd_weight_bias_cat(const fcd_conv_desc* d, const float* const* src, const int* chans, int nsrc,
+                                   const float* dy, const float* relu_out, float* dw, float* db, void* ws, size_t ws_bytes,
+                                   void* stream);
 /* dx from dy, dy * [relu_out > 0] (relu_out != NULL) or the pooled gradient routed by pool_code */
 int fcd_conv2d_bwd_data_wino(const fcd_conv_desc* d, const float* dy, const float* relu_out,
                              const unsigned char* pool_code, const float* U, float* dx, void* ws,

@@ -423,6 +423,35 @@ def test_wino_gemm_matrix_pipes(case):
             assert err[mode][q] <= 1.15 * err[0][q] + 1e-8, (mode, q, err)
 
 
+@pytest.mark.parametrize('case', [(2, 128, 32, 32, 256, 256), (1, 64, 40, 72, 128, 128), (3, 256, 16, 32, 512, 384)],
+                         ids=lambda c: 'x'.join(map(str, c)))
+@pytest.mark.parametrize('relu', [False, True])
+def test_conv3x3_pair_cat_equals_conv_of_concatenation(case, relu):
+    """Decoder convolution reading [branch-1 skip | branch-2 skip | upsampled] in place (ops.conv3x3_pair_cat) vs the same
+    layer on torch.cat([...], dim=1): outputs, both input gradients, filter and bias gradients -- bit for bit (same
+    kernels, same summation order; only the addressing differs)."""
+    ops = _ops()
+    n, c, H, W, cu, K = case
+    f = rnd(2 * n, c, H, W, seed=41).cuda()
+    u = rnd(n, cu, H, W, seed=42).cuda()
+    w = rnd(K, 2 * c + cu, 3, 3, seed=43, scale=(2.0 / ((2 * c + cu) * 9)) ** 0.5).cuda()
+    b = rnd(K, seed=44, scale=0.1).cuda()
+    g = rnd(n, K, H, W, seed=45).cuda()
+    assert ops.conv3x3_pair_cat_ok(f, u, w)
+    f1, u1, w1, b1 = (t.clone().requires_grad_(True) for t in (f, u, w, b))
+    y1 = ops.conv3x3_pair_cat(f1, u1, w1, b1, relu=relu)
+    y1.backward(g)
+    f2, u2, w2, b2 = (t.clone().requires_grad_(True) for t in (f, u, w, b))
+    y2 = ops.conv2d(torch.cat([f2[:n], f2[n:], u2], dim=1), w2, b2, 1, 1, relu=relu)
+    y2.backward(g)
+    assert torch.equal(y1, y2)
+    assert torch.equal(f1.grad, f2.grad) and torch.equal(u1.grad, u2.grad)
+    assert torch.equal(w1.grad, w2.grad) and torch.equal(b1.grad, b2.grad)
+    # layers off the F(4x4) path are refused (the caller concatenates)
+    assert not ops.conv3x3_pair_cat_ok(f[:, :16], u, w[:, :32 + cu])
+    assert not ops.conv3x3_pair_cat_ok(f[..., :2, :], u[..., :2, :], w)
+
+
 def test_conv_winograd_matches_direct_kernels():
     """Same layer through the direct MFMA kernel and both Winograd tile sizes."""
     ops = _ops()
