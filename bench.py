@@ -407,8 +407,8 @@ def main():
                            wg['ms'], wg['flops'], wg['launches'], 'algorithmic weight-gradient FLOPs (direct count)'),
             ]
             if wsplit['launches'] > 0:
-                e = mfma_entry('wino_gemm_split256_kernel / wino_gemm_split_kernel (batched GEMM of the Winograd F(4x4,3x3) path, forward + '
-                               'data-gradient launches, on the bf16 matrix pipe: every fp32 operand split exactly into three bf16 parts, six '
+                e = mfma_entry('wino_gemm_split256_kernel / wino_gemm_split_kernel (batched GEMM of the Winograd F(4x4,3x3) path, forward, '
+                               'data-gradient and weight-gradient launches, on the bf16 matrix pipe: every fp32 operand split exactly into three bf16 parts, six '
                                'partial products per multiply accumulated in fp32 -- fp32-equivalent results, tests/test_gpu_ops.py)',
                                wsplit['ms'], 6.0 * wsplit['flops'], wsplit['launches'],
                                'executed bf16 MFMA FLOPs = 6 x the fp32-equivalent GEMM FLOPs')
@@ -423,6 +423,7 @@ def main():
                                         'transform in one kernel; the 64-row 3x3 layers, forward + data gradient)', w2f['ms'] + w2d['ms'],
                                         (w2f['flops'] + w2d['flops']) * 16.0 / 36.0, w2f['launches'] + w2d['launches'],
                                         'executed MFMA FLOPs (= algorithmic conv FLOPs x 16/36)'))
+            cands = [e for e in cands if e['launches_per_step'] > 0]
             cands.sort(key=lambda e: -(e['share_of_step_time'] or 0.0))
             res['roofline'] = cands[0]
             res['roofline']['other_mfma_kernels'] = cands[1:]
