@@ -795,6 +795,130 @@ static int conv_dispatch(const ConvArgs& a, int R, int S, int stride, int dil, h
   return -1;
 }
 
+// ---------------------------------------------------------------------------
+// 1x1 convolution on 1x1 maps with a handful of samples (the Discriminator's classifier after global average pooling:
+// Module.py:205-213, 8..32 samples x 512 -> 1024 -> 1): a 2-MB filter read and ~10 MFLOP.  On the implicit-GEMM tiles this
+// is ONE workgroup column walking the whole filter (87-161 us per call); here 64 outputs x 4 reduction slices per block,
+// every lane streams its filter column ([reduction][Kpad] packing => coalesced), the samples' inputs are wave-uniform.
+struct SmallFcArgs {
+  const float* x;       // (N, C)
+  const float* mask;    // optional gate on x (data gradient: ReLU output of the layer), same shape
+  const float* wp;      // [C][Kpad]
+  const float* bias;
+  float* y;             // (N, K)
+  int N, C, K, Kpad, relu;
+};
+
+// K >= 64: lanes over outputs.  The samples' inputs are staged through LDS in 128-element reduction chunks (coalesced
+// load, gate applied once), every lane streams its filter column, LDS reads are broadcasts.
+template <int NB>
+__global__ __launch_bounds__(256) void small_fc_kernel(SmallFcArgs a) {
+  constexpr int CH = 128;
+  __shared__ float xs[NB][CH];
+  __shared__ float red[3][64][NB + 1];
+  const int l64 = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int o = blockIdx.x * 64 + l64;
+  const bool live = o < a.K;
+  float acc[NB];
+#pragma unroll
+  for (int n = 0; n < NB; ++n) acc[n] = 0.f;
+  for (int c0 = 0; c0 < a.C; c0 += CH) {
+    for (int idx = threadIdx.x; idx < NB * CH; idx += 256) {
+      const int n = idx / CH, rr = idx % CH;
+      float v = 0.f;
+      if (n < a.N && c0 + rr < a.C) {
+        v = a.x[(size_t)n * a.C + c0 + rr];
+        if (a.mask && !(a.mask[(size_t)n * a.C + c0 + rr] > 0.f)) v = 0.f;
+      }
+      xs[n][rr] = v;
+    }
+    __syncthreads();
+    // the 32 filter values of this slice first (independent loads in flight together), then the multiply-adds
+    float wv[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const int r = c0 + sl * 32 + i;
+      wv[i] = (live && r < a.C) ? a.wp[(size_t)r * a.Kpad + o] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 32; ++i)
+#pragma unroll
+      for (int n = 0; n < NB; ++n) acc[n] += wv[i] * xs[n][sl * 32 + i];
+    __syncthreads();
+  }
+  if (sl > 0) {
+#pragma unroll
+    for (int n = 0; n < NB; ++n) red[sl - 1][l64][n] = acc[n];
+  }
+  __syncthreads();
+  if (sl == 0 && live) {
+    const float b = a.bias ? a.bias[o] : 0.f;
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+      if (n < a.N) {
+        float v = ((acc[n] + red[0][l64][n]) + red[1][l64][n]) + red[2][l64][n] + b;
+        if (a.relu) v = v > 0.f ? v : 0.f;
+        a.y[(size_t)n * a.K + o] = v;
+      }
+  }
+}
+
+// K < 64 (the final 1024 -> 1 layer): block = one output, threads over the reduction, fixed-order block sums
+template <int NB>
+__global__ __launch_bounds__(256) void small_fc_narrow_kernel(SmallFcArgs a) {
+  __shared__ float red[256][NB + 1];
+  const int o = blockIdx.x;
+  float acc[NB];
+#pragma unroll
+  for (int n = 0; n < NB; ++n) acc[n] = 0.f;
+  for (int r = threadIdx.x; r < a.C; r += 256) {
+    const float w = a.wp[(size_t)r * a.Kpad + o];
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+      if (n < a.N) {
+        float v = a.x[(size_t)n * a.C + r];
+        if (a.mask && !(a.mask[(size_t)n * a.C + r] > 0.f)) v = 0.f;
+        acc[n] += w * v;
+      }
+  }
+#pragma unroll
+  for (int n = 0; n < NB; ++n) red[threadIdx.x][n] = acc[n];
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) {
+#pragma unroll
+      for (int n = 0; n < NB; ++n) red[threadIdx.x][n] += red[threadIdx.x + st][n];
+    }
+    __syncthreads();
+  }
+  if ((int)threadIdx.x < a.N && (int)threadIdx.x < NB) {
+    float v = red[0][threadIdx.x] + (a.bias ? a.bias[o] : 0.f);
+    if (a.relu) v = v > 0.f ? v : 0.f;
+    a.y[(size_t)threadIdx.x * a.K + o] = v;
+  }
+}
+
+// 0 = launched
+static int try_small_fc(int N, int C, int K, int H, int W, int R, int S, int stride, int pad, const float* x, const float* mask,
+                        const float* wp, const float* bias, float* y, int relu, hipStream_t st) {
+  if (!(R == 1 && S == 1 && stride == 1 && pad == 0 && H == 1 && W == 1 && N <= 32)) return 1;
+  SmallFcArgs a;
+  a.x = x; a.mask = mask; a.wp = wp; a.bias = bias; a.y = y;
+  a.N = N; a.C = C; a.K = K; a.Kpad = round_up(K, 128); a.relu = relu;
+  if (K >= 64) {
+    const dim3 grid((unsigned)cdiv(K, 64));
+    if (N <= 8) hipLaunchKernelGGL(small_fc_kernel<8>, grid, dim3(256), 0, st, a);
+    else if (N <= 16) hipLaunchKernelGGL(small_fc_kernel<16>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(small_fc_kernel<32>, grid, dim3(256), 0, st, a);
+  } else {
+    const dim3 grid((unsigned)K);
+    if (N <= 8) hipLaunchKernelGGL(small_fc_narrow_kernel<8>, grid, dim3(256), 0, st, a);
+    else if (N <= 16) hipLaunchKernelGGL(small_fc_narrow_kernel<16>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(small_fc_narrow_kernel<32>, grid, dim3(256), 0, st, a);
+  }
+  return 0;
+}
+
 static int check_desc(const fcd_conv_desc* d, const char* who) {
   FCD_CHECK_ARG(d, "%s: null desc", who);
   FCD_CHECK_ARG(d->N > 0 && d->C > 0 && d->H > 0 && d->W > 0 && d->K > 0, "%s: non-positive dims", who);
@@ -839,6 +963,12 @@ extern "C" int fcd_conv2d_fwd_ex(const fcd_conv_desc* d, const float* x, const f
     FCD_LAUNCH_CHECK("conv2d_fwd(thin)");
     return FCD_OK;
   }
+  if (!a.act_slope && !residual &&
+      try_small_fc(d->N, d->C, d->K, d->H, d->W, d->R, d->S, d->stride, d->pad, x, nullptr, wp, bias, y, a.relu,
+                   (hipStream_t)stream) == 0) {
+    FCD_LAUNCH_CHECK("conv2d_fwd(small fc)");
+    return FCD_OK;
+  }
   rc = conv_dispatch(a, d->R, d->S, d->stride, 1, (hipStream_t)stream);
   FCD_CHECK_ARG(rc == 0, "fcd_conv2d_fwd: unsupported filter %dx%d stride %d", d->R, d->S, d->stride);
   FCD_LAUNCH_CHECK("conv2d_fwd");
@@ -863,6 +993,11 @@ extern "C" int fcd_conv2d_bwd_data(const fcd_conv_desc* d, const float* dy, cons
   FcdProfScope prof(FCD_K_CONV_DGRAD, (hipStream_t)stream, flops, bytes, fcd_prof_tag_desc("dgrad", d));
   if (fcd_try_dgrad_thin(d, dy, relu_out, wp_bwd, dx, (hipStream_t)stream, 0) == 0) {   // <= 4 input channels: VALU kernel
     FCD_LAUNCH_CHECK("conv2d_bwd_data(thin)");
+    return FCD_OK;
+  }
+  if (try_small_fc(d->N, d->K, d->C, d->P, d->Q, d->R, d->S, d->stride, d->pad, dy, relu_out, wp_bwd, nullptr, dx, 0,
+                   (hipStream_t)stream) == 0) {      // transposed: reduction over K, outputs = C
+    FCD_LAUNCH_CHECK("conv2d_bwd_data(small fc)");
     return FCD_OK;
   }
   rc = conv_dispatch(a, d->R, d->S, 1, d->stride, (hipStream_t)stream);

@@ -49,6 +49,8 @@ CONV_CASES = [
     (2, 128, 40, 56, 1, 1, 1, 0),
     (3, 512, 1, 1, 1024, 1, 1, 0),
     (3, 1024, 1, 1, 1, 1, 1, 0),
+    (32, 512, 1, 1, 1000, 1, 1, 0),     # small-FC kernel at its sample limit, ragged output block
+    (33, 96, 1, 1, 130, 1, 1, 0),       # one sample more: implicit-GEMM tiles
     (2, 3, 48, 40, 64, 3, 1, 1),
     (2, 512, 6, 5, 512, 3, 1, 1),
     # thin (<= 4 input channels) VALU kernels: forward (K > 32) and data gradient, float4 rows
