@@ -71,7 +71,7 @@ def wino_weight(weight, mode, m):
     """Winograd-transformed filters (fcd_conv_wino_pack), cached like :func:`packed_weight`."""
     cache = weight.__dict__.setdefault('_fcd_pack', {})
     ver = weight._version
-    key = ('wino', mode, m)
+    key = ('wino', mode, m, lib.fcd_conv_wino_split_set(-1) != 0)      # the pack writes fp32 U or its bf16 planes
     hit = cache.get(key)
     if hit is not None and hit[0] == ver and hit[1].device == weight.device:
         return hit[1]

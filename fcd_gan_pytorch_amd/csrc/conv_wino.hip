@@ -104,7 +104,7 @@ __global__ void wino_filter_kernel(const float* __restrict__ w, float* __restric
       for (int b = 0; b < A; ++b) {
         const float u = t[a][0] * WinoMat<MM>::G(b, 0) + t[a][1] * WinoMat<MM>::G(b, 1) + t[a][2] * WinoMat<MM>::G(b, 2);
         const long long o = ((long long)(a * A + b) * rows + row) * Kc + kc;
-        U[o] = u;
+        if (U) U[o] = u;
         if (planes) {
           const long long ps = (long long)A * A * total;
           const unsigned short h = bf16_rn_bits(u);
@@ -1251,6 +1251,7 @@ static int wino_split() {
   }
   return g_wino_split;
 }
+static int wino_split_state() { return wino_split(); }
 extern "C" int fcd_conv_wino_split_set(int on) {
   const int old = wino_split();
   if (on >= 0) g_wino_split = on > 2 ? 1 : on;      // 2: as 1, and the 256 x 256 kernel for every GEMM with >= 256 rows (tests)
@@ -1503,18 +1504,25 @@ extern "C" int64_t fcd_conv_wino_filter_elems(int K, int C, int mode, int m) {
   return elems + elems / 2 * 3;      // fp32 U, then three bf16 planes (the split GEMM's A operand)
 }
 
+static int wino_split_state();      // fcd_conv_wino_split_set(-1)
 extern "C" int fcd_conv_wino_pack(const float* w, float* U, int K, int C, int mode, int m, void* stream) {
   FCD_CHECK_ARG(w && U && K > 0 && C > 0 && (mode == 0 || mode == 1) && (m == 2 || m == 4),
                 "fcd_conv_wino_pack: bad arguments");
   const int rows = mode == 0 ? K : C, Kc = round_up(mode == 0 ? C : K, 32);
   const long long total = (long long)rows * Kc;
   const int grid = (int)std::min<long long>(cdiv64(total, 256), 4096);
-  FcdProfScope prof(FCD_K_PACK, (hipStream_t)stream, 0.0, 4.0 * total * (9 + 2.5 * (m + 2) * (m + 2)));
+  FcdProfScope prof(FCD_K_PACK, (hipStream_t)stream, 0.0, 4.0 * total * (9 + 1.5 * (m + 2) * (m + 2)));
+  // the GEMM reads EITHER the fp32 U (fp32 matrix pipe) OR its three bf16 planes behind it (split pipe, every GEMM of
+  // >= 128 rows = every layer the plan sends here): only that one is written.  The host cache keys the packed buffer by
+  // fcd_conv_wino_split_set(-1), so flipping the switch re-packs.
   unsigned short* planes = (unsigned short*)(U + (long long)(m + 2) * (m + 2) * total);
+  const bool split = wino_split_state() != 0 && rows > 64;
+  float* Uw = split ? nullptr : U;
+  if (!split) planes = nullptr;
   if (m == 2)
-    hipLaunchKernelGGL(wino_filter_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, U, K, C, rows, Kc, mode, planes);
+    hipLaunchKernelGGL(wino_filter_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, Uw, K, C, rows, Kc, mode, planes);
   else
-    hipLaunchKernelGGL(wino_filter_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, U, K, C, rows, Kc, mode, planes);
+    hipLaunchKernelGGL(wino_filter_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, Uw, K, C, rows, Kc, mode, planes);
   FCD_LAUNCH_CHECK("wino_pack");
   return FCD_OK;
 }

@@ -91,7 +91,8 @@ int fcd_conv_wino_plan(const fcd_conv_desc* d, int mode);
 int fcd_conv_wino_set(int m);
 /* matrix pipe of the batched GEMM of the three-kernel path: 1 (default, env FCD_WINO_SPLIT) = bf16 MFMA on exact
  * three-way bf16 splits of the fp32 operands, six partial products accumulated in fp32 (fp32-equivalent result);
- * 0 = v_mfma_f32_32x32x2_f32; 2 = as 1 with the 256 x 256-tile kernel for every GEMM of >= 256 rows (tests: the policy
+ * 0 = v_mfma_f32_32x32x2_f32 (fcd_conv_wino_pack writes the operand form of the CURRENT setting -- fp32 U or its three
+ * bf16 planes -- so filters packed before a change of this switch must be packed again); 2 = as 1 with the 256 x 256-tile kernel for every GEMM of >= 256 rows (tests: the policy
  * otherwise keeps it for launches that fill the chip).  on < 0 only queries.  Returns the previous value. */
 int fcd_conv_wino_split_set(int on);
 size_t fcd_conv_wino_ws_bytes(const fcd_conv_desc* d, int mode);
