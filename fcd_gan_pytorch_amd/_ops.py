@@ -49,6 +49,18 @@ def _desc(xs, ws, stride, pad):
     return ConvDesc(N, C, H, W, K, R, S, stride, pad, P, Q)
 
 
+MULTI_STREAM = False      # set by steps._side_stream: packed filters are then shared between two HIP streams
+
+
+def _shared(t):
+    """A cached tensor handed to a kernel on the CURRENT stream.  With a second stream in play the tensor may have been
+    allocated on the other one, and dropping it from the cache (optimizer step, new weight version) would let the caching
+    allocator re-use its memory while this stream's kernels still read it: tell the allocator about the use."""
+    if MULTI_STREAM and t.is_cuda:
+        t.record_stream(torch.cuda.current_stream(t.device))
+    return t
+
+
 def packed_weight(weight, mode):
     """Packed GEMM-A layout of ``weight`` (mode 0 forward / 1 data-grad), cached on
     the tensor object and keyed by its version counter.  fcd optimizers update
@@ -57,14 +69,14 @@ def packed_weight(weight, mode):
     ver = weight._version
     hit = cache.get(mode)
     if hit is not None and hit[0] == ver and hit[1].device == weight.device:
-        return hit[1]
+        return _shared(hit[1])
     K, C, R, S = weight.shape
     n = lib.fcd_conv_packed_elems(K, C, R, S, mode)
     wp = torch.empty(n, dtype=torch.float32, device=weight.device)
     w = weight.detach().contiguous()
     check(lib.fcd_conv_pack_weights(_p(w), _p(wp), K, C, R, S, mode, _stream()), 'fcd_conv_pack_weights')
     cache[mode] = (ver, wp)
-    return wp
+    return _shared(wp)
 
 
 def wino_weight(weight, mode, m):
@@ -74,13 +86,13 @@ def wino_weight(weight, mode, m):
     key = ('wino', mode, m, lib.fcd_conv_wino_split_set(-1) != 0)      # the pack writes fp32 U or its bf16 planes
     hit = cache.get(key)
     if hit is not None and hit[0] == ver and hit[1].device == weight.device:
-        return hit[1]
+        return _shared(hit[1])
     K, C = weight.shape[:2]
     U = torch.empty(lib.fcd_conv_wino_filter_elems(K, C, mode, m), dtype=torch.float32, device=weight.device)
     w = weight.detach().contiguous()
     check(lib.fcd_conv_wino_pack(_p(w), _p(U), K, C, mode, m, _stream()), 'fcd_conv_wino_pack')
     cache[key] = (ver, U)
-    return U
+    return _shared(U)
 
 
 def wino2_weight(weight, mode):
@@ -91,13 +103,13 @@ def wino2_weight(weight, mode):
     key = ('wino2', mode)
     hit = cache.get(key)
     if hit is not None and hit[0] == ver and hit[1].device == weight.device:
-        return hit[1]
+        return _shared(hit[1])
     K, C = weight.shape[:2]
     U = torch.empty(lib.fcd_conv_wino2_filter_elems(K, C, mode), dtype=torch.float32, device=weight.device)
     w = weight.detach().contiguous()
     check(lib.fcd_conv_wino2_pack(_p(w), _p(U), K, C, mode, _stream()), 'fcd_conv_wino2_pack')
     cache[key] = (ver, U)
-    return U
+    return _shared(U)
 
 
 def _fwd_conv(d, x, weight, bias, y, relu, pool_y=None, code=None):
@@ -127,12 +139,12 @@ def s2_weight(weight):
     ver = weight._version
     hit = cache.get('s2')
     if hit is not None and hit[0] == ver and hit[1].device == weight.device:
-        return hit[1]
+        return _shared(hit[1])
     K, C = weight.shape[:2]
     wp = torch.empty(lib.fcd_conv_s2_dgrad_packed_elems(K, C), dtype=torch.float32, device=weight.device)
     check(lib.fcd_conv_s2_dgrad_pack(_p(weight.detach().contiguous()), _p(wp), K, C, _stream()), 'fcd_conv_s2_dgrad_pack')
     cache['s2'] = (ver, wp)
-    return wp
+    return _shared(wp)
 
 
 def _bwd_data_conv(d, dy, weight, dx, yrelu=None, code=None):

@@ -54,6 +54,30 @@ def _bcast_keep(cmask, C):
     return 1 - cmask            # (N,1,H,W) broadcasts over the C bands (reference uses .repeat)
 
 
+_SIDE = {}
+
+
+def _side_stream(device):
+    """Second HIP stream of the adversarial steps -- EXPERIMENTAL, off unless FCD_STEP_OVERLAP=1.  The Discriminator
+    step -- its forward on the detached change map, backward, gradient exchange and update: many short launches on
+    32x..16x16 maps that leave most of the 256 CUs idle -- is independent of the frozen-Generator forward and of the
+    VGG feature passes of the Segmentor step, so it runs beside them; the Segmentor step's own Discriminator forward
+    (which must see the UPDATED weights, Demo_RSSS.py:311) waits for it.  Measured on one MI355X: 98.9 -> 98.5 ms/step,
+    bit-identical results (tools/debug/dbg_overlap.py) -- once the packed-filter caches tell the caching allocator about
+    their cross-stream readers (_ops._shared; without that the optimizer's cache invalidation let the other stream's
+    allocations overwrite filters a queued kernel was still reading).  Not the default: 0.4 % is not worth a second
+    stream next to the RCCL stream on the multi-GPU path, which cannot be exercised here."""
+    import os
+    if device.type != 'cuda' or os.environ.get('FCD_STEP_OVERLAP') != '1':
+        return None
+    s = _SIDE.get(device.index)
+    if s is None:
+        from . import _ops
+        _ops.MULTI_STREAM = True            # cached packed filters are now used from two streams (see _ops._shared)
+        s = _SIDE[device.index] = torch.cuda.Stream(device=device)
+    return s
+
+
 # ------------------------------------------------------------------------ RSSS
 def rsss_g_pretrain_step(netG, crit, optG, x, y, region, perception_weight=0.1, ssim_weight=0, group=None):
     """Demo_RSSS.py:190-208."""
@@ -86,26 +110,40 @@ def rsss_adversarial_step(netS, netD, netG, crit, optS, optD, x, y, region, perc
         optD.begin_overlap(group)
         d_loss.backward(retain_graph=True)
     else:
-        keep_d = _bcast_keep(cmask.detach(), x.shape[1])
-        xm_d = x * keep_d
-        c_out, nc_out = netD.forward_pairs([(xm_d, y * keep_d), (xm_d, y_unc * keep_d)])
-        optD.zero_grad()
-        d_loss = 1 + nc_out.mean() - c_out.mean()
-        optD.begin_overlap(group)
-        d_loss.backward()
-    optD.allreduce_grads(group)
-    optD.step()
+        side = _side_stream(x.device)
+        main = torch.cuda.current_stream(x.device) if side is not None else None
+        if side is not None:
+            side.wait_stream(main)              # cmap, y_unc are ready
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            keep_d = _bcast_keep(cmask.detach(), x.shape[1])
+            xm_d = x * keep_d
+            c_out, nc_out = netD.forward_pairs([(xm_d, y * keep_d), (xm_d, y_unc * keep_d)])
+            optD.zero_grad()
+            d_loss = 1 + nc_out.mean() - c_out.mean()
+            optD.begin_overlap(group)
+            d_loss.backward()
+    if literal or side is None:
+        optD.allreduce_grads(group)
+        optD.step()
+    else:
+        with torch.cuda.stream(side):
+            optD.allreduce_grads(group)
+            optD.step()
+            d_loss.record_stream(main)
     # ---- S step
     if literal:
         c_out = netD(x_mask, y_mask)
         y_fake = netG(x)
+        generator_loss, ssim_loss, perception_loss = crit(y, y_fake, cmap)
     else:
         keep = _bcast_keep(cmask, x.shape[1])
-        with _frozen(netD):
-            c_out = netD(x * keep, y * keep)
         with torch.no_grad():
             y_fake = netG(x)
-    generator_loss, ssim_loss, perception_loss = crit(y, y_fake, cmap)
+        generator_loss, ssim_loss, perception_loss = crit(y, y_fake, cmap)
+        if side is not None:
+            main.wait_stream(side)              # D's updated weights and running statistics
+        with _frozen(netD):
+            c_out = netD(x * keep, y * keep)
     g_loss = generator_loss + perception_weight * perception_loss + _weighted(ssim_weight, ssim_loss, literal)
     l1_loss = region_loss(cmap, region, 'l1')
     s_d_loss = c_out.mean()
