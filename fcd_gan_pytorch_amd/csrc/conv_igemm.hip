@@ -272,6 +272,153 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_kernel(ConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// <= 16 output channels (the Generator's last layer, 64 -> C bands through 9x9 taps: Module.py:165): the 32-row MFMA tile
+// above does 13 useful rows out of 32.  Same staging, v_mfma_f32_16x16x4_f32 instead: a wave multiplies 16 rows x 64
+// pixels (four 16-pixel column blocks) and FOUR input channels per instruction (lane group l >> 4 = channel), i.e. half
+// the matrix-pipe cycles per (channel, pixel) of the 32x32x2 form.  Workgroup: 4 waves side by side on a TH x TW = 256
+// pixel tile, CB = 8 channels per chunk, one filter-row chunk (RCH rows of taps) per step.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <int R, int S, int RCH, int CB, int TH, int TW>
+__global__ __launch_bounds__(256, 3) void conv_igemm_rows16_kernel(ConvArgs a) {
+  constexpr int BM = 16, BN = 256;
+  static_assert(TH * TW == BN && R % RCH == 0 && CB % 4 == 0, "tile");
+  constexpr int PH = TH - 1 + R, PW = TW - 1 + S, PWP = PW | 1, PLANE = PH * PWP;
+  constexpr int KC = CB * RCH * S, NR = R / RCH;
+  constexpr int W_F4 = KC * BM / 4, W_PER_T = (W_F4 + 255) / 256;
+  constexpr int X_ELEMS = CB * PH * PW, X_PER_T = (X_ELEMS + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float smem[KC * BM + CB * PLANE];
+  float* Ws = smem;
+  float* Xs = smem + KC * BM;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, kc = lane >> 4;
+  int bx = blockIdx.x;
+  const int tq = bx % a.tiles_q;
+  bx /= a.tiles_q;
+  const int tp = bx % a.tiles_p;
+  const int n = bx / a.tiles_p;
+  const int p0 = tp * TH, q0 = tq * TW;
+  int xoff[4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    const int pidx = wave * 64 + ni * 16 + l15;
+    xoff[ni] = kc * PLANE + (pidx / TW) * PWP + (pidx % TW);
+  }
+  const int woff = kc * (RCH * S) * BM + l15;
+  f32x4v acc[4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) acc[ni] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+  float4 wr[W_PER_T];
+  float xr[X_PER_T];
+  int w_goff[W_PER_T], x_goff[X_PER_T], x_loff[X_PER_T], x_cc[X_PER_T];
+  const int ih0 = p0 - a.pad, iw0 = q0 - a.pad;
+#pragma unroll
+  for (int i = 0; i < W_PER_T; ++i) {
+    const int idx = tid + i * 256;
+    const int row = idx / (BM / 4), col4 = idx % (BM / 4);
+    const int cc = row / (RCH * S), rem = row % (RCH * S);
+    w_goff[i] = (cc * (R * S) + rem) * a.Kpad + col4 * 4;
+  }
+#pragma unroll
+  for (int i = 0; i < X_PER_T; ++i) {
+    const int idx = tid + i * 256;
+    const int cc = idx / (PH * PW), rem = idx % (PH * PW);
+    const int ph = rem / PW, pw = rem % PW;
+    const int ih = ih0 + ph, iw = iw0 + pw;
+    const bool ok = idx < X_ELEMS && ih >= 0 && iw >= 0 && ih < a.H && iw < a.W;
+    x_cc[i] = ok ? cc : -1;
+    x_goff[i] = (cc * a.H + ih) * a.W + iw;
+    x_loff[i] = cc * PLANE + ph * PWP + pw;
+  }
+  const float* xin = a.x + (size_t)n * a.C * a.H * a.W;
+  const int chunk_elems = CB * a.H * a.W;
+#define R16_LOAD_W(CCHUNK, RR)                                                                        \
+  {                                                                                                   \
+    const float* wsrc = a.wp + ((size_t)(CCHUNK) * CB * (R * S) + (RR) * (RCH * S)) * a.Kpad;         \
+    _Pragma("unroll") for (int i = 0; i < W_PER_T; ++i)                                               \
+      if (W_F4 % 256 == 0 || tid + i * 256 < W_F4) wr[i] = *reinterpret_cast<const float4*>(wsrc + w_goff[i]); \
+  }
+#define R16_STORE_W()                                                                                 \
+  {                                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < W_PER_T; ++i)                                               \
+      if (W_F4 % 256 == 0 || tid + i * 256 < W_F4) *reinterpret_cast<float4*>(Ws + (tid + i * 256) * 4) = wr[i]; \
+  }
+#define R16_LOAD_X(CCHUNK)                                                                            \
+  {                                                                                                   \
+    const float* xsrc = xin + (size_t)(CCHUNK) * chunk_elems;                                         \
+    const int cleft = a.C - (CCHUNK) * CB;                                                            \
+    _Pragma("unroll") for (int i = 0; i < X_PER_T; ++i) {                                             \
+      const bool ok = (unsigned)x_cc[i] < (unsigned)cleft;                                            \
+      const float v = xsrc[ok ? (unsigned)x_goff[i] : 0u];                                            \
+      xr[i] = ok ? v : 0.f;                                                                           \
+    }                                                                                                 \
+  }
+#define R16_STORE_X()                                                                                 \
+  {                                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < X_PER_T; ++i)                                               \
+      if (X_ELEMS % 256 == 0 || tid + i * 256 < X_ELEMS) Xs[x_loff[i]] = xr[i];                       \
+  }
+  const int nsteps = a.nchunks * NR;
+  R16_LOAD_X(0)
+  R16_LOAD_W(0, 0)
+  R16_STORE_X()
+  R16_STORE_W()
+  __syncthreads();
+  for (int step = 0; step < nsteps; ++step) {
+    const int nxt = step + 1;
+    const int rr = (NR == 1) ? 0 : step % NR;
+    const bool have_next = nxt < nsteps;
+    const bool next_patch = have_next && (NR == 1 || nxt % NR == 0);
+    if (have_next) {
+      if (next_patch) R16_LOAD_X(nxt / NR)
+      R16_LOAD_W(nxt / NR, (NR == 1) ? 0 : nxt % NR)
+    }
+    const float* wl = Ws + woff;
+    const float* xl = Xs + rr * RCH * PWP;
+#pragma unroll
+    for (int cg = 0; cg < CB / 4; ++cg)
+#pragma unroll
+      for (int rl = 0; rl < RCH; ++rl)
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+          const float av = wl[((cg * 4) * (RCH * S) + rl * S + s) * BM];
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni)
+            acc[ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xl[xoff[ni] + (cg * 4) * PLANE + rl * PWP + s], acc[ni], 0, 0, 0);
+        }
+    __syncthreads();
+    if (have_next) {
+      if (next_patch) R16_STORE_X()
+      R16_STORE_W()
+    }
+    __syncthreads();
+  }
+#undef R16_LOAD_W
+#undef R16_STORE_W
+#undef R16_LOAD_X
+#undef R16_STORE_X
+  // D layout: col = lane & 15 (pixel), row = 4 * (lane >> 4) + reg (channel)
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    const int pidx = wave * 64 + ni * 16 + l15;
+    const int p = p0 + pidx / TW, q = q0 + pidx % TW;
+    if (p >= a.P || q >= a.Q) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ko = 4 * kc + r;
+      if (ko >= a.K) continue;
+      float v = acc[ni][r];
+      if (a.bias) v += a.bias[ko];
+      if (a.relu) v = v > 0.f ? v : 0.f;
+      if (a.act_slope) v = v > 0.f ? v : v * (a.slope_ptr ? a.slope_ptr[0] : a.slope_imm);
+      const size_t yo = (((size_t)n * a.K + ko) * a.P + p) * a.Q + q;
+      if (a.residual) v += a.residual[yo];
+      a.y[yo] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // v2: same math, different staging.  The packed filter slab of a step is a set of
 // KC rows of BM contiguous floats, i.e. its LDS image [KC][BM] is lane-linear, so it is
 // DMA'd straight into LDS with global_load_lds (16 B per lane, no VGPR staging, no
@@ -787,7 +934,22 @@ static int conv_dispatch(const ConvArgs& a, int R, int S, int stride, int dil, h
   if (R == 3 && S == 3 && stride == 1 && dil == 1) return launch_family<3, 3, 3, 1, 1, 8>(a, st);
   if (R == 3 && S == 3 && stride == 2 && dil == 1) return launch_family<3, 3, 3, 2, 1, 8>(a, st);
   if (R == 3 && S == 3 && stride == 1 && dil == 2) return launch_family<3, 3, 3, 1, 2, 8>(a, st);
-  if (R == 9 && S == 9 && stride == 1 && dil == 1) return launch_family<9, 9, 1, 1, 1, 8>(a, st);
+  if (R == 9 && S == 9 && stride == 1 && dil == 1) {
+    static int rows16 = -1;
+    if (rows16 < 0) { const char* e = getenv("FCD_CONV_ROWS16"); rows16 = (e && e[0] == '0') ? 0 : 1; }
+    if (rows16 && a.K <= 16 && !a.mask && !a.pool_code_in && !a.shuf_C) {       // 16-row MFMA tiles
+      ConvArgs b = a;
+      const bool wide = a.Q > 16;
+      b.tiles_p = cdiv(a.P, wide ? 8 : 16);
+      b.tiles_q = cdiv(a.Q, wide ? 32 : 16);
+      b.nchunks = cdiv(a.C, 8);
+      const dim3 grid((unsigned)(a.N * b.tiles_p * b.tiles_q));
+      if (wide) hipLaunchKernelGGL((conv_igemm_rows16_kernel<9, 9, 1, 8, 8, 32>), grid, dim3(256), 0, st, b);
+      else hipLaunchKernelGGL((conv_igemm_rows16_kernel<9, 9, 1, 8, 16, 16>), grid, dim3(256), 0, st, b);
+      return 0;
+    }
+    return launch_family<9, 9, 1, 1, 1, 8>(a, st);
+  }
   if (R == 1 && S == 1 && stride == 1 && dil == 1) return launch_family<1, 1, 1, 1, 1, 32>(a, st);
   if (R == 2 && S == 2 && stride == 2 && dil == 1) return launch_family<2, 2, 2, 2, 1, 8>(a, st);
   if (R == 2 && S == 2 && stride == 1 && dil == 2) return launch_family<2, 2, 2, 1, 2, 8>(a, st);
