@@ -919,7 +919,7 @@ static int launch_family(const ConvArgs& a, hipStream_t st) {
                 : launch_cfg<R, S, RCH, STRIDE, DIL, CB, 2, 2, 2, 2, 8, 16>(a, st);
   } else if (a.K > 32) {
     // 64 output channels: 64 x 256-pixel tiles (8x32 / 16x16 pixels), each wave 64x64
-    if (R == 3 && a.P >= 8)
+    if ((R == 3 || R == 9) && a.P >= 8)      // (9x9: a 16 x 40 patch per 8 x 32 pixels instead of 12 x 40 per 4 x 32)
       return wide ? launch_cfg<R, S, RCH, STRIDE, DIL, CB, 2, 2, 1, 4, 8, 32>(a, st)
                   : launch_cfg<R, S, RCH, STRIDE, DIL, CB, 2, 2, 1, 4, 16, 16>(a, st);
     return wide ? launch_cfg<R, S, RCH, STRIDE, DIL, CB, 2, 1, 1, 4, 4, 32>(a, st)
