@@ -6,12 +6,19 @@
 //
 // per (m+2)^2 transform position xi the channel sum is a plain GEMM
 //   M_xi[k][t] = sum_c U_xi[k][c] * V_xi[t][c]             t = image tile index
-// with 2.25x (m = 2) / 4x (m = 4) fewer multiplies than the direct convolution.  Three kernels:
-//   wino_input_kernel   x (or the gated / pooled gradient)  -> V   [xi][chunk of 32 ch][t][32]   HBM-bound
-//   wino_gemm_kernel    batched TN GEMM on v_mfma_f32_32x32x2_f32                                MFMA-bound
-//   wino_output_kernel  M [xi][k][t] -> y (+bias, ReLU, 2x2 max-pool with argmax code)          HBM-bound
-// The transformed filters U [xi][rows][channels padded to 32] are packed once per weight version
-// (fcd_conv_wino_pack): mode 0 forward, mode 1 data gradient (flipped taps, channels swapped).
+// with 2.25x (m = 2) / 4x (m = 4) fewer multiplies than the direct convolution.  Three kernels per layer call:
+//   wino_input_roll_kernel   x (or the gated / pooled gradient; or a LIST of tensors standing for their channel
+//   (wino_input_kernel        concatenation)  -> V   [xi][chunk of 32 ch][t][32]                      HBM-bound
+//    on maps one strip high)
+//   wino_gemm_split256_kernel / wino_gemm_split_kernel   batched TN GEMM on v_mfma_f32_32x32x16_bf16 with every
+//                            fp32 operand split EXACTLY into three bf16 parts (six partial products, fp32
+//                            accumulation: fp32-equivalent)                                            MFMA-bound
+//   (wino_gemm_kernel         the same GEMM on v_mfma_f32_32x32x2_f32: 64-row GEMMs, FCD_WINO_SPLIT=0)
+//   wino_output_kernel       M [xi][k][t] -> y (+bias, ReLU, 2x2 max-pool with argmax code; or into a list
+//                            of tensors)                                                               HBM-bound
+// The weight gradient of the K, C >= 128 layers takes the same form (reduction over the tiles): wino_wg_* below.
+// The transformed filters U [xi][rows][channels padded to 32] -- fp32, or their three bf16 planes -- are packed once per
+// weight version (fcd_conv_wino_pack): mode 0 forward, mode 1 data gradient (flipped taps, channels swapped).
 // The same arithmetic order is used for every launch => bit-reproducible; fp32 rounding of the
 // m = 4 transforms is ~1e-5 relative (tests/test_gpu_ops.py), m = 2 ~3e-7.
 #include <stdlib.h>
