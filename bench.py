@@ -6,7 +6,9 @@ synthetic bi-temporal tiles, fp32, one process per GPU (weak scaling: fixed tile
 per GPU, gradients all-reduced over RCCL).
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+    N > 1 without a torchrun environment: bench.py launches the N ranks itself (re-exec through
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`, one rank per GPU,
+    backend nccl = RCCL); under torchrun (RANK / LOCAL_RANK / WORLD_SIZE set by the launcher) it is one of the ranks.
 
 Prints ONE JSON line on rank 0 (see the driver contract) with two extra objects:
   roofline     -- the dominant kernel family (MFMA implicit-GEMM conv, forward +
@@ -213,13 +215,14 @@ def effective_cores():
 
 
 def cpu_baseline(args):
-    """Oracle step (CPU port of the reference loop body, literal call order) on the host cores."""
+    """Oracle step (CPU port of the reference loop body, literal call order) on the host cores: batch 2, one warm-up,
+    then >= 3 timed iterations (bounded to ~30 s); min / median / mean iteration time reported."""
     sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
     from oracle import nets as onets, steps as osteps
     from fcd_gan_pytorch_amd.synthetic import synthetic_tiles
     import fcd_gan_pytorch_amd as fcd
     C, H, W = args.bands, args.size, args.size
-    n = 1
+    n = 2
     cores = effective_cores()
     torch.set_num_threads(cores)
     torch.manual_seed(0)
@@ -232,21 +235,75 @@ def cpu_baseline(args):
     nets = osteps.Nets(sdG, sdS, sdD, sdV).make_optimizers('rsss')
     x, y, region = synthetic_tiles(1234, n, C, H, W)
     osteps.rsss_adversarial_step(nets, x, y, region)            # warm-up (oneDNN primitive creation)
-    iters, t0 = 0, time.perf_counter()
-    while iters < 2 and (time.perf_counter() - t0) < 25.0 or iters == 0:
+    times, t_all = [], time.perf_counter()
+    while len(times) < 3 or (len(times) < 8 and (time.perf_counter() - t_all) < 20.0):
+        t0 = time.perf_counter()
         osteps.rsss_adversarial_step(nets, x, y, region)
-        iters += 1
-    dt = time.perf_counter() - t0
+        times.append(time.perf_counter() - t0)
+    dt = sum(times)
+    ts = sorted(times)
+    med = ts[len(ts) // 2] if len(ts) % 2 else 0.5 * (ts[len(ts) // 2 - 1] + ts[len(ts) // 2])
     model = ''
     try:
         with open('/proc/cpuinfo') as f:
             model = [l.split(':', 1)[1].strip() for l in f if l.startswith('model name')][0]
     except Exception:
         pass
-    return {'value': n * iters / dt, 'unit': 'tile-pairs/s', 'cores': cores, 'kind': 'port',
-            'sample': '%d iteration(s) of the literal Demo_RSSS adversarial step, batch %d, %dx%dx%d, '
-                      'torch CPU (oneDNN) fp32, %d threads, after 1 warm-up' % (iters, n, H, W, C, cores),
+    return {'value': n / med, 'unit': 'tile-pairs/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d timed iterations of the literal Demo_RSSS adversarial step, batch %d, %dx%dx%d, '
+                      'torch CPU (oneDNN) fp32, %d threads, after 1 warm-up; value = batch / median iteration time'
+                      % (len(times), n, H, W, C, cores),
+            'value_best': n / ts[0], 'value_mean': n * len(times) / dt,
+            'iteration_s': {'min': ts[0], 'median': med, 'max': ts[-1], 'n': len(times)},
             'cpu_model': model, 'seconds': dt}
+
+
+def resolve_launch(gpus, env):
+    """How this invocation relates to the rank set: ('single', 1, 0, 0) -- one process, one GPU;
+    ('worker', world, rank, local_rank) -- one rank of a torchrun launch; ('spawn', gpus, 0, 0) -- `--gpus N > 1`
+    outside a launcher: bench.py must start the N ranks itself.
+
+    ``--gpus`` is authoritative.  A launcher environment is recognised by RANK + LOCAL_RANK + WORLD_SIZE together
+    (what torch.distributed.run exports); a stale WORLD_SIZE alone (e.g. inherited from an outer job) is ignored, and a
+    live launcher whose WORLD_SIZE disagrees with --gpus is an error rather than a mis-reported n_gpus."""
+    have = all(k in env for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'))
+    if have:
+        world, rank, local = int(env['WORLD_SIZE']), int(env['RANK']), int(env['LOCAL_RANK'])
+        if world != gpus:
+            raise SystemExit('bench.py: --gpus %d but the launcher environment says WORLD_SIZE=%d (RANK=%d): '
+                             'launch `torch.distributed.run --nproc-per-node %d bench.py --gpus %d`, or unset '
+                             'RANK/LOCAL_RANK/WORLD_SIZE' % (gpus, world, rank, gpus, gpus))
+        if world == 1:
+            return ('single', 1, 0, 0)
+        return ('worker', world, rank, local)
+    if gpus > 1:
+        return ('spawn', gpus, 0, 0)
+    return ('single', 1, 0, 0)
+
+
+def spawn_ranks(gpus, argv):
+    """Re-exec this script as `gpus` ranks through torch.distributed.run (the launch line the driver uses for N > 1);
+    rank 0's JSON line reaches our stdout unchanged.  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'GROUP_RANK', 'ROLE_RANK'):
+        env.pop(k, None)                               # a stale partial launcher environment must not leak into the children
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')  # dmabuf IPC: the only mode the host driver supports (RCCL needs it)
+    env.setdefault('OMP_NUM_THREADS', '4')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def latest_traffic_file():
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_hbm_traffic.json')))
+    return files[-1] if files else None
 
 
 def main():
@@ -273,12 +330,15 @@ def main():
     args.size = args.size or d_size
     args.batch = args.batch or d_batch
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    mode, world, rank, local_rank = resolve_launch(args.gpus, os.environ)
+    if mode == 'spawn':
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the product has no CPU fallback')
     ndev = torch.cuda.device_count()
+    if world > 1 and args.backend == 'nccl' and ndev < world:
+        raise SystemExit('bench.py: --gpus %d over RCCL needs %d GPUs, this node shows %d (for a functional test of the '
+                         'multi-rank path on fewer GPUs use --backend gloo)' % (world, world, ndev))
     dev_index = local_rank if args.backend == 'nccl' else local_rank % ndev
     torch.cuda.set_device(dev_index)
     dev = torch.device('cuda', dev_index)
@@ -383,6 +443,7 @@ def main():
             w2f, w2d = prof.get('conv_wino2_fwd', zero), prof.get('conv_wino2_dgrad', zero)
             wgemm, wxf = prof.get('wino_gemm', zero), prof.get('wino_transform', zero)
             wsplit = prof.get('wino_gemm_bf16x6', zero)
+            wgw_ = prof.get('conv_wgrad_wino', zero)
 
             def mfma_entry(name, ms, flops, launches, what):
                 ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
@@ -402,9 +463,11 @@ def main():
                            fwd['launches'] + dg['launches'], 'algorithmic convolution FLOPs'),
                 mfma_entry('wino_gemm_kernel (batched fp32 MFMA GEMM of the Winograd F(4x4,3x3) path; forward, data-gradient '
                            'and weight-gradient launches)', wgemm['ms'], wgemm['flops'], wgemm['launches'], 'executed GEMM FLOPs'),
-                mfma_entry('weight gradient: conv_wgrad_roll_kernel / conv_wgrad_kernel (+ re-layout, split-K reduce) and, for the wide '
-                           '3x3 layers, the Winograd F(4x4,3x3) form (its GEMM launches are also part of wino_gemm_kernel above)',
-                           wg['ms'], wg['flops'], wg['launches'], 'algorithmic weight-gradient FLOPs (direct count)'),
+                mfma_entry('weight gradient, direct kernels: conv_wgrad_roll_kernel / conv_wgrad_kernel (+ re-layout, split-K reduce).  The '
+                           'wide 3x3 layers take the Winograd F(4x4,3x3) form instead: their GEMMs are priced under the wino_gemm* entry '
+                           'and their transforms under kernel_families.wino_transform, not here',
+                           wg['ms'] - wgw_['ms'], wg['flops'] - wgw_['flops'], wg['launches'] - wgw_['launches'],
+                           'executed = algorithmic weight-gradient FLOPs of the layers on the direct kernels'),
             ]
             if wsplit['launches'] > 0:
                 e = mfma_entry('wino_gemm_split256_kernel / wino_gemm_split_kernel (batched GEMM of the Winograd F(4x4,3x3) path, forward, '
@@ -430,10 +493,19 @@ def main():
             # HBM bytes per launch of the direct-conv family from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate
             # rocprofv3 passes over this very command: tools/pmc_bench.sh); bench.py cannot run the profiler on itself,
             # so it reports the committed measurement of the family it belongs to.
-            tpath = os.path.join(ROOT, 'profiles', 'r02_hbm_traffic.json')
-            if os.path.exists(tpath) and args.workload == 'rsss' and args.batch == 8 and args.bands == 13 and args.size == 256:
+            tpath = latest_traffic_file()
+            stamp = _lib.kernel_source_hash()
+            if tpath and args.workload == 'rsss' and args.batch == 8 and args.bands == 13 and args.size == 256:
                 with open(tpath) as f:
-                    tj = json.load(f).get('families', {})
+                    tjson = json.load(f)
+                tj = tjson.get('families', {})
+                fresh = tjson.get('kernel_source_hash') == stamp
+                res['hbm_traffic_source'] = {
+                    'file': os.path.relpath(tpath, ROOT), 'measured_on_kernel_source_hash': tjson.get('kernel_source_hash'),
+                    'this_build_kernel_source_hash': stamp, 'valid_for_this_build': fresh,
+                    'note': 'bench.py cannot run rocprofv3 --pmc on itself: `traffic` is the committed PMC measurement of this very '
+                            'command (tools/pmc_hbm.sh), reported ONLY while the HIP sources it was taken on are the ones built here; '
+                            'otherwise traffic is null'}
                 alg = {'wino_gemm': wgemm['bytes'] / max(wgemm['launches'], 1),
                        'wino_gemm_split': wsplit['bytes'] / max(wsplit['launches'], 1),
                        'conv_igemm': (fwd['bytes'] + dg['bytes']) / max(fwd['launches'] + dg['launches'], 1)}
@@ -441,12 +513,13 @@ def main():
                     key = ('wino_gemm_split' if e['kernel'].startswith('wino_gemm_split') else
                            'wino_gemm' if e['kernel'].startswith('wino_gemm') else
                            'conv_igemm' if e['kernel'].startswith('conv_igemm') else None)
-                    if key and key in tj:
+                    if key:
+                        e['algorithmic_bytes_per_launch'] = alg[key]
+                    if fresh and key and key in tj:
                         e['traffic'] = tj[key]['hbm_bytes_per_launch']
                         e['traffic_unit'] = ('HBM bytes per launch: PMC FETCH_SIZE x %.2f + WRITE_SIZE x %.2f (factors calibrated in the same '
-                                             'session on known 2 GiB streams in the kernel\'s access pattern, profiles/r02_hbm_traffic.json)'
-                                             % (tj[key]['fetch_factor'] or 1.0, tj[key]['write_factor'] or 1.0))
-                        e['algorithmic_bytes_per_launch'] = alg[key]
+                                             'session on known 2 GiB streams in the kernel\'s access pattern, %s)'
+                                             % (tj[key]['fetch_factor'] or 1.0, tj[key]['write_factor'] or 1.0, os.path.relpath(tpath, ROOT)))
                         e['traffic_over_algorithmic'] = e['traffic'] / alg[key] if alg[key] else None
             if wf['launches'] + wd['launches'] > 0:
                 wms, wfl = wf['ms'] + wd['ms'], wf['flops'] + wd['flops']

@@ -39,6 +39,22 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+def kernel_source_hash():
+    """sha256 over the HIP sources + the C-ABI header (sorted by name): the stamp that ties a committed PMC
+    measurement (profiles/r*_hbm_traffic.json) to the kernels it was taken on -- bench.py reports the measured
+    traffic only while the stamp matches."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(CSRC, '*.hip')) + glob.glob(os.path.join(CSRC, '*.h')) +
+                   glob.glob(os.path.join(_HERE, '..', 'include', '*.h')))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 class ConvDesc(Structure):
     _fields_ = [(n, c_int32) for n in ('N', 'C', 'H', 'W', 'K', 'R', 'S', 'stride', 'pad', 'P', 'Q')]
 

@@ -131,6 +131,7 @@ def demo_usss(scene_x, scene_y, ref=None, device='cuda', patch_size=(220, 220), 
         if log:
             log('joint epoch %d loss %.4f' % (ep + 1, hist['joint'][-1]))
 
+    dp.sync_buffers((netS, netG))            # one set of BatchNorm statistics for the stitched map AND the checkpoint
     res = infer_scene(netS, ds, dev, batch_size=batch_size, prob_thresh=prob_thresh, gt_map=gt_map, pre_map=pre_map)
     if out_density and dp.world_info()[0] == 0:
         tiles.write_tiff(out_density, res['density'])
@@ -148,8 +149,12 @@ def infer_scene(netS, ds, device, batch_size=10, prob_thresh=0.5, gt_map=(1, 2),
     (Demo_USSS.py:404-470, Demo_RSSS.py:451-491): density map (float32), TP/FP/FN colour codes
     and the evaluator over the owned centres.  ``eval_mode=False`` keeps train() statistics
     like Demo_WSSS.py:389-391.  Under data parallelism the tiles are sharded rank-strided; every
-    centre is owned by exactly one tile, so the stitched maps are the SUM over ranks."""
+    centre is owned by exactly one tile, so the stitched maps are the SUM over ranks; in eval mode rank 0's BatchNorm
+    running statistics are broadcast first (``dp.sync_buffers``) so every tile is normalised alike and the map equals
+    what rank 0's checkpoint reproduces."""
     dev = torch.device(device)
+    if eval_mode:
+        dp.sync_buffers((netS,))
     was_training = netS.training
     netS.train(not eval_mode)
     grid = ds.grid
@@ -244,6 +249,7 @@ def demo_rsss(dataset, device='cuda', n_channels=4, epochs_g=50, epochs_adv=100,
         hist['adv'].append([float(v) for v in _epoch_mean(sums)] + [float(acc.Pixel_F1_score())])
         if log:
             log('adv epoch %d d %.4f s %.4f g %.4f F1 %.4f' % ((ep + 1,) + tuple(hist['adv'][-1])))
+    dp.sync_buffers((netS, netG, netD))      # the saved .pkl = the statistics every rank infers with from here on
     _save(netS, save_s)
     _save(netG, save_g)
     _save(netD, save_d)
@@ -318,6 +324,7 @@ def demo_wsss(changed_ds, unchanged_ds, device='cuda', n_channels=3, epochs_g=50
         hist['adv'].append([float(v) for v in _epoch_mean(sums)])
         if log:
             log('adv epoch %d d %.4f s %.4f' % ((ep + 1,) + tuple(hist['adv'][-1])))
+    dp.sync_buffers((netS, netG, netD))
     _save(netS, save_s)
     _save(netG, save_g)
     _save(netD, save_d)

@@ -13,6 +13,8 @@ across ranks, no data-path collective except the gradient exchange of ``optim`` 
    out.  ``ragged='drop'`` drops the ragged global batch on every rank instead.  Either way all ranks run the same
    number of steps -- a rank that ran out of tiles early would dead-lock the next all-reduce.
  * :func:`sync_start` -- rank 0's weights, BatchNorm buffers and optimizer-visible parameters broadcast once.
+ * :func:`sync_buffers` -- rank 0's BatchNorm running statistics re-broadcast before inference / checkpointing
+   (per-replica statistics drift apart during training).
  * :func:`mean_scalars` / :func:`sum_counts` -- the per-epoch logging reductions (<= 9 loss averages, the 2x2
    confusion matrix: SURVEY.md 8e collective 4).
 """
@@ -102,6 +104,24 @@ def sync_start(nets=(), optimizers=(), src=0, group=None):
         if loose:
             torch._C._increment_version(loose)
             ops.invalidate_packs(loose)
+
+
+def sync_buffers(nets=(), src=0, group=None):
+    """Broadcast rank ``src``'s module buffers (BatchNorm running statistics, ``num_batches_tracked``) to every rank.
+
+    With per-replica BatchNorm the running statistics drift apart after :func:`sync_start`; eval-mode inference over
+    rank-sharded tiles would then stitch a map out of ``world`` different normalisations, and the checkpoint rank 0
+    writes would not reproduce it.  The demos call this before ``infer_scene`` and before every ``_save`` -- the same
+    rule DistributedDataParallel applies on each forward (``broadcast_buffers``), paid once per phase instead.
+    No-op on one rank."""
+    _, world = world_info(group)
+    if world <= 1:
+        return
+    bufs = [b for net in nets for b in net.buffers()]
+    for b in bufs:
+        dist.broadcast(b.data, src, group=group)
+    if bufs:
+        torch._C._increment_version(bufs)        # folded (conv + BN) filter caches are keyed by these versions
 
 
 def mean_scalars(values, weight=1.0, group=None):

@@ -255,3 +255,50 @@ def test_bucketed_overlapped_exchange_rsss_shaped_step():
         assert eS['launched_during_backward'] >= 2, eS
         assert eD['buckets'] == 1
     np.testing.assert_array_equal(res[0][2], res[1][2])                  # both ranks end with the same reduced buffer
+
+
+# ------------------------------------------------- BatchNorm running statistics before inference / checkpoints
+def _buffers_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from fcd_gan_pytorch_amd import dp, Module
+        torch.set_num_threads(1)
+        D = Module.Discriminator_SRGAN_simple(3)
+        D.load_state_dict(seeded_state(onets.discriminator_spec(3), 6))
+        with torch.no_grad():                      # per-replica statistics drift: every rank ends training elsewhere
+            for i, b in enumerate(D.buffers()):
+                b.add_(rank * (i + 1)) if b.is_floating_point() else b.add_(7 * rank)
+        before = [b._version for b in D.buffers()]
+        dp.sync_buffers((D,))
+        after = [b._version for b in D.buffers()]
+        q.put((rank, [b.double().numpy().copy() for b in D.buffers()], all(a > b for a, b in zip(after, before))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sync_buffers_makes_inference_and_checkpoint_agree():
+    """with per-replica BatchNorm the running statistics differ per rank after training; the demos
+    broadcast rank 0's before eval-mode inference and before saving, so the stitched map == what the saved
+    checkpoint reproduces.  Version counters are bumped (the folded conv+BN caches are keyed by them)."""
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_buffers_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    from fcd_gan_pytorch_amd import Module
+    D = Module.Discriminator_SRGAN_simple(3)
+    D.load_state_dict(seeded_state(onets.discriminator_spec(3), 6))
+    want = [b.double().numpy() for b in D.buffers()]            # rank 0 added 0
+    assert len(want) > 0
+    for rank, bufs, bumped in res:
+        assert bumped
+        for got, w in zip(bufs, want):
+            np.testing.assert_array_equal(got, w)

@@ -3,9 +3,10 @@
 #   1. tools/hbm_calib.bin (known 2 GiB streams in our access patterns) under --pmc FETCH_SIZE and --pmc WRITE_SIZE
 #   2. bench.py (2 steps + 1 warm-up) under the same two passes (FETCH_SIZE takes 3 TCC slots, WRITE_SIZE 2: separate
 #      passes; --kernel-trace only, as MI355X_MICROARCH.md prescribes)
-#   3. tools/pmc_hbm_report.py -> gpurun_out/r02_hbm_traffic.json
+#   3. tools/pmc_hbm_report.py -> gpurun_out/${ROUND}_hbm_traffic.json (stamped with the kernel source hash; copy to profiles/)
 cd /tmp && export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+ROUND=${ROUND:-r03}
 agg() {  # dir counter
 python3 - "$1" "$2" <<'PY'
 import csv, sys, collections, json, glob
@@ -34,4 +35,4 @@ for pass in FETCH_SIZE WRITE_SIZE; do
   tail -1 $OUT/run.log | cut -c1-200
   agg $OUT $pass
 done
-cd $ROOT && python3 tools/pmc_hbm_report.py gpurun_out > gpurun_out/r02_hbm_traffic.json && head -c 1500 gpurun_out/r02_hbm_traffic.json
+cd $ROOT && python3 tools/pmc_hbm_report.py gpurun_out > gpurun_out/${ROUND}_hbm_traffic.json && head -c 1500 gpurun_out/${ROUND}_hbm_traffic.json

@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
-"""Turn the four aggregates of tools/pmc_hbm.sh into profiles/r02_hbm_traffic.json: calibration factors (known bytes /
+"""Turn the four aggregates of tools/pmc_hbm.sh into profiles/rNN_hbm_traffic.json: calibration factors (known bytes /
 reported bytes per access pattern) and the corrected HBM bytes per launch of the step's kernel families."""
 import json
 import os
 import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+from fcd_gan_pytorch_amd._lib import kernel_source_hash      # noqa: E402  (stamp: which kernels the counters were taken on)
 
 d = sys.argv[1]
 CAL_BYTES = float(2 << 30)
@@ -45,6 +48,7 @@ FAM = {
 }
 out = {'source': 'tools/pmc_hbm.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over tools/hbm_calib.bin '
                  '(2 GiB known streams) and over `python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof` (3 steps in total)',
+       'kernel_source_hash': kernel_source_hash(),
        'counter_unit': 'KiB', 'calibration': cal, 'families': {}}
 for fam, (keys, ff, wf, what) in FAM.items():
     fsum = sum(v['FETCH_SIZE'] for k, v in bf.items() if any(s in k for s in keys)) * unit
