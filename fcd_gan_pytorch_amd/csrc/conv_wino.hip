@@ -81,46 +81,63 @@ __device__ __forceinline__ unsigned short bf16_rn_bits(float x) {
 template <int MM>
 __global__ void wino_filter_kernel(const float* __restrict__ w, float* __restrict__ U, int K, int C, int rows, int Kc,
                                    int mode, unsigned short* __restrict__ planes) {
+  // one thread = TWO adjacent reduction channels (Kc is a multiple of 32): the bf16 planes are written as 4-byte pairs
+  // and the fp32 U as float2 -- the pack is store-bound (40 B written per filter tap read), 2-byte stores halve its rate
   constexpr int A = WinoMat<MM>::A;
   const long long total = (long long)rows * Kc;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+  const long long pairs = total >> 1;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < pairs;
        i += (long long)gridDim.x * blockDim.x) {
-    const int kc = (int)(i % Kc), row = (int)(i / Kc);
-    float g[3][3];
+    const int kc0 = (int)((2 * i) % Kc), row = (int)((2 * i) / Kc);
+    float g[2][3][3];
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
+    for (int e = 0; e < 2; ++e) {
+      const int kc = kc0 + e;
 #pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        float v = 0.f;
-        if (mode == 0) {
-          if (kc < C) v = w[(((long long)row * C + kc) * 3 + r) * 3 + s];
-        } else {
-          if (kc < K) v = w[(((long long)kc * C + row) * 3 + (2 - r)) * 3 + (2 - s)];
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+          float v = 0.f;
+          if (mode == 0) {
+            if (kc < C) v = w[(((long long)row * C + kc) * 3 + r) * 3 + s];
+          } else {
+            if (kc < K) v = w[(((long long)kc * C + row) * 3 + (2 - r)) * 3 + (2 - s)];
+          }
+          g[e][r][s] = v;
         }
-        g[r][s] = v;
-      }
-    float t[A][3];
+    }
+    float t[2][A][3];
 #pragma unroll
-    for (int a = 0; a < A; ++a)
+    for (int e = 0; e < 2; ++e)
 #pragma unroll
-      for (int s = 0; s < 3; ++s)
-        t[a][s] = WinoMat<MM>::G(a, 0) * g[0][s] + WinoMat<MM>::G(a, 1) * g[1][s] + WinoMat<MM>::G(a, 2) * g[2][s];
+      for (int a = 0; a < A; ++a)
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+          t[e][a][s] = WinoMat<MM>::G(a, 0) * g[e][0][s] + WinoMat<MM>::G(a, 1) * g[e][1][s] + WinoMat<MM>::G(a, 2) * g[e][2][s];
 #pragma unroll
     for (int a = 0; a < A; ++a)
 #pragma unroll
       for (int b = 0; b < A; ++b) {
-        const float u = t[a][0] * WinoMat<MM>::G(b, 0) + t[a][1] * WinoMat<MM>::G(b, 1) + t[a][2] * WinoMat<MM>::G(b, 2);
-        const long long o = ((long long)(a * A + b) * rows + row) * Kc + kc;
-        if (U) U[o] = u;
+        float u[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+          u[e] = t[e][a][0] * WinoMat<MM>::G(b, 0) + t[e][a][1] * WinoMat<MM>::G(b, 1) + t[e][a][2] * WinoMat<MM>::G(b, 2);
+        const long long o = ((long long)(a * A + b) * rows + row) * Kc + kc0;       // even
+        if (U) *(float2*)(U + o) = make_float2(u[0], u[1]);
         if (planes) {
           const long long ps = (long long)A * A * total;
-          const unsigned short h = bf16_rn_bits(u);
-          const float r = u - __uint_as_float((unsigned)h << 16);
-          const unsigned short m = bf16_rn_bits(r);
-          const float q = r - __uint_as_float((unsigned)m << 16);
-          planes[o] = h;
-          planes[ps + o] = m;
-          planes[2 * ps + o] = bf16_rn_bits(q);
+          unsigned h[2], m[2], l[2];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            h[e] = bf16_rn_bits(u[e]);
+            const float r = u[e] - __uint_as_float(h[e] << 16);
+            m[e] = bf16_rn_bits(r);
+            const float q = r - __uint_as_float(m[e] << 16);
+            l[e] = bf16_rn_bits(q);
+          }
+          *(unsigned*)(planes + o) = h[0] | (h[1] << 16);
+          *(unsigned*)(planes + ps + o) = m[0] | (m[1] << 16);
+          *(unsigned*)(planes + 2 * ps + o) = l[0] | (l[1] << 16);
         }
       }
   }
@@ -1517,7 +1534,7 @@ extern "C" int fcd_conv_wino_pack(const float* w, float* U, int K, int C, int mo
                 "fcd_conv_wino_pack: bad arguments");
   const int rows = mode == 0 ? K : C, Kc = round_up(mode == 0 ? C : K, 32);
   const long long total = (long long)rows * Kc;
-  const int grid = (int)std::min<long long>(cdiv64(total, 256), 4096);
+  const int grid = (int)std::min<long long>(cdiv64(total / 2, 256), 4096);
   FcdProfScope prof(FCD_K_PACK, (hipStream_t)stream, 0.0, 4.0 * total * (9 + 1.5 * (m + 2) * (m + 2)));
   // the GEMM reads EITHER the fp32 U (fp32 matrix pipe) OR its three bf16 planes behind it (split pipe, every GEMM of
   // >= 128 rows = every layer the plan sends here): only that one is written.  The host cache keys the packed buffer by

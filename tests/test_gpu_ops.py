@@ -61,6 +61,13 @@ CONV_CASES = [
     (1, 4, 33, 68, 40, 3, 1, 1),
     (2, 3, 16, 64, 44, 3, 1, 1),
     (1, 2, 5, 7, 16, 3, 1, 1),
+    # first-layer weight gradient (conv_wgrad_thin.hip: C x 9 < 128 columns, N P Q >= 4096): 13 / 4 / 3 bands, stride 1 and 2,
+    # rows that are not float4 multiples, ragged tiles in both directions, fewer than 64 filters
+    (2, 13, 72, 136, 64, 3, 1, 1),
+    (3, 4, 55, 70, 48, 3, 1, 1),
+    (2, 13, 96, 130, 64, 3, 2, 1),
+    (4, 3, 64, 64, 64, 3, 2, 1),
+    (1, 14, 66, 64, 33, 3, 1, 1),
 ]
 
 
@@ -85,7 +92,8 @@ def test_conv2d_fwd_bwd(case):
 
 
 @pytest.mark.parametrize('case', [(2, 3, 24, 40, 64, 3, 1, 1), (2, 64, 20, 28, 128, 3, 1, 1), (3, 16, 9, 7, 24, 3, 1, 1),
-                                  (2, 8, 16, 16, 40, 3, 2, 1), (2, 1, 36, 68, 64, 3, 1, 1), (1, 1, 21, 30, 64, 3, 1, 1)], ids=lambda c: 'x'.join(map(str, c)))
+                                  (2, 8, 16, 16, 40, 3, 2, 1), (2, 1, 36, 68, 64, 3, 1, 1), (1, 1, 21, 30, 64, 3, 1, 1),
+                                  (2, 13, 40, 72, 64, 3, 1, 1), (2, 4, 90, 102, 64, 3, 2, 1)], ids=lambda c: 'x'.join(map(str, c)))
 def test_conv2d_fused_relu(case):
     """conv + bias + ReLU in the kernel epilogue; backward re-derives the mask from the output."""
     ops = _ops()
@@ -423,6 +431,102 @@ def test_wino_gemm_matrix_pipes(case):
     for mode in (1, 2):
         for q in (1, 3):      # rms error of y and of dx (the F(4x4) transforms' own rounding dominates both)
             assert err[mode][q] <= 1.15 * err[0][q] + 1e-8, (mode, q, err)
+
+
+def _split_modes_conv(ops, x, w, b):
+    """y of the 3x3 layer with the F(4x4) GEMMs on the fp32 matrix pipe (mode 0) and on the two split-bf16 kernels."""
+    lib = ops.lib
+    prev = lib.fcd_conv_wino_split_set(-1)
+    out = {}
+    try:
+        for mode in (0, 1, 2):
+            lib.fcd_conv_wino_split_set(mode)
+            with torch.no_grad():
+                out[mode] = ops.conv2d(x.cuda(), w.cuda(), b.cuda(), 1, 1).cpu()
+    finally:
+        lib.fcd_conv_wino_split_set(prev)
+    return out
+
+
+@pytest.mark.parametrize('scale', ['mixed_1e+-12', 'big_1e30', 'small_1e-30', 'tiny_1e-36'])
+def test_wino_split_gemm_operand_magnitudes(scale):
+    """the exact three-way bf16 split on the GPU with operands far from N(0,1) -- per-channel
+    magnitudes spread over 24 decades (every reduction mixes them), |x| ~ 1e30 against |w| ~ 1e-30, and the other way
+    round, and activations at 1e-36 where the LOW parts of the split (2^-16 x) are fp32 subnormals.  Truth = torch fp64;
+    the split path must stay within the fp32 matrix pipe's error (both carry the F(4x4) transforms' rounding)."""
+    ops = _ops()
+    N, C, H, W, K = 2, 256, 32, 32, 256
+    x = rnd(N, C, H, W, seed=61)
+    w = rnd(K, C, 3, 3, seed=62, scale=(2.0 / (C * 9)) ** 0.5)
+    b = torch.zeros(K)
+    if scale == 'mixed_1e+-12':
+        e = torch.linspace(-12, 12, C)
+        x = x * (10.0 ** e).view(1, C, 1, 1).float()
+        w = w * (10.0 ** (-e)).view(1, C, 1, 1).float()
+    elif scale == 'big_1e30':
+        x, w = x * 1e30, w * 1e-30
+    elif scale == 'small_1e-30':
+        x, w = x * 1e-30, w * 1e30
+    else:
+        x, w = x * 1e-36, w * 1e36
+    yr = F.conv2d(x.double(), w.double(), None, padding=1)
+    ys = yr.abs().max().item()
+    out = _split_modes_conv(ops, x, w, b)
+    err = {m: ((out[m].double() - yr).abs().max().item() / ys, (out[m].double() - yr).pow(2).mean().sqrt().item() / ys) for m in out}
+    print('\n[split GEMM, %s] (max, rms) error / max|y|: fp32 pipe %.2e/%.2e  split128 %.2e/%.2e  split256 %.2e/%.2e'
+          % ((scale,) + err[0] + err[1] + err[2]))
+    for m in (0, 1, 2):
+        assert torch.isfinite(out[m]).all(), (scale, m)
+    if scale == 'tiny_1e-36':
+        # low parts of the activations' split are fp32 subnormals (2^-16 * 1e-36 < 1.2e-38): whatever the matrix pipe
+        # does with subnormal bf16 inputs, the result keeps at least the two upper parts (2^-16 relative) -- and the
+        # fp32 pipe on the same data is held to the same bound, so the difference between them is on record
+        for m in (0, 1, 2):
+            assert err[m][0] < 2e-4, (scale, m, err[m])
+        return
+    for m in (0, 1, 2):
+        assert err[m][0] < 6e-5, (scale, m, err[m])
+    for m in (1, 2):
+        assert err[m][1] <= 1.15 * err[0][1] + 1e-8, (scale, m, err)
+
+
+def test_wino_split_gemm_nonfinite_propagation():
+    """Inf / NaN in the activations.  Winograd itself spreads a non-finite pixel over every output tile whose 6x6 input
+    patch holds it (B^T d B and A^T M A form differences: Inf - Inf = NaN) -- on ANY matrix pipe -- where the direct
+    kernel confines it to the 3x3 neighbourhood.  The split adds one more Inf - Inf (x - bf16(x)), so an Inf becomes NaN
+    where the fp32 pipe may keep +-Inf.  Checked here: (1) every output the direct convolution
+    makes non-finite is non-finite on both pipes; (2) the split path flags every output the fp32 pipe flags; (3) nothing
+    leaks outside the tiles whose patch holds the bad pixel, and there the finite results are the usual ones."""
+    ops = _ops()
+    N, C, H, W, K = 1, 128, 32, 32, 128
+    x = rnd(N, C, H, W, seed=71)
+    w = rnd(K, C, 3, 3, seed=72, scale=(2.0 / (C * 9)) ** 0.5)
+    b = torch.zeros(K)
+    clean = F.conv2d(x.double(), w.double(), None, padding=1)
+    x = x.clone()
+    x[0, 5, 9, 13] = float('inf')
+    x[0, 77, 22, 6] = float('nan')
+    direct_bad = ~torch.isfinite(F.conv2d(x, w, None, padding=1)).any(dim=1)          # (N, H, W)
+    out = _split_modes_conv(ops, x, w, b)
+    tiles_bad = torch.zeros(N, H, W, dtype=torch.bool)
+    for (pi, pj) in ((9, 13), (22, 6)):
+        for ti in range(H // 4):
+            for tj in range(W // 4):
+                if 4 * ti - 1 <= pi <= 4 * ti + 4 and 4 * tj - 1 <= pj <= 4 * tj + 4:
+                    tiles_bad[0, 4 * ti:4 * ti + 4, 4 * tj:4 * tj + 4] = True
+    bad = {m: ~torch.isfinite(out[m]).all(dim=1) for m in out}
+    for m in (0, 1, 2):
+        assert (bad[m] | ~direct_bad).all(), ('mode %d lost a non-finite output of the direct convolution' % m)
+        assert (~bad[m] | tiles_bad).all(), ('mode %d: non-finite values outside the tiles that hold the bad pixels' % m)
+        ok = ~tiles_bad
+        e = ((out[m].double() - clean).abs().amax(dim=1)[ok]).max().item() / clean.abs().max().item()
+        assert e < 6e-5, (m, e)
+    for m in (1, 2):
+        assert (bad[m] | ~bad[0]).all(), 'the split path must flag every output the fp32 pipe flags'
+    n_inf = {m: int(torch.isinf(out[m]).sum()) for m in out}
+    print('\n[non-finite propagation] flagged pixels: direct %d, fp32 pipe %d, split %d / %d (of %d in the touched tiles); '
+          '+-Inf values kept: %s' % (int(direct_bad.sum()), int(bad[0].sum()), int(bad[1].sum()), int(bad[2].sum()),
+                                      int(tiles_bad.sum()), n_inf))
 
 
 @pytest.mark.parametrize('case', [(2, 128, 32, 32, 256, 256), (1, 64, 40, 72, 128, 128), (3, 256, 16, 32, 512, 384)],
