@@ -79,6 +79,10 @@ _SIGS = {
     'fcd_conv2d_bwd_data_wino_cat': (c_int, [P, P, P, P, P, P, c_int, P, c_size_t, P]),
     'fcd_conv2d_bwd_weight_bias_cat': (c_int, [P, P, P, c_int, P, P, P, P, P, c_size_t, P]),
     'fcd_conv_wino_ws_bytes': (c_size_t, [POINTER(ConvDesc), c_int]),
+    'fcd_conv_wino_keepv_bytes': (c_size_t, [POINTER(ConvDesc)]),
+    'fcd_conv2d_fwd_wino_keepv': (c_int, [POINTER(ConvDesc), P, P, P, P, c_int, P, P, P, c_size_t, P, P]),
+    'fcd_conv2d_fwd_wino_cat_keepv': (c_int, [P, P, P, c_int, P, P, P, c_int, P, c_size_t, P, P]),
+    'fcd_conv2d_bwd_weight_bias_v': (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, c_size_t, P]),
     'fcd_conv_wino_filter_elems': (c_int64, [c_int, c_int, c_int, c_int]),
     'fcd_conv_wino_pack': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     'fcd_conv2d_fwd_wino': (c_int, [POINTER(ConvDesc), P, P, P, P, c_int, P, P, P, c_size_t, P]),

@@ -112,9 +112,18 @@ def wino2_weight(weight, mode):
     return _shared(U)
 
 
-def _fwd_conv(d, x, weight, bias, y, relu, pool_y=None, code=None):
+def _keepv(d, want_dw, device):
+    """Buffer for the forward pass's transformed input when this layer's weight gradient can consume it
+    (fcd_conv_wino_keepv_bytes > 0 and a weight gradient will be asked for: ``ctx.needs_input_grad``), else None."""
+    if not want_dw:
+        return None
+    nb = lib.fcd_conv_wino_keepv_bytes(ctypes.byref(d))
+    return torch.empty(nb // 4, dtype=torch.float32, device=device) if nb else None
+
+
+def _fwd_conv(d, x, weight, bias, y, relu, pool_y=None, code=None, v_keep=None):
     """Forward launch: fused F(2x2) kernel for the 64-row layers, three-kernel F(4x4) for the wide ones when the
-    library plans them so, else direct."""
+    library plans them so, else direct.  ``v_keep``: see :func:`_keepv`."""
     if lib.fcd_conv_wino2_plan(ctypes.byref(d), 0):
         check(lib.fcd_conv2d_fwd_wino2(ctypes.byref(d), _p(x), _p(wino2_weight(weight, 0)), _p(bias), _p(y),
                                        ACT_RELU if relu else ACT_NONE, None, 0.0, None, _p(pool_y), _p(code), _stream()),
@@ -123,8 +132,9 @@ def _fwd_conv(d, x, weight, bias, y, relu, pool_y=None, code=None):
     m = lib.fcd_conv_wino_plan(ctypes.byref(d), 0)
     if m:
         ws = _ws(lib.fcd_conv_wino_ws_bytes(ctypes.byref(d), 0), x.device)
-        check(lib.fcd_conv2d_fwd_wino(ctypes.byref(d), _p(x), _p(wino_weight(weight, 0, m)), _p(bias), _p(y), int(relu),
-                                      _p(pool_y), _p(code), _p(ws), ws.numel(), _stream()), 'fcd_conv2d_fwd_wino')
+        check(lib.fcd_conv2d_fwd_wino_keepv(ctypes.byref(d), _p(x), _p(wino_weight(weight, 0, m)), _p(bias), _p(y), int(relu),
+                                            _p(pool_y), _p(code), _p(ws), ws.numel(), _p(v_keep), _stream()),
+              'fcd_conv2d_fwd_wino')
     elif pool_y is not None:
         check(lib.fcd_conv2d_fwd_relu_pool(ctypes.byref(d), _p(x), _p(packed_weight(weight, 0)), _p(bias), _p(pool_y),
                                            _p(code), _stream()), 'fcd_conv2d_fwd_relu_pool')
@@ -207,17 +217,21 @@ class _Conv2d(torch.autograd.Function):
                 bits = torch.empty(nb, dtype=torch.uint8, device=x.device)
                 check(lib.fcd_conv2d_fwd_relu_bits(ctypes.byref(d), _p(x), _p(packed_weight(weight, 0)), _p(b), _p(y),
                                                    _p(bits), _stream()), 'fcd_conv2d_fwd_relu_bits')
+        vk = None
         if bits is None:
-            _fwd_conv(d, x, weight, b, y, relu)
-        # x is only needed for the weight gradient; the fused-ReLU output doubles as the backward mask
-        ctx.save_for_backward(x if weight.requires_grad else None, weight, (y if relu and bits is None else None), bits)
+            vk = _keepv(d, ctx.needs_input_grad[1], x.device)
+            _fwd_conv(d, x, weight, b, y, relu, v_keep=vk)
+        # x is only needed for the weight gradient (or, on the wide F(4x4) layers, its transform V kept by the forward
+        # pass instead); the fused-ReLU output doubles as the backward mask
+        ctx.save_for_backward(x if (weight.requires_grad and vk is None) else None, weight,
+                              (y if relu and bits is None else None), bits, vk)
         ctx.geom = (stride, pad, bias is not None, tuple(x.shape))
         ctx.bias_param = bias
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight, yrelu, bits = ctx.saved_tensors
+        x, weight, yrelu, bits, vk = ctx.saved_tensors
         stride, pad, has_bias, xshape = ctx.geom
         dy = _dev(dy, 'conv grad')
         d = _desc(xshape, weight.shape, stride, pad)
@@ -235,8 +249,12 @@ class _Conv2d(torch.autograd.Function):
             if want_db:        # channel sums come out of the dy re-layout pass of the weight gradient
                 db = _grad_out(ctx.bias_param, (d.K,), dy.device)
             ws = _ws(lib.fcd_conv2d_bwd_weight_ws_bytes(ctypes.byref(d)), dy.device)
-            check(lib.fcd_conv2d_bwd_weight_bias(ctypes.byref(d), _p(x), _p(dy), _p(yrelu), _p(dw), _p(db), _p(ws),
-                                                 ws.numel(), _stream()), 'fcd_conv2d_bwd_weight_bias')
+            if vk is not None:
+                check(lib.fcd_conv2d_bwd_weight_bias_v(ctypes.byref(d), _p(vk), _p(dy), _p(yrelu), _p(dw), _p(db), _p(ws),
+                                                       ws.numel(), _stream()), 'fcd_conv2d_bwd_weight_bias_v')
+            else:
+                check(lib.fcd_conv2d_bwd_weight_bias(ctypes.byref(d), _p(x), _p(dy), _p(yrelu), _p(dw), _p(db), _p(ws),
+                                                     ws.numel(), _stream()), 'fcd_conv2d_bwd_weight_bias')
         elif want_db:
             db = _channel_sum(dy, yrelu, d.N, d.K, d.P * d.Q)
         return dx, dw, db, None, None, None
@@ -265,17 +283,19 @@ class _ConvPairCat(torch.autograd.Function):
         chans = (ctypes.c_int * 3)(c, c, cu)
         ws = _ws(lib.fcd_conv_wino_ws_bytes(ctypes.byref(d), 0), up.device)
         b = _dev(bias, 'conv bias') if bias is not None else None
-        check(lib.fcd_conv2d_fwd_wino_cat(ctypes.byref(d), srcs, chans, 3, _p(wino_weight(weight, 0, 4)), _p(b), _p(y),
-                                          1 if relu else 0, _p(ws), ws.numel(), _stream()), 'fcd_conv2d_fwd_wino_cat')
-        ctx.save_for_backward(f2n if weight.requires_grad else None, up if weight.requires_grad else None, weight,
-                              y if relu else None)
+        vk = _keepv(d, ctx.needs_input_grad[2], up.device)
+        check(lib.fcd_conv2d_fwd_wino_cat_keepv(ctypes.byref(d), srcs, chans, 3, _p(wino_weight(weight, 0, 4)), _p(b), _p(y),
+                                                1 if relu else 0, _p(ws), ws.numel(), _p(vk), _stream()),
+              'fcd_conv2d_fwd_wino_cat')
+        keep_x = weight.requires_grad and vk is None
+        ctx.save_for_backward(f2n if keep_x else None, up if keep_x else None, weight, y if relu else None, vk)
         ctx.geom = (tuple(f2n.shape), tuple(up.shape), bias is not None)
         ctx.bias_param = bias
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        f2n, up, weight, yrelu = ctx.saved_tensors
+        f2n, up, weight, yrelu, vk = ctx.saved_tensors
         fshape, ushape, has_bias = ctx.geom
         dy = _dev(dy, 'conv grad')
         n, cu, H, W = ushape
@@ -297,10 +317,14 @@ class _ConvPairCat(torch.autograd.Function):
             if want_db:
                 db = _grad_out(ctx.bias_param, (d.K,), dy.device)
             ws = _ws(lib.fcd_conv2d_bwd_weight_ws_bytes(ctypes.byref(d)), dy.device)
-            check(lib.fcd_conv2d_bwd_weight_bias_cat(ctypes.byref(d), _ptr_list([f2n.data_ptr(), f2n.data_ptr() + half,
-                                                                                  up.data_ptr()]), chans, 3, _p(dy), _p(yrelu),
-                                                     _p(dw), _p(db), _p(ws), ws.numel(), _stream()),
-                  'fcd_conv2d_bwd_weight_bias_cat')
+            if vk is not None:
+                check(lib.fcd_conv2d_bwd_weight_bias_v(ctypes.byref(d), _p(vk), _p(dy), _p(yrelu), _p(dw), _p(db), _p(ws),
+                                                       ws.numel(), _stream()), 'fcd_conv2d_bwd_weight_bias_v')
+            else:
+                check(lib.fcd_conv2d_bwd_weight_bias_cat(ctypes.byref(d), _ptr_list([f2n.data_ptr(), f2n.data_ptr() + half,
+                                                                                      up.data_ptr()]), chans, 3, _p(dy), _p(yrelu),
+                                                         _p(dw), _p(db), _p(ws), ws.numel(), _stream()),
+                      'fcd_conv2d_bwd_weight_bias_cat')
         elif want_db:
             db = _channel_sum(dy, yrelu, d.N, d.K, d.P * d.Q)
         return df, du, dw, db, None

@@ -535,6 +535,8 @@ struct WinoGemmArgs {
   int batches, xb;        // blockIdx.y = group of xb consecutive batches (transform positions) run by ONE workgroup as a
                           // single software pipeline: the first slabs of batch b + 1 are in flight while batch b's last
                           // MFMAs run and its C tile is stored -- no pipeline refill per batch
+  int bt;                 // split kernel, weight gradient: B is the FORWARD pass's V [xi][N / 32][bt_T][32] (GEMM row n = channel,
+  long long bt_T;         // reduction = tile index): b_batch = elements per xi, the reduction runs to bt_T (rows clamped), b_ld / b_adv unused
 };
 
 template <int WM, int WN>      // waves along M / N, each 64 x 64: block tile (64 WM) x (64 WN)
@@ -704,7 +706,12 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& h, unsi
   l = __builtin_bit_cast(unsigned, lp);
 }
 
-template <int WM, int WN>      // waves along M / N, each 64 x 64
+// BT: the B operand is read TRANSPOSED from the forward pass's transformed activations V [xi][channel chunk][tile][32 ch]
+// (weight gradient: GEMM row n = channel, reduction = tiles).  A stage's slab is four contiguous 4-KiB blocks [32 tiles][32
+// ch] (one per 32-channel chunk of the 128 columns), DMA'd as they lie; a lane then picks its 16 reduction elements with
+// ds_read_b32 (lanes = consecutive channels: conflict-free) instead of four ds_read_b128.  This is what lets the weight
+// gradient skip its own input transform (wino_wg_input_kernel: x read again, 2.25x written, 1.6 ms per step).
+template <int WM, int WN, bool BT = false>      // waves along M / N, each 64 x 64
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void wino_gemm_split_kernel(WinoGemmArgs a) {
   constexpr int KC = 32;
   constexpr int NW = WM * WN;
@@ -740,7 +747,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void wino_gem
   const int b_first = (int)blockIdx.y * a.xb;
   const int nb = min(a.xb, a.batches - b_first);
   const unsigned short* Ab = a.As + (size_t)b_first * a.a_batch + (size_t)q_beg * KC + (size_t)m0 * a.a_ld;
-  const float* Bb = a.B + (size_t)b_first * a.b_batch + (size_t)q_beg * a.b_adv + (size_t)n0 * a.b_ld;
+  const float* Bb = BT ? a.B + (size_t)b_first * a.b_batch
+                       : a.B + (size_t)b_first * a.b_batch + (size_t)q_beg * a.b_adv + (size_t)n0 * a.b_ld;
 
   // A slab in LDS: unit u = ((plane * 2 + half) * BM + row) * 2 + pj, 32-B row pitch.  A 16-lane ds_read_b128 group
   // ({0-3,12-15,20-27}, {4-11,16-19,28-31}) covers 16 distinct 16-B slots iff rows 16..31 take the other unit parity.
@@ -754,12 +762,20 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void wino_gem
     const int jl = pj ^ ((row >> 4) & 1);
     a_goff[j] = plane * a.as_plane + (long long)min(row, a.M - 1 - m0) * a.a_ld + h * (KC / 2) + jl * 8;
   }
+  int bt_t[PPW_B];                 // BT: tile (reduction element) of the stage this unit holds
 #pragma unroll
   for (int j = 0; j < PPW_B; ++j) {
     const int u = (wave + NW * j) * 64 + lane;
-    const int h = u / (BN * UH), row = (u / UH) % BN, pj = u % UH;
-    const int jl = pj ^ ((row >> SWS) & (UH - 1));
-    b_goff[j] = (int)(min(row, a.N - 1 - n0) * a.b_ld) + h * (KC / 2) + jl * 4;
+    if (BT) {                      // unit u of the slab [chunk][32 tiles][8 units of 4 channels]
+      const int chunk = min(n0 / 32 + (u >> 8), a.N / 32 - 1);
+      bt_t[j] = (u >> 3) & 31;
+      b_goff[j] = (int)((long long)chunk * a.bt_T * 32) + (u & 7) * 4;      // + tile * 32, per stage
+    } else {
+      const int h = u / (BN * UH), row = (u / UH) % BN, pj = u % UH;
+      const int jl = pj ^ ((row >> SWS) & (UH - 1));
+      b_goff[j] = (int)(min(row, a.N - 1 - n0) * a.b_ld) + h * (KC / 2) + jl * 4;
+      bt_t[j] = 0;
+    }
   }
 
   int aoff[2], boff[2];
@@ -767,7 +783,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void wino_gem
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     aoff[i] = ((half * BM + wm * 64 + i * 32 + l31) * 2) * 8;      // in bf16 elements, plane 0, unit 0
-    boff[i] = (half * BN + wn * 64 + i * 32 + l31) * (UH * 4);
+    boff[i] = BT ? ((wn * 2 + i) * 32 + half * 16) * 32 + l31      // [chunk][tile = half * 16 + e][channel l31]
+                 : (half * BN + wn * 64 + i * 32 + l31) * (UH * 4);
   }
 
   f32x16 acc[2][2];
@@ -782,13 +799,17 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void wino_gem
 #define WS_DMA(SA, SB)                                                                           \
   {                                                                                              \
     const unsigned short* as_ = Ab + (size_t)fb * a.a_batch + (size_t)fq * KC;                   \
-    const float* bs_ = Bb + (size_t)fb * a.b_batch + (size_t)fq * a.b_adv;                       \
+    const float* bs_ = BT ? Bb + (size_t)fb * a.b_batch : Bb + (size_t)fb * a.b_batch + (size_t)fq * a.b_adv; \
     _Pragma("unroll") for (int j = 0; j < PPW_A; ++j)                                            \
       __builtin_amdgcn_global_load_lds((gbl_void_t*)(as_ + a_goff[j]),                           \
                                        (lds_void_t*)((SA) + (wave + NW * j) * 512), 16, 0, 0);   \
-    _Pragma("unroll") for (int j = 0; j < PPW_B; ++j)                                            \
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(bs_ + b_goff[j]),                           \
+    _Pragma("unroll") for (int j = 0; j < PPW_B; ++j) {                                          \
+      /* BT: tile (q_beg + fq) * 32 + t of the forward V, clamped to the last real tile (A is zero there) */ \
+      const long long bo_ = BT ? (long long)b_goff[j] + min((long long)(q_beg + fq) * KC + bt_t[j], a.bt_T - 1) * 32 \
+                               : (long long)b_goff[j];                                           \
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(bs_ + bo_),                                 \
                                        (lds_void_t*)((SB) + (wave + NW * j) * 256), 16, 0, 0);   \
+    }                                                                                            \
     if (++fq == Q) { fq = 0; ++fb; }                                                             \
   }
 #define WS_MFMA(AV, BV)                                                                          \
@@ -825,8 +846,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void wino_gem
     u32x4 ah[2][2], am[2][2], al[2][2], bh[2][2], bm[2][2], bl[2][2];                            \
     _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                \
       _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                            \
+        if (BT) {                                                                                \
+          const float* bp_ = (SB) + boff[i] + s * 8 * 32;                                        \
+          xr[s][i][0] = f32x4{bp_[0], bp_[32], bp_[64], bp_[96]};                                \
+          xr[s][i][1] = f32x4{bp_[128], bp_[160], bp_[192], bp_[224]};                           \
+        } else {                                                                                 \
         xr[s][i][0] = (FCD_SEXP & 32) ? f32x4{(float)lane, 1.f, (float)s, 2.f} : *(const f32x4*)((SB) + boff[i] + (((2 * s) ^ swb) * 4));     \
         xr[s][i][1] = (FCD_SEXP & 32) ? f32x4{(float)i, 3.f, (float)lane, 2.f} : *(const f32x4*)((SB) + boff[i] + (((2 * s + 1) ^ swb) * 4)); \
+        }                                                                                        \
       }                                                                                          \
     _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                \
       _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                            \
@@ -840,7 +867,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void wino_gem
     _Pragma("unroll") for (int i = 0; i < 2; ++i) WS_SPLIT(xr[1][i][0], xr[1][i][1], bh[1][i], bm[1][i], bl[1][i]) \
     WS_SIX(ah[1], am[1], al[1], bh[1], bm[1], bl[1])                                             \
     if (!(FCD_SEXP & 16)) {                                                                      \
-      __builtin_amdgcn_sched_group_barrier(0x100, 20, 0);                                        \
+      __builtin_amdgcn_sched_group_barrier(0x100, BT ? 44 : 20, 0);                              \
       __builtin_amdgcn_sched_group_barrier(0x002, 88, 0);                                        \
       _Pragma("unroll") for (int k = 0; k < 22; ++k) {                                           \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                       \
@@ -1286,11 +1313,12 @@ static void wino_gemm_launch(WinoGemmArgs ga, int batches, int splits, hipStream
   int cfg = wino_gemm_cfg();
   if (ga.As && ga.M > 64 && wino_split()) {
     ga.batches = batches;
-    if (splits > 1) {          // weight gradient: split reduction, one transform position per workgroup
+    if (splits > 1 || ga.bt) {          // weight gradient: split reduction, one transform position per workgroup
       ga.m_tiles = cdiv(ga.M, 128); ga.n_tiles = cdiv(ga.N, 128);
       ga.xb = 1;
-      hipLaunchKernelGGL((wino_gemm_split_kernel<2, 2>), dim3((unsigned)(ga.m_tiles * ga.n_tiles), (unsigned)batches, (unsigned)splits),
-                         dim3(256), 0, st, ga);
+      const dim3 grid((unsigned)(ga.m_tiles * ga.n_tiles), (unsigned)batches, (unsigned)splits);
+      if (ga.bt) hipLaunchKernelGGL((wino_gemm_split_kernel<2, 2, true>), grid, dim3(256), 0, st, ga);
+      else hipLaunchKernelGGL((wino_gemm_split_kernel<2, 2>), grid, dim3(256), 0, st, ga);
       return;
     }
     // FCD_WINO_SPLIT_BIG: 0 = 128 x 128 tiles only; 1 (default) = 256 x 256 two-stage kernel for GEMMs with >= 256
@@ -1611,8 +1639,8 @@ static bool wino_cat_input_ok(const WinoPlan& pl, int W) {
 static int wino_run(const WinoPlan& pl, int N, int in_ch, int H, int W, const float* src, const float* mask,
                     const unsigned char* code_in, int Hp, int Wp, const float* U, const float* bias, int relu, float* y,
                     float* pool_y, unsigned char* code_out, void* ws, hipStream_t st,
-                    const WinoCat* in_cat = nullptr, const WinoCat* out_cat = nullptr) {
-  float* V = (float*)ws;
+                    const WinoCat* in_cat = nullptr, const WinoCat* out_cat = nullptr, float* v_keep = nullptr) {
+  float* V = v_keep ? v_keep : (float*)ws;       // v_keep: the caller keeps the transformed input for the weight gradient
   float* Mb = (float*)((char*)ws + ((pl.v_bytes + 255) & ~(size_t)255));
   WinoInArgs ia;
   memset(&ia, 0, sizeof(ia));
@@ -1678,10 +1706,23 @@ static double wino_bytes(const WinoPlan& pl) {
 }
 
 // y = [relu](conv(x, w) + bias)  or, when pool_y != NULL, pool_y / code = maxpool2(relu(conv + bias))
+// Bytes of the forward pass's transformed input V the WEIGHT GRADIENT of this layer can consume instead of transforming x
+// again (fcd_conv2d_fwd_wino_keepv -> fcd_conv2d_bwd_weight_bias_v); 0 when the layer's passes do not line up that way
+extern "C" size_t fcd_conv_wino_keepv_bytes(const fcd_conv_desc* d);
+
+extern "C" int fcd_conv2d_fwd_wino_keepv(const fcd_conv_desc* d, const float* x, const float* U, const float* bias, float* y,
+                                         int fuse_relu, float* pool_y, unsigned char* code, void* ws, size_t ws_bytes,
+                                         float* v_keep, void* stream);
 extern "C" int fcd_conv2d_fwd_wino(const fcd_conv_desc* d, const float* x, const float* U, const float* bias, float* y,
                                    int fuse_relu, float* pool_y, unsigned char* code, void* ws, size_t ws_bytes,
                                    void* stream) {
+  return fcd_conv2d_fwd_wino_keepv(d, x, U, bias, y, fuse_relu, pool_y, code, ws, ws_bytes, nullptr, stream);
+}
+extern "C" int fcd_conv2d_fwd_wino_keepv(const fcd_conv_desc* d, const float* x, const float* U, const float* bias, float* y,
+                                         int fuse_relu, float* pool_y, unsigned char* code, void* ws, size_t ws_bytes,
+                                         float* v_keep, void* stream) {
   FCD_CHECK_ARG(d && x && U && (y || (pool_y && code)), "fcd_conv2d_fwd_wino: null pointer");
+  FCD_CHECK_ARG(!v_keep || fcd_conv_wino_keepv_bytes(d) > 0, "fcd_conv2d_fwd_wino_keepv: fcd_conv_wino_keepv_bytes(d) == 0 for this layer");
   WinoPlan pl;
   FCD_CHECK_ARG(wino_plan(d, 0, &pl), "fcd_conv2d_fwd_wino: layer is not planned for the Winograd path");
   if (!ws || ws_bytes < fcd_conv_wino_ws_bytes(d, 0)) {
@@ -1690,7 +1731,7 @@ extern "C" int fcd_conv2d_fwd_wino(const fcd_conv_desc* d, const float* x, const
   }
   FcdProfScope prof(FCD_K_WINO_FWD, (hipStream_t)stream, conv_flops(d), wino_bytes(pl), fcd_prof_tag_desc("wino_fwd", d));
   wino_run(pl, d->N, d->C, d->H, d->W, x, nullptr, nullptr, 0, 0, U, bias, (fuse_relu || pool_y) ? 1 : 0,
-           pool_y ? nullptr : y, pool_y, code, ws, (hipStream_t)stream);
+           pool_y ? nullptr : y, pool_y, code, ws, (hipStream_t)stream, nullptr, nullptr, v_keep);
   FCD_LAUNCH_CHECK("conv2d_fwd_wino");
   return FCD_OK;
 }
@@ -1793,81 +1834,108 @@ __global__ __launch_bounds__(256) void wino_wg_input_kernel(WinoWgArgs a) {
 
 // W[xi][k][t] = A dY A^T, plus per-block channel sums of dY (bias gradient)
 __global__ __launch_bounds__(256) void wino_wg_dy_kernel(WinoWgArgs a) {
+  // one thread = TWO consecutive tiles (Tpad is even): float4 row reads where the rows allow it, and the three bf16
+  // planes leave as 4-byte pairs (2-byte stores run at half the rate: the pass is store-bound, 3.4x the bytes it reads)
   constexpr int A = 6;
   __shared__ double red[16];
-  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long t0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 2;
   const int k = blockIdx.y;
-  float dy[4][4];
+  float dy[2][4][4];
   float lsum = 0.f;
-  const bool live = t < a.T;
-  if (live) {
-    const int tx = (int)(t % a.TW);
-    const long long r2 = t / a.TW;
-    const int ty = (int)(r2 % a.TH), n = (int)(r2 / a.TH);
-    const size_t base = ((size_t)n * a.CH + k) * a.H * a.W;
+  const bool vec = (a.W & 3) == 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int ih = ty * 4 + i;
+  for (int e = 0; e < 2; ++e) {
+    const long long t = t0 + e;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int iw = tx * 4 + j;
-        float v = 0.f;
-        if (ih < a.H && iw < a.W) {
-          const size_t off = base + (size_t)ih * a.W + iw;
-          v = a.src[off];
-          if (a.mask && !(a.mask[off] > 0.f)) v = 0.f;
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dy[e][i][j] = 0.f;
+    if (t < a.T) {
+      const int tx = (int)(t % a.TW);
+      const long long r2 = t / a.TW;
+      const int ty = (int)(r2 % a.TH), n = (int)(r2 / a.TH);
+      const size_t base = ((size_t)n * a.CH + k) * a.H * a.W;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ih = ty * 4 + i;
+        if (ih >= a.H) continue;
+        const size_t off = base + (size_t)ih * a.W + tx * 4;
+        if (vec) {                          // W % 4 == 0: the whole 4-column group is inside the row
+          f32x4 v = *(const f32x4*)(a.src + off);
+          if (a.mask) {
+            const f32x4 m = *(const f32x4*)(a.mask + off);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (!(m[j] > 0.f)) v[j] = 0.f;
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) dy[e][i][j] = v[j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (tx * 4 + j < a.W) {
+              float v = a.src[off + j];
+              if (a.mask && !(a.mask[off + j] > 0.f)) v = 0.f;
+              dy[e][i][j] = v;
+            }
+          }
         }
-        dy[i][j] = v;
-        lsum += v;
       }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lsum += dy[e][i][j];
     }
   }
   if (a.psum != nullptr) {       // uniform: every thread of the block takes part
     const double bs = block_sum_d((double)lsum, red);
     if (threadIdx.x == 0) a.psum[(size_t)blockIdx.x * a.CH + k] = (float)bs;
   }
-  if (t >= a.Tpad) return;
-  float* wout = a.dst + (size_t)k * a.Tpad + t;
+  if (t0 >= a.Tpad) return;
+  float* wout = a.dst + (size_t)k * a.Tpad + t0;
   const size_t xs = (size_t)a.CH * a.Tpad;
-  unsigned short* pout = a.planes ? a.planes + (size_t)k * a.Tpad + t : nullptr;
+  unsigned short* pout = a.planes ? a.planes + (size_t)k * a.Tpad + t0 : nullptr;
   const size_t ps = 36 * xs;
-  if (!live) {
+  float t1[2][A][4];   // A dY : A[q][i] = AT(i, q)
 #pragma unroll
-    for (int i = 0; i < A * A; ++i) {
-      if (pout) { pout[(size_t)i * xs] = 0; pout[ps + (size_t)i * xs] = 0; pout[2 * ps + (size_t)i * xs] = 0; }
-      else wout[(size_t)i * xs] = 0.f;
-    }
-    return;
-  }
-  float t1[A][4];   // A dY : A[q][i] = AT(i, q)
+  for (int e = 0; e < 2; ++e)
 #pragma unroll
-  for (int q = 0; q < A; ++q)
+    for (int q = 0; q < A; ++q)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float s = 0.f;
+      for (int j = 0; j < 4; ++j) {
+        float s = 0.f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (WinoMat<4>::AT(i, q) != 0.f) s += WinoMat<4>::AT(i, q) * dy[i][j];
-      t1[q][j] = s;
-    }
+        for (int i = 0; i < 4; ++i)
+          if (WinoMat<4>::AT(i, q) != 0.f) s += WinoMat<4>::AT(i, q) * dy[e][i][j];
+        t1[e][q][j] = s;
+      }
 #pragma unroll
   for (int q = 0; q < A; ++q)
 #pragma unroll
     for (int p2 = 0; p2 < A; ++p2) {
-      float s = 0.f;
+      float sv[2];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (WinoMat<4>::AT(j, p2) != 0.f) s += t1[q][j] * WinoMat<4>::AT(j, p2);
+      for (int e = 0; e < 2; ++e) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (WinoMat<4>::AT(j, p2) != 0.f) s += t1[e][q][j] * WinoMat<4>::AT(j, p2);
+        sv[e] = s;                           // tiles past T: dy = 0 => exact zeros in every plane
+      }
       const size_t o = (size_t)(q * A + p2) * xs;
       if (pout) {      // exact three-way split, as wino_filter_kernel does for U
-        const unsigned short h = bf16_rn_bits(s);
-        const float r = s - __uint_as_float((unsigned)h << 16);
-        const unsigned short m = bf16_rn_bits(r);
-        pout[o] = h;
-        pout[ps + o] = m;
-        pout[2 * ps + o] = bf16_rn_bits(r - __uint_as_float((unsigned)m << 16));
+        unsigned h[2], m[2], l[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          h[e] = bf16_rn_bits(sv[e]);
+          const float r = sv[e] - __uint_as_float(h[e] << 16);
+          m[e] = bf16_rn_bits(r);
+          l[e] = bf16_rn_bits(r - __uint_as_float(m[e] << 16));
+        }
+        *(unsigned*)(pout + o) = h[0] | (h[1] << 16);
+        *(unsigned*)(pout + ps + o) = m[0] | (m[1] << 16);
+        *(unsigned*)(pout + 2 * ps + o) = l[0] | (l[1] << 16);
       } else {
-        wout[o] = s;
+        *(float2*)(wout + o) = make_float2(sv[0], sv[1]);
       }
     }
 }
@@ -1987,13 +2055,42 @@ size_t fcd_wino_wgrad_ws_bytes(const fcd_conv_desc* d) {
 
 // called by fcd_conv2d_bwd_weight_bias (conv_wgrad.hip) when the plan says so; ws holds fcd_wino_wgrad_ws_bytes
 static int wino_wgrad_run_impl(const fcd_conv_desc* d, const float* x, const WinoCat* xcat, const float* dy,
-                               const float* relu_out, float* dw, float* db, void* ws, hipStream_t st);
+                               const float* relu_out, float* dw, float* db, void* ws, hipStream_t st, const float* v_fwd = nullptr);
 int fcd_wino_wgrad_run(const fcd_conv_desc* d, const float* x, const float* dy, const float* relu_out, float* dw,
                        float* db, void* ws, hipStream_t st) {
   return wino_wgrad_run_impl(d, x, nullptr, dy, relu_out, dw, db, ws, st);
 }
+
+extern "C" size_t fcd_conv_wino_keepv_bytes(const fcd_conv_desc* d) {
+  WinoPlan pf;
+  WinoWgPlan pw;
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("FCD_WINO_KEEPV"); on = (e && e[0] == '0') ? 0 : 1; }
+  if (!d || !on || !wino_split() || (d->C & 31) || !wino_plan(d, 0, &pf) || pf.m != 4 || !fcd_wino_wgrad_plan(d, &pw)) return 0;
+  if (pf.T != pw.T || pf.TW != pw.TW) return 0;
+  return pf.v_bytes;
+}
+
+// weight (+ bias) gradient from the forward pass's transformed input (fcd_conv2d_fwd_wino[_cat]_keepv) instead of x
+extern "C" int fcd_conv2d_bwd_weight_bias_v(const fcd_conv_desc* d, const float* v_fwd, const float* dy, const float* relu_out,
+                                            float* dw, float* db, void* ws, size_t ws_bytes, void* stream) {
+  FCD_CHECK_ARG(d && v_fwd && dy && dw, "fcd_conv2d_bwd_weight_bias_v: null pointer");
+  FCD_CHECK_ARG(fcd_conv_wino_keepv_bytes(d) > 0, "fcd_conv2d_bwd_weight_bias_v: this layer's weight gradient does not take the forward V");
+  const size_t need = fcd_wino_wgrad_ws_bytes(d);
+  if (!ws || ws_bytes < need) {
+    fcd_set_error("fcd_conv2d_bwd_weight_bias_v: workspace %zu < %zu bytes", ws_bytes, need);
+    return FCD_ERR_WORKSPACE;
+  }
+  FcdProfScope prof(FCD_K_CONV_WGRAD, (hipStream_t)stream, conv_flops(d),
+                    4.0 * (2.25 * d->N * d->C * (double)d->H * d->W + (double)d->N * d->K * d->P * d->Q + (double)d->K * d->C * 9),
+                    fcd_prof_tag_desc("wgrad", d));
+  wino_wgrad_run_impl(d, nullptr, nullptr, dy, relu_out, dw, db, ws, (hipStream_t)stream, v_fwd);
+  FCD_LAUNCH_CHECK("conv2d_bwd_weight_bias_v");
+  return FCD_OK;
+}
+
 static int wino_wgrad_run_impl(const fcd_conv_desc* d, const float* x, const WinoCat* xcat, const float* dy,
-                               const float* relu_out, float* dw, float* db, void* ws, hipStream_t st) {
+                               const float* relu_out, float* dw, float* db, void* ws, hipStream_t st, const float* v_fwd) {
   WinoWgPlan pl;
   if (!fcd_wino_wgrad_plan(d, &pl)) return 1;
   FcdProfScope pw(FCD_K_WGRAD_WINO, st, 2.0 * d->N * d->K * (double)d->P * d->Q * d->C * 9, 0.0,
@@ -2007,20 +2104,22 @@ static int wino_wgrad_run_impl(const fcd_conv_desc* d, const float* x, const Win
   const bool split = wino_split() != 0;      // dY~ written as three bf16 planes, GEMM on the bf16 matrix pipe
   {
     FcdProfScope p1(FCD_K_WINO_XFORM, st, 0.0,
-                    4.0 * ((double)d->N * d->C * d->H * d->W + (double)d->N * d->K * d->P * d->Q) + (double)pl.w_bytes / 6 * (split ? 6 : 4) +
-                        (double)pl.v_bytes, fcd_prof_tag_desc("wgrad_in", d));
+                    4.0 * ((v_fwd ? 0.0 : (double)d->N * d->C * d->H * d->W) + (double)d->N * d->K * d->P * d->Q) +
+                        (double)pl.w_bytes / 6 * (split ? 6 : 4) + (v_fwd ? 0.0 : (double)pl.v_bytes),
+                    fcd_prof_tag_desc(v_fwd ? "wgrad_in_dy_only" : "wgrad_in", d));
     WinoWgArgs ia;
     memset(&ia, 0, sizeof(ia));
     if (xcat) ia.cat = *xcat;
     ia.src = x; ia.dst = Vb; ia.N = d->N; ia.CH = d->C; ia.H = d->H; ia.W = d->W;
     ia.TH = pl.TH; ia.TW = pl.TW; ia.T = pl.T; ia.Tpad = pl.Tpad;
-    hipLaunchKernelGGL(wino_wg_input_kernel, dim3(tb, (unsigned)d->C), dim3(256), 0, st, ia);
+    if (!v_fwd) hipLaunchKernelGGL(wino_wg_input_kernel, dim3(tb, (unsigned)d->C), dim3(256), 0, st, ia);
     WinoWgArgs ya = ia;
     memset(&ya.cat, 0, sizeof(ya.cat));
     ya.src = dy; ya.mask = relu_out; ya.dst = Wb; ya.CH = d->K; ya.psum = db ? psum : nullptr;
     ya.planes = split ? (unsigned short*)Wb : nullptr;
-    hipLaunchKernelGGL(wino_wg_dy_kernel, dim3(tb, (unsigned)d->K), dim3(256), 0, st, ya);
-    if (db) hipLaunchKernelGGL(wino_psum_fin_kernel, dim3((unsigned)d->K), dim3(256), 0, st, (const float*)psum, db, d->K, (int)tb);
+    const unsigned tb2 = (unsigned)cdiv64(pl.Tpad, 512);     // two tiles per thread
+    hipLaunchKernelGGL(wino_wg_dy_kernel, dim3(tb2, (unsigned)d->K), dim3(256), 0, st, ya);
+    if (db) hipLaunchKernelGGL(wino_psum_fin_kernel, dim3((unsigned)d->K), dim3(256), 0, st, (const float*)psum, db, d->K, (int)tb2);
   }
   WinoGemmArgs ga;
   memset(&ga, 0, sizeof(ga));
@@ -2031,6 +2130,10 @@ static int wino_wgrad_run_impl(const fcd_conv_desc* d, const float* x, const Win
   ga.xcd_remap = 0;
   ga.a_ld = pl.Tpad; ga.a_batch = (long long)d->K * pl.Tpad;
   ga.b_ld = pl.Tpad; ga.b_adv = 32; ga.b_batch = (long long)d->C * pl.Tpad;
+  if (v_fwd) {                     // forward V [xi][C / 32][T][32], read transposed by the split kernel (BT)
+    ga.B = v_fwd; ga.bt = 1; ga.bt_T = pl.T;
+    ga.b_batch = (long long)(d->C / 32) * pl.T * 32;
+  }
   ga.stages_per_split = pl.sps;
   {
     FcdProfScope p2(split ? FCD_K_WINO_GEMM_SPLIT : FCD_K_WINO_GEMM, st, 2.0 * 36 * d->K * (double)d->C * (double)pl.Tpad,
@@ -2077,10 +2180,19 @@ extern "C" int fcd_conv_wino_cat_ok(const fcd_conv_desc* d) {
   return wino_cat_input_ok(pf, d->W) ? 1 : 0;
 }
 
+extern "C" int fcd_conv2d_fwd_wino_cat_keepv(const fcd_conv_desc* d, const float* const* src, const int* chans, int nsrc,
+                                             const float* U, const float* bias, float* y, int fuse_relu, void* ws,
+                                             size_t ws_bytes, float* v_keep, void* stream);
 extern "C" int fcd_conv2d_fwd_wino_cat(const fcd_conv_desc* d, const float* const* src, const int* chans, int nsrc,
                                        const float* U, const float* bias, float* y, int fuse_relu, void* ws, size_t ws_bytes,
                                        void* stream) {
+  return fcd_conv2d_fwd_wino_cat_keepv(d, src, chans, nsrc, U, bias, y, fuse_relu, ws, ws_bytes, nullptr, stream);
+}
+extern "C" int fcd_conv2d_fwd_wino_cat_keepv(const fcd_conv_desc* d, const float* const* src, const int* chans, int nsrc,
+                                             const float* U, const float* bias, float* y, int fuse_relu, void* ws,
+                                             size_t ws_bytes, float* v_keep, void* stream) {
   FCD_CHECK_ARG(d && U && y, "fcd_conv2d_fwd_wino_cat: null pointer");
+  FCD_CHECK_ARG(!v_keep || fcd_conv_wino_keepv_bytes(d) > 0, "fcd_conv2d_fwd_wino_cat_keepv: fcd_conv_wino_keepv_bytes(d) == 0 for this layer");
   WinoCat cat;
   FCD_CHECK_ARG(wino_cat_fill(&cat, src, chans, nsrc, d->C),
                 "fcd_conv2d_fwd_wino_cat: 1..3 tensors, channel counts multiples of 32 that add up to C");
@@ -2093,7 +2205,7 @@ extern "C" int fcd_conv2d_fwd_wino_cat(const fcd_conv_desc* d, const float* cons
   }
   FcdProfScope prof(FCD_K_WINO_FWD, (hipStream_t)stream, conv_flops(d), wino_bytes(pl), fcd_prof_tag_desc("wino_fwd", d));
   wino_run(pl, d->N, d->C, d->H, d->W, cat.p[0], nullptr, nullptr, 0, 0, U, bias, fuse_relu ? 1 : 0, y, nullptr, nullptr, ws,
-           (hipStream_t)stream, &cat, nullptr);
+           (hipStream_t)stream, &cat, nullptr, v_keep);
   FCD_LAUNCH_CHECK("conv2d_fwd_wino_cat");
   return FCD_OK;
 }

@@ -34,7 +34,8 @@ typedef __attribute__((address_space(1))) const void gbl_void_t;
 int fcd_wino_mode_now();   // conv_wino.hip: 0 = direct kernels only (tests' A/B switch), 2 / 4 otherwise
 
 // W2_EXP: diagnostic builds only (WRONG results): 1 = no filter DMA / patch loads / LDS stores in the loop, 2 = no barrier in the
-// loop, 4 = operands from registers instead of LDS, 8 = no transform adds
+// loop, 4 = operands from registers instead of LDS, 8 = no transform adds, 64 = ONE patch buffer (racy; LDS 68 KB: is a
+// second resident workgroup per CU worth a second barrier per stage?)
 #ifndef W2_EXP
 #define W2_EXP 0
 #endif
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wino2_kernel(Wino2Args a) {
   constexpr int U_PER_W = (U_INSTR + NW - 1) / NW;
   __shared__ __attribute__((aligned(16))) float su0[U_STAGE];
   __shared__ __attribute__((aligned(16))) float su1[U_STAGE];
-  __shared__ __attribute__((aligned(16))) float sx[2 * XS_SZ];
+  __shared__ __attribute__((aligned(16))) float sx[((W2_EXP & 64) ? 1 : 2) * XS_SZ];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = wave & 3, hrow = wave >> 2;
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wino2_kernel(Wino2Args a) {
   {                                                                                                  \
     const int cch = (CH);                                                                             \
     const bool have_next = cch + 1 < a.nchunks;                                                       \
-    const int xb = cch & 1;                                                                           \
+    const int xb = (W2_EXP & 64) ? 0 : (cch & 1);                                                     \
     if (have_next && !(W2_EXP & 1)) {                                                                \
       W2_DMA(cch + 1, UNXT)                                                                           \
       W2_LOAD_X(cch + 1)                                                                              \
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wino2_kernel(Wino2Args a) {
       }                                                                                              \
     }                                                                                                \
     }                                                                                                \
-    if (have_next && !(W2_EXP & 1)) W2_STORE_X(xb ^ 1, cch + 1)                                       \
+    if (have_next && !(W2_EXP & 1)) W2_STORE_X(((W2_EXP & 64) ? 0 : (xb ^ 1)), cch + 1)               \
     if (!(W2_EXP & 2)) __syncthreads();                                                                                 \
   }
 

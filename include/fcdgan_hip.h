@@ -116,6 +116,22 @@ int fcd_conv2d_bwd_data_wino_cat(const fcd_conv_desc* d, const float* dy, const 
 int fcd_conv2d_bwd_weight_bias_cat(const fcd_conv_desc* d, const float* const* src, const int* chans, int nsrc,
                                    const float* dy, const float* relu_out, float* dw, float* db, void* ws, size_t ws_bytes,
                                    void* stream);
+/* ---- the forward pass's transformed input kept for the weight gradient (round 3).  The weight gradient of a wide 3x3 layer
+ * (Winograd form) needs V = B^T x B of the layer input -- exactly what the forward pass just computed.  With
+ * fcd_conv_wino_keepv_bytes(d) > 0 the caller may hand the forward call a buffer of that size (v_keep); it receives V
+ * [36][C/32][tiles][32], and fcd_conv2d_bwd_weight_bias_v() computes dw / db from it and dy alone (x is not read again:
+ * the weight gradient's own input transform, 1.6 ms per Demo_RSSS step, disappears; the GEMM reads V transposed).  The
+ * autograd tape of reference Module.py:25-31 keeps x for the weight gradient; here it keeps V instead.  Workspace of the
+ * _v call: fcd_conv2d_bwd_weight_ws_bytes(d). */
+size_t fcd_conv_wino_keepv_bytes(const fcd_conv_desc* d);
+int fcd_conv2d_fwd_wino_keepv(const fcd_conv_desc* d, const float* x, const float* U, const float* bias, float* y,
+                              int fuse_relu, float* pool_y, unsigned char* code, void* ws, size_t ws_bytes, float* v_keep,
+                              void* stream);
+int fcd_conv2d_fwd_wino_cat_keepv(const fcd_conv_desc* d, const float* const* src, const int* chans, int nsrc, const float* U,
+                                  const float* bias, float* y, int fuse_relu, void* ws, size_t ws_bytes, float* v_keep,
+                                  void* stream);
+int fcd_conv2d_bwd_weight_bias_v(const fcd_conv_desc* d, const float* v_fwd, const float* dy, const float* relu_out, float* dw,
+                                 float* db, void* ws, size_t ws_bytes, void* stream);
 /* dx from dy, dy * [relu_out > 0] (relu_out != NULL) or the pooled gradient routed by pool_code */
 int fcd_conv2d_bwd_data_wino(const fcd_conv_desc* d, const float* dy, const float* relu_out,
                              const unsigned char* pool_code, const float* U, float* dx, void* ws,
