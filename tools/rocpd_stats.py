@@ -12,9 +12,14 @@ tot = sum(r[2] for r in rows)
 out = ['# rocprofv3 --kernel-trace summary (%s)' % sys.argv[1].split('/')[-2], '',
        'total kernel time %.2f ms over %d dispatches' % (tot / 1e6, sum(r[1] for r in rows)), '',
        '| kernel | calls | total ms | avg us | min us | max us | % | vgpr | agpr | lds |', '|---|---|---|---|---|---|---|---|---|---|']
-for r in rows[:40]:
+for r in rows[:60]:
     out.append('| %s | %d | %.2f | %.1f | %.1f | %.1f | %.1f | %s | %s | %s |' % (
         r[0][:120], r[1], r[2] / 1e6, r[3] / 1e3, r[4] / 1e3, r[5] / 1e3, 100.0 * r[2] / tot, r[6], r[7], r[8]))
+host = [r for r in rows if ('at::' in r[0] or 'rocclr' in r[0] or 'Cijk' in r[0] or 'hipcub' in r[0] or 'rocprim' in r[0])]
+out += ['', '## host-framework (ATen / runtime) kernels: %.2f ms total, %d dispatches' % (sum(r[2] for r in host) / 1e6, sum(r[1] for r in host)), '',
+        '| kernel | calls | total ms | avg us |', '|---|---|---|---|']
+for r in host[:25]:
+    out.append('| %s | %d | %.2f | %.1f |' % (r[0][:150], r[1], r[2] / 1e6, r[3] / 1e3))
 out += ['', '## conv kernels by launch geometry (top 40 by time)', '',
         '| kernel | grid | calls | total ms | avg us |', '|---|---|---|---|---|']
 rows2 = db.execute("select name, grid_x, grid_y, grid_z, count(*), sum(duration), avg(duration) from kernels "
