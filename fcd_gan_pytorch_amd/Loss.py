@@ -124,14 +124,6 @@ class PerceptionLoss(nn.Module):
         taps = {}
         layers = list(self.net)
         i = 0
-        # conv1_1 + ReLU + conv1_2 + ReLU + MaxPool on band images in one fused pair (no tap inside: _TAPS[-1] = 3 is the
-        # ReLU after conv1_2, only reached with feature_layer = 5)
-        if (single_band and len(layers) > 4 and isinstance(layers[0], nn.Conv2d) and isinstance(layers[2], nn.Conv2d)
-                and isinstance(layers[4], nn.MaxPool2d) and not any(t in self.feature_layer_list for t in (1, 3))):
-            w1 = self._first_filter_1ch()
-            if ops.vgg_stem_supported(z, w1, layers[0].bias, layers[2].weight, layers[2].bias):
-                z = ops.vgg_stem_pool(z, w1, layers[0].bias, layers[2].weight, layers[2].bias)
-                i = 5
         while i < len(layers):
             layer = layers[i]
             if isinstance(layer, nn.Conv2d):

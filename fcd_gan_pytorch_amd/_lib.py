@@ -92,8 +92,6 @@ _SIGS = {
     'fcd_conv_s2_dgrad_pack': (c_int, [P, P, c_int, c_int, P]),
     'fcd_conv2d_bwd_data_s2': (c_int, [POINTER(ConvDesc), P, P, P, P, P]),
     'fcd_conv_wino2_plan': (c_int, [POINTER(ConvDesc), c_int]),
-    'fcd_vgg_stem_ok': (c_int, [POINTER(ConvDesc)]),
-    'fcd_vgg_stem_fwd_pool': (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, P, P, P]),
     'fcd_conv_wino2_filter_elems': (c_int64, [c_int, c_int, c_int]),
     'fcd_conv_wino2_pack': (c_int, [P, P, c_int, c_int, c_int, P]),
     'fcd_conv2d_fwd_wino2': (c_int, [POINTER(ConvDesc), P, P, P, P, c_int, P, c_float, P, P, P, P]),

@@ -402,64 +402,6 @@ class _ConvReluPool(torch.autograd.Function):
         return dx, None, None
 
 
-class _VggStemPool(torch.autograd.Function):
-    """maxpool2(relu(conv3x3(relu(conv3x3(band, w1) + b1), w2) + b2)) on one-channel band images with frozen filters --
-    the first five entries of the VGG16 feature stack of the perception term (reference Loss.py:45-53) -- in two launches:
-    a mask-only pass of the first layer and the fused F(2x2,3x3) kernel whose loader recomputes that layer's activation
-    from the band (fcd_vgg_stem_fwd_pool).  Backward: pooled data gradient of the second layer, then the first layer's
-    data gradient gated by the bit mask (same kernels as the unfused path)."""
-
-    @staticmethod
-    def forward(ctx, band, w1, b1, w2, b2):
-        band = _dev(band, 'band images')
-        N, _, H, W = band.shape
-        K1, K2 = w1.shape[0], w2.shape[0]
-        d2 = _desc((N, K1, H, W), w2.shape, 1, 1)
-        d1 = _desc(band.shape, w1.shape, 1, 1)
-        yp = torch.empty((N, K2, H // 2, W // 2), dtype=torch.float32, device=band.device)
-        code = torch.empty((N, K2, H // 2, W // 2), dtype=torch.uint8, device=band.device)
-        bits = torch.empty(lib.fcd_conv2d_relu_bits_bytes(ctypes.byref(d1)), dtype=torch.uint8, device=band.device)
-        check(lib.fcd_vgg_stem_fwd_pool(ctypes.byref(d2), _p(band), _p(packed_weight(w1, 0)), _p(b1),
-                                        _p(wino2_weight(w2, 0)), _p(b2), _p(yp), _p(code), _p(bits), _stream()),
-              'fcd_vgg_stem_fwd_pool')
-        ctx.save_for_backward(w1, w2, code, bits)
-        ctx.shapes = (tuple(band.shape), (N, K1, H, W))
-        return yp
-
-    @staticmethod
-    def backward(ctx, dyp):
-        w1, w2, code, bits = ctx.saved_tensors
-        bshape, mshape = ctx.shapes
-        dyp = _dev(dyp, 'pooled grad')
-        dband = None
-        if ctx.needs_input_grad[0]:
-            d2 = _desc(mshape, w2.shape, 1, 1)
-            dmid = torch.empty(mshape, dtype=torch.float32, device=dyp.device)
-            _bwd_data_conv(d2, dyp, w2, dmid, code=code)
-            d1 = _desc(bshape, w1.shape, 1, 1)
-            dband = torch.empty(bshape, dtype=torch.float32, device=dyp.device)
-            check(lib.fcd_conv2d_bwd_data_bits(ctypes.byref(d1), _p(dmid), _p(bits), _p(packed_weight(w1, 1)), _p(dband),
-                                               _stream()), 'fcd_conv2d_bwd_data_bits')
-        return dband, None, None, None, None
-
-
-def vgg_stem_supported(band, w1, b1, w2, b2):
-    if band.dim() != 4 or band.shape[1] != 1 or tuple(w1.shape[1:]) != (1, 3, 3) or tuple(w2.shape[2:]) != (3, 3):
-        return False
-    if any(t is not None and t.requires_grad for t in (w1, b1, w2, b2)) or w2.shape[1] != w1.shape[0]:
-        return False
-    N, _, H, W = band.shape
-    if (H | W) & 1:
-        return False
-    d2 = _desc((N, w1.shape[0], H, W), w2.shape, 1, 1)
-    return band.is_cuda and bool(lib.fcd_vgg_stem_ok(ctypes.byref(d2)))
-
-
-def vgg_stem_pool(band, w1, b1, w2, b2):
-    """See :class:`_VggStemPool`; check with :func:`vgg_stem_supported` first."""
-    return _VggStemPool.apply(band.contiguous(), w1, b1, w2, b2)
-
-
 def conv_relu_pool_supported(x, weight):
     K, C, R, S = weight.shape
     if os.environ.get('FCD_NO_POOLFUSE'):          # A/B switch for benchmarking

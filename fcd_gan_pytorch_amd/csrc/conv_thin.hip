@@ -294,7 +294,6 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_thin_kernel(const float* __re
       if (bits != nullptr)        // W % 4 == 0: element index / 4 = strip index
         bits[(((size_t)n * K + k) * H + h) * (W >> 2) + ((w0 + col) >> 2)] =
             (unsigned char)((a4[0] > 0.f) | ((a4[1] > 0.f) << 1) | ((a4[2] > 0.f) << 2) | ((a4[3] > 0.f) << 3));
-      if (y == nullptr) continue;        // mask only (fcd_vgg_stem_fwd_pool: the next layer recomputes these values itself)
       if (vec_ok) {
         f32x4_t v = {a4[0], a4[1], a4[2], a4[3]};
         *(f32x4_t*)o = v;

@@ -74,8 +74,6 @@ struct Wino2Args {
   unsigned char* code_out;
   const float* residual;
   const float* slope_ptr;
-  const float* w1;      // SRC == 3: T-layout pack of the ONE-channel 3x3 filter in front (taps of row k at w1 + 20 k) ...
-  const float* b1;      // ... and its bias: the source is relu(conv3x3(x, w1) + b1), computed in the loader (x: (N, 1, H, W))
   float slope_imm;
   int relu, act_slope;
   int N, C, H, W, K, Hp, Wp, nchunks, tiles_p, tiles_q, xcd_remap;
@@ -116,11 +114,6 @@ __global__ void wino2_pack_kernel(const float* __restrict__ w, float* __restrict
   }
 }
 
-// SRC == 3 (round 3): the layer's input is never read -- it is relu(conv3x3(band) + b1) of a ONE-channel image (VGG
-// conv1_1 on a band replicated to three channels, Loss.py:52-53) and is recomputed by the loader: thread t < patch pixels
-// keeps the 3 x 3 band window of ITS patch pixel in nine registers for the whole kernel and forms the stage's 8 channels
-// with 72 FMAs (filter taps: wave-uniform scalar loads) -- same fma order as conv3x3_fwd_thin_kernel, bit-identical
-// values.  The 64-channel activation (3.5 GB at 208 band images) is then neither written by conv1_1 nor read here.
 template <int SRC, int EPI, int NW, int W2_KS, int PG>     // PG: pairs of tile rows per wave (2 PG accumulators per xi)
 __global__ __launch_bounds__(64 * NW) void conv_wino2_kernel(Wino2Args a) {
   constexpr int NT = 64 * NW;                         // threads
@@ -132,8 +125,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wino2_kernel(Wino2Args a) {
   // groups) collide two ways on every operand read
   constexpr int W2_PL = (W2_TH * W2_RP + 63) / 64 * 64;
   constexpr int X_ELEMS = W2_CB * W2_PH * W2_PW;
-  constexpr int X_PER_T = (SRC == 3) ? W2_CB : (X_ELEMS + NT - 1) / NT;
-  static_assert(SRC != 3 || W2_PH * W2_PW <= NT, "SRC 3: one patch pixel per thread");
+  constexpr int X_PER_T = (X_ELEMS + NT - 1) / NT;
   constexpr int XS_SZ = W2_CB * W2_PL;
   constexpr int U_STAGE = W2_KS * W2_SLAB;            // floats per stage of the filter pipeline
   constexpr int U_INSTR = U_STAGE / 256;              // wave-instructions of 1 KiB per stage
@@ -181,24 +173,8 @@ __global__ __launch_bounds__(64 * NW) void conv_wino2_kernel(Wino2Args a) {
   // .x copy exists : 1, .y copy exists : 1} -- staging registers are what pushes this kernel against the 256-VGPR limit
   unsigned x_pk[X_PER_T];
   const int ih0 = p0 - 1, iw0 = q0 - 1;
-  // SRC == 3: patch pixel of this thread, its 3 x 3 band window, where its values go
-  const bool s3_act = SRC == 3 && tid < W2_PH * W2_PW;
-  const int s3_ph = tid / W2_PW, s3_pw = tid % W2_PW;
-  const bool s3_ok = s3_act && ih0 + s3_ph >= 0 && iw0 + s3_pw >= 0 && ih0 + s3_ph < a.H && iw0 + s3_pw < a.W;
-  const int s3_lo = s3_ph * W2_RP + 2 * s3_pw;
-  const bool s3_x = s3_ph < W2_TH, s3_y = s3_ph >= 2;
-  float bw[9];
-  if (SRC == 3) {
-    const float* band = a.x + (size_t)n * a.H * a.W;
-#pragma unroll
-    for (int t9 = 0; t9 < 9; ++t9) {
-      const int ih = ih0 + s3_ph + t9 / 3 - 1, iw = iw0 + s3_pw + t9 % 3 - 1;
-      bw[t9] = (s3_ok && ih >= 0 && iw >= 0 && ih < a.H && iw < a.W) ? band[(size_t)ih * a.W + iw] : 0.f;
-    }
-  }
 #pragma unroll
   for (int i = 0; i < X_PER_T; ++i) {
-    if (SRC == 3) break;
     const int idx = tid + i * NT;
     const int cc = idx / (W2_PH * W2_PW), rem = idx % (W2_PH * W2_PW);
     const int ph = rem / W2_PW, pw = rem % W2_PW;
@@ -232,15 +208,6 @@ __global__ __launch_bounds__(64 * NW) void conv_wino2_kernel(Wino2Args a) {
     }                                                                                                \
   }
 #define W2_LOAD_X(CH)                                                                                \
-  if (SRC == 3) {                                                                                    \
-    _Pragma("unroll") for (int i = 0; i < X_PER_T; ++i) {                                            \
-      const int k_ = min((CH) * W2_CB + i, a.C - 1);                                                 \
-      const float* wk_ = a.w1 + (size_t)k_ * 20;                 /* wave-uniform: scalar loads */     \
-      float acc_ = a.b1 ? a.b1[k_] : 0.f;                                                            \
-      _Pragma("unroll") for (int t9 = 0; t9 < 9; ++t9) acc_ = fmaf(bw[t9], wk_[t9], acc_);           \
-      xr[i] = acc_ > 0.f ? acc_ : 0.f;                                                               \
-    }                                                                                                \
-  } else                                                                                             \
   {                                                                                                  \
     const int cleft = a.C - (CH) * W2_CB;                                                            \
     const bool tail = cleft < W2_CB;                                                                 \
@@ -256,17 +223,6 @@ __global__ __launch_bounds__(64 * NW) void conv_wino2_kernel(Wino2Args a) {
     }                                                                                                \
   }
 #define W2_STORE_X(BUF, CH)                                                                          \
-  if (SRC == 3) {                                                                                    \
-    const int cleft = a.C - (CH) * W2_CB;                                                            \
-    if (s3_act) {                                                                                    \
-      _Pragma("unroll") for (int i = 0; i < X_PER_T; ++i) {                                          \
-        const float xv = (s3_ok && i < cleft) ? xr[i] : 0.f;                                         \
-        const int lo_ = i * W2_PL + s3_lo;                                                           \
-        if (s3_x) sx[(BUF) * XS_SZ + lo_] = xv;                                                      \
-        if (s3_y) sx[(BUF) * XS_SZ + lo_ - 2 * W2_RP + 1] = xv;                                      \
-      }                                                                                              \
-    }                                                                                                \
-  } else                                                                                             \
   {                                                                                                  \
     const int cleft = a.C - (CH) * W2_CB;                                                            \
     _Pragma("unroll") for (int i = 0; i < X_PER_T; ++i) {                                            \
@@ -540,60 +496,6 @@ extern "C" int fcd_conv2d_fwd_wino2(const fcd_conv_desc* d, const float* x, cons
   if (pool_y) w2_launch<0, 1>(a, d->C, (hipStream_t)stream); else w2_launch<0, 0>(a, d->C, (hipStream_t)stream);
   FCD_LAUNCH_CHECK("conv2d_fwd_wino2");
   return FCD_OK;
-}
-
-// conv_igemm.hip: y = [relu](conv3x3(x, w) + b) of a layer with <= 4 input channels, ReLU mask as one byte per 1 x 4 strip;
-// y == NULL: mask only
-int fcd_try_fwd_thin(const fcd_conv_desc* d, const float* x, const float* wp, const float* bias, float* y, int relu,
-                     hipStream_t st, unsigned char* bits);
-
-// The first two VGG16 layers on a ONE-channel image (a band replicated to three channels, reference Loss.py:45-53:
-// features[0..4] = conv1_1, ReLU, conv1_2, ReLU, MaxPool):
-//   pool_y, code = maxpool2(relu(conv3x3(relu(conv3x3(band, w1) + b1), w2) + b2))
-// d describes the SECOND convolution (N, C = K1, H, W, K).  wp1: fcd_conv_pack_weights(mode 0) of the (K1, 1, 3, 3) filter,
-// U2: fcd_conv_wino2_pack(mode 0) of the second.  bits1 (fcd_conv2d_relu_bits_bytes of the FIRST layer's descriptor): ReLU mask
-// of the first layer for fcd_conv2d_bwd_data_bits -- the only thing the backward pass needs from it; its 64-channel
-// activation is never materialised.
-extern "C" int fcd_vgg_stem_fwd_pool(const fcd_conv_desc* d, const float* band, const float* wp1, const float* b1,
-                                     const float* U2, const float* b2, float* pool_y, unsigned char* code,
-                                     unsigned char* bits1, void* stream) {
-  FCD_CHECK_ARG(d && band && wp1 && U2 && pool_y && code && bits1, "fcd_vgg_stem_fwd_pool: null pointer");
-  FCD_CHECK_ARG(fcd_conv_wino2_plan(d, 0) && w2_waves() == 8 && (d->C % 8) == 0 && (d->W & 3) == 0,
-                "fcd_vgg_stem_fwd_pool: the second layer must run on the fused F(2x2,3x3) kernel (fcd_vgg_stem_ok)");
-  fcd_conv_desc d1 = *d;
-  d1.C = 1; d1.K = d->C; d1.P = d->H; d1.Q = d->W;
-  {
-    FcdProfScope prof(FCD_K_CONV_FWD, (hipStream_t)stream, 2.0 * d1.N * d1.K * (double)d1.P * d1.Q * 9,
-                      4.0 * d1.N * (double)d1.H * d1.W * (1.0 + d1.K / 16.0), fcd_prof_tag_desc("fwd_bits_only", &d1));
-    FCD_CHECK_ARG(fcd_try_fwd_thin(&d1, band, wp1, b1, nullptr, 1, (hipStream_t)stream, bits1) == 0,
-                  "fcd_vgg_stem_fwd_pool: first layer has no bit-mask kernel");
-  }
-  Wino2Args a;
-  memset(&a, 0, sizeof(a));
-  a.x = band; a.U = U2; a.bias = b2; a.pool_y = pool_y; a.code_out = code; a.relu = 1;
-  a.w1 = wp1; a.b1 = b1;
-  a.N = d->N; a.C = d->C; a.H = d->H; a.W = d->W; a.K = d->K;
-  const double flops = 2.0 * d->N * d->K * (double)d->P * d->Q * d->C * 9;
-  const double bytes = 4.0 * ((double)d->N * d->H * d->W + 0.3125 * d->N * d->K * d->P * d->Q + (double)d->K * d->C * 16);
-  FcdProfScope prof(FCD_K_WINO2_FWD, (hipStream_t)stream, flops, bytes, fcd_prof_tag_desc("w2_stem_fwd_pool", d));
-  a.tiles_q = cdiv(a.W, W2_TW);
-  a.xcd_remap = w2_xcd();
-  a.tiles_p = cdiv(a.H, 8);
-  a.nchunks = cdiv(d->C, 8);
-  hipLaunchKernelGGL((conv_wino2_kernel<3, 1, 8, 2, 1>), dim3((unsigned)(a.N * a.tiles_p * a.tiles_q)), dim3(512), 0,
-                     (hipStream_t)stream, a);
-  FCD_LAUNCH_CHECK("vgg_stem_fwd_pool");
-  return FCD_OK;
-}
-
-// 1 when fcd_vgg_stem_fwd_pool takes this (second-layer) descriptor
-extern "C" int fcd_vgg_stem_ok(const fcd_conv_desc* d) {
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("FCD_VGG_STEM"); on = (e && e[0] == '0') ? 0 : 1; }
-  if (!d || !on || !fcd_conv_wino2_plan(d, 0) || w2_waves() != 8 || (d->C % 8) != 0 || (d->W & 3) != 0 || d->H < 2) return 0;
-  fcd_conv_desc d1 = *d;
-  d1.C = 1; d1.K = d->C; d1.P = d->H; d1.Q = d->W;
-  return fcd_conv2d_relu_bits_bytes(&d1) > 0 ? 1 : 0;
 }
 
 // dx = conv_transpose(dy') with dy' = dy, dy * [relu_out > 0], or the pooled gradient routed by pool_code

@@ -132,17 +132,6 @@ int fcd_conv2d_fwd_wino_cat_keepv(const fcd_conv_desc* d, const float* const* sr
                                   void* stream);
 int fcd_conv2d_bwd_weight_bias_v(const fcd_conv_desc* d, const float* v_fwd, const float* dy, const float* relu_out, float* dw,
                                  float* db, void* ws, size_t ws_bytes, void* stream);
-/* ---- the first two VGG16 layers of the perception term on ONE-channel band images (reference Loss.py:45-53: a band
- * repeated to three channels through features[0..4]; the summed first filter is a 1-channel 3x3 conv).
- *   pool_y, code = maxpool2(relu(conv3x3(relu(conv3x3(band, w1) + b1), w2) + b2))
- * The loader of the fused F(2x2,3x3) kernel recomputes the first layer's activation from the band (9 registers per patch
- * pixel, 72 FMAs per 8 channels), so the 64-channel full-resolution tensor between the two layers is never written or read.
- * d = descriptor of the SECOND layer; wp1 = fcd_conv_pack_weights(mode 0) of the (C, 1, 3, 3) first filter; U2 =
- * fcd_conv_wino2_pack(mode 0) of the second; bits1 = ReLU mask of the first layer (fcd_conv2d_relu_bits_bytes of ITS
- * descriptor) for fcd_conv2d_bwd_data_bits.  fcd_vgg_stem_ok(d): 1 when the pair runs this way. */
-int fcd_vgg_stem_ok(const fcd_conv_desc* d);
-int fcd_vgg_stem_fwd_pool(const fcd_conv_desc* d, const float* band, const float* wp1, const float* b1, const float* U2,
-                          const float* b2, float* pool_y, unsigned char* code, unsigned char* bits1, void* stream);
 /* dx from dy, dy * [relu_out > 0] (relu_out != NULL) or the pooled gradient routed by pool_code */
 int fcd_conv2d_bwd_data_wino(const fcd_conv_desc* d, const float* dy, const float* relu_out,
                              const unsigned char* pool_code, const float* U, float* dx, void* ws,
