@@ -14,6 +14,7 @@ How it differs from a layer-by-layer module tree:
    ``groups=2`` (see include/fcdgan_hip.h: fcd_bn_act_fwd).
 CUDA/ROCm tensors only: there is no CPU fallback in the product.
 """
+import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -204,13 +205,24 @@ class Segmentor(nn.Module):
         (w0, b0), (w1, b1) = self.inc._folded_params()
         n = x1_raw.shape[0]
         feats = []
-        for x, mean, std in ((x1_raw, stats[0], stats[1]), (x2_raw, stats[2], stats[3])):
-            m = torch.as_tensor(mean, dtype=torch.float64, device=w0.device)[:w0.shape[1]]
-            s = torch.as_tensor(std, dtype=torch.float64, device=w0.device)[:w0.shape[1]]
-            wd = w0.double()
-            w_aug = torch.cat([wd / s.view(1, -1, 1, 1), -(wd * (m / s).view(1, -1, 1, 1)).sum(dim=1, keepdim=True)], dim=1)
+        # the augmented first-layer filters depend on the folded weights and the statistics only: built once per (weights,
+        # statistics) and kept on the module, so the packed-filter cache of ops.conv2d (keyed on the tensor object) hits on
+        # every later batch instead of re-folding and re-packing per call
+        key = (id(w0), w0._version, tuple(tuple(float(v) for v in np.asarray(t, dtype=np.float64).reshape(-1)) for t in stats))
+        hit = self.__dict__.get('_fcd_raw_filters')
+        if hit is None or hit[0] != key:
+            augs = []
+            for mean, std in ((stats[0], stats[1]), (stats[2], stats[3])):
+                m = torch.as_tensor(mean, dtype=torch.float64, device=w0.device)[:w0.shape[1]]
+                s = torch.as_tensor(std, dtype=torch.float64, device=w0.device)[:w0.shape[1]]
+                wd = w0.double()
+                augs.append(torch.cat([wd / s.view(1, -1, 1, 1), -(wd * (m / s).view(1, -1, 1, 1)).sum(dim=1, keepdim=True)],
+                                      dim=1).float().contiguous())
+            hit = (key, augs)
+            self.__dict__['_fcd_raw_filters'] = hit
+        for x, w_aug in ((x1_raw, hit[1][0]), (x2_raw, hit[1][1])):
             xa = torch.cat([x, valid.to(x.dtype)], dim=1)
-            feats.append(ops.conv2d(xa, w_aug.float().contiguous(), b0, 1, 1, relu=True))
+            feats.append(ops.conv2d(xa, w_aug, b0, 1, 1, relu=True))
         f = ops.conv2d(torch.cat(feats, dim=0), w1, b1, 1, 1, relu=True)
         return self._after_inc(f, n)
 

@@ -171,7 +171,12 @@ class _FlatOptimizer:
             if g is not None:
                 view.copy_(g)
             p.grad = view
-        self._pending[self._bucket_of[i]] -= 1
+        b = self._bucket_of[i]
+        if b < self._next:
+            # a second backward pass reached a parameter whose bucket already left (begin_overlap arms exactly ONE pass)
+            raise RuntimeError('fcd optimizer: gradient of parameter %d arrived after its bucket was all-reduced; call '
+                               'begin_overlap() once per backward pass, or allreduce_grads() without it' % i)
+        self._pending[b] -= 1
         self._launch_ready_buckets()
 
     _launched_early = 0

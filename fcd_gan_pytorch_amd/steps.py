@@ -70,6 +70,11 @@ def _side_stream(device):
     import os
     if device.type != 'cuda' or os.environ.get('FCD_STEP_OVERLAP') != '1':
         return None
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        # the side stream would issue the Discriminator's collectives and read workspaces / gradient buffers the main stream
+        # owns without record_stream: not supported (and not measured) under data parallelism
+        raise RuntimeError('FCD_STEP_OVERLAP=1 is a single-GPU experiment; unset it for multi-GPU runs')
     s = _SIDE.get(device.index)
     if s is None:
         from . import _ops
