@@ -689,7 +689,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void wino_gem
 // kernel (three bf16 planes); B (the transformed activations V, fp32 in HBM and in LDS) is split in registers right
 // before the MFMAs.  Lane (row, half) owns reduction elements half*16 .. half*16+15 of the 32-chunk, 8 per MFMA step.
 #ifndef FCD_SEXP
-#define FCD_SEXP 0   // diagnostic builds only (wrong results): 1 no operand split, 2 one MFMA of the six, 4 no barrier, 8 no DMA
+#define FCD_SEXP 0   // diagnostic builds only (wrong results): 1 no operand split, 2 one MFMA of the six, 4 no barrier, 8 no DMA,
+                     // 64 no A-operand DMA (128-tile kernel), 128 no C stores (128-tile kernel)
 #endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -800,9 +801,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void wino_gem
   {                                                                                              \
     const unsigned short* as_ = Ab + (size_t)fb * a.a_batch + (size_t)fq * KC;                   \
     const float* bs_ = BT ? Bb + (size_t)fb * a.b_batch : Bb + (size_t)fb * a.b_batch + (size_t)fq * a.b_adv; \
-    _Pragma("unroll") for (int j = 0; j < PPW_A; ++j)                                            \
+    if (!(FCD_SEXP & 64)) { _Pragma("unroll") for (int j = 0; j < PPW_A; ++j)                    \
       __builtin_amdgcn_global_load_lds((gbl_void_t*)(as_ + a_goff[j]),                           \
-                                       (lds_void_t*)((SA) + (wave + NW * j) * 512), 16, 0, 0);   \
+                                       (lds_void_t*)((SA) + (wave + NW * j) * 512), 16, 0, 0); } \
     _Pragma("unroll") for (int j = 0; j < PPW_B; ++j) {                                          \
       /* BT: tile (q_beg + fq) * 32 + t of the forward V, clamped to the last real tile (A is zero there) */ \
       const long long bo_ = BT ? (long long)b_goff[j] + min((long long)(q_beg + fq) * KC + bt_t[j], a.bt_T - 1) * 32 \
@@ -898,7 +899,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void wino_gem
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int n = n0 + wn * 64 + j * 32 + l31;
-          if (m < a.M && n < ldc) Cb[(size_t)m * ldc + n] = acc[i][j][r];
+          if (m < a.M && n < ldc && (!(FCD_SEXP & 128) || acc[i][j][r] == 12345.f)) Cb[(size_t)m * ldc + n] = acc[i][j][r];
           acc[i][j][r] = 0.f;
         }
       }
