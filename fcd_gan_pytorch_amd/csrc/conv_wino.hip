@@ -535,6 +535,9 @@ struct WinoGemmArgs {
   int batches, xb;        // blockIdx.y = group of xb consecutive batches (transform positions) run by ONE workgroup as a
                           // single software pipeline: the first slabs of batch b + 1 are in flight while batch b's last
                           // MFMAs run and its C tile is stored -- no pipeline refill per batch
+  int c_blk;              // split kernels: C in MFMA-native 32 x 32 blocks [xi][M/32][c_tblk][half*4 + r/4][32 cols][r%4] (one
+  int c_mblk, c_tblk;     // dwordx4 store per four accumulator registers: 16 / 32 stores per lane and batch instead of 64 / 128);
+  long long c_batch;      // c_batch = floats per xi.  Read back by wino_output_blk_kernel.
   int bt;                 // split kernel, weight gradient: B is the FORWARD pass's V [xi][N / 32][bt_T][32] (GEMM row n = channel,
   long long bt_T;         // reduction = tile index): b_batch = elements per xi, the reduction runs to bt_T (rows clamped), b_ld / b_adv unused
 };
@@ -888,6 +891,24 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void wino_gem
       WS_STEP(sa0, sb0, sa1, sb1)
       if (qc + 1 < Q) WS_STEP(sa1, sb1, sa0, sb0)
     }
+    if (a.c_blk) {             // MFMA-native blocks: registers 4g .. 4g + 3 of a lane are rows (8g + 4 half) + 0..3 of ITS column
+      float* Cb = a.C + (size_t)(b_first + cb) * a.c_batch;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int mb = (m0 + wm * 64 + i * 32) >> 5, tb = (n0 + wn * 64 + j * 32) >> 5;
+          if (mb < a.c_mblk && tb < a.c_tblk) {
+            float* blk = Cb + ((size_t)mb * a.c_tblk + tb) * 1024 + (half * 4 * 32 + l31) * 4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              *(f32x4*)(blk + g * 128) = f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        }
+      continue;
+    }
     int ldc = a.N;
     asm volatile("" : "+s"(ldc));
     float* Cb = a.C + ((size_t)blockIdx.z * a.batches + (b_first + cb)) * a.M * ldc;
@@ -1066,6 +1087,24 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split256_kernel(WinoGemmArgs
     for (int qc = 0; qc < Q; qc += 2) {
       Y_STEP(sa0, sb0, sa1, sb1)
       if (qc + 1 < Q) Y_STEP(sa1, sb1, sa0, sb0)
+    }
+    if (a.c_blk) {
+      float* Cb = a.C + (size_t)(b_first + cb) * a.c_batch;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int mb = (m0 + wm * 128 + i * 32) >> 5, tb = (n0 + wn * 64 + j * 32) >> 5;
+          if (mb < a.c_mblk && tb < a.c_tblk) {
+            float* blk = Cb + ((size_t)mb * a.c_tblk + tb) * 1024 + (half * 4 * 32 + l31) * 4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              *(f32x4*)(blk + g * 128) = f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        }
+      continue;
     }
     int ldc = a.N;
     asm volatile("" : "+s"(ldc));
