@@ -1415,21 +1415,14 @@ struct WinoOutArgs {
   int K, P, Q, TH, TW, relu;
   long long T;
   WinoCat cat;          // data gradient of a virtually concatenated input: channel k of dx goes to its own tensor (cat.n > 0)
+  int tblk;             // wino_output_blk_kernel: Mb in the split GEMM's 32 x 32 blocks (WinoGemmArgs.c_blk): blocks per
+  long long xs_blk;     // row block, floats per xi
 };
 
 template <int MM>
-__global__ __launch_bounds__(256) void wino_output_kernel(WinoOutArgs a) {
+__device__ __forceinline__ void wino_out_one(const WinoOutArgs& a, const float (&mv)[WinoMat<MM>::A][WinoMat<MM>::A], int k,
+                                             long long t) {
   constexpr int A = WinoMat<MM>::A;
-  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-  const int k = blockIdx.y;
-  if (t >= a.T) return;
-  const size_t xs = (size_t)a.K * a.T;
-  const float* mp = a.Mb + (size_t)k * a.T + t;
-  float mv[A][A];
-#pragma unroll
-  for (int i = 0; i < A; ++i)
-#pragma unroll
-    for (int j = 0; j < A; ++j) mv[i][j] = mp[(size_t)(i * A + j) * xs];
   float t1[MM][A];   // A^T M
 #pragma unroll
   for (int i = 0; i < MM; ++i)
@@ -1513,6 +1506,45 @@ __global__ __launch_bounds__(256) void wino_output_kernel(WinoOutArgs a) {
   }
 }
 
+template <int MM>
+__global__ __launch_bounds__(256) void wino_output_kernel(WinoOutArgs a) {
+  constexpr int A = WinoMat<MM>::A;
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int k = blockIdx.y;
+  if (t >= a.T) return;
+  const size_t xs = (size_t)a.K * a.T;
+  const float* mp = a.Mb + (size_t)k * a.T + t;
+  float mv[A][A];
+#pragma unroll
+  for (int i = 0; i < A; ++i)
+#pragma unroll
+    for (int j = 0; j < A; ++j) mv[i][j] = mp[(size_t)(i * A + j) * xs];
+  wino_out_one<MM>(a, mv, k, t);
+}
+
+// [r3] M in the split GEMM's MFMA-native 32 x 32 blocks: a thread takes FOUR channels of its tile -- the four rows a GEMM
+// lane held in adjacent registers lie in one 16-B word, so the 36 positions arrive as 36 float4 loads (lanes = consecutive
+// tiles: 512 B contiguous per 32 lanes) and the GEMM's epilogue is a quarter of the store instructions it was.
+__global__ __launch_bounds__(256) void wino_output_blk_kernel(WinoOutArgs a) {
+  constexpr int A = 6;
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int k0 = blockIdx.y * 4;
+  if (t >= a.T) return;
+  const float* mp = a.Mb + ((size_t)(k0 >> 5) * a.tblk + (size_t)(t >> 5)) * 1024 +
+                    ((((k0 >> 2) & 1) * 4 + ((k0 >> 3) & 3)) * 32 + (int)(t & 31)) * 4;
+  f32x4 m4[A * A];
+#pragma unroll
+  for (int q = 0; q < A * A; ++q) m4[q] = *(const f32x4*)(mp + (size_t)q * a.xs_blk);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    if (k0 + c >= a.K) break;
+    float mv[A][A];
+#pragma unroll
+    for (int q = 0; q < A * A; ++q) mv[q / A][q % A] = m4[q][c];
+    wino_out_one<4>(a, mv, k0 + c, t);
+  }
+}
+
 // --------------------------------------------------------------------------------------------
 // host side
 static int g_wino_mode = -1;   // -1: not initialised (FCD_WINO env, default 4)
@@ -1579,7 +1611,8 @@ static bool wino_plan(const fcd_conv_desc* d, int mode, WinoPlan* pl) {
   pl->TW = cdiv(d->W, pl->m);
   pl->T = (long long)d->N * pl->TH * pl->TW;
   pl->v_bytes = (size_t)pl->A2 * pl->Q * pl->T * 32 * sizeof(float);
-  pl->m_bytes = (size_t)pl->A2 * pl->rows * pl->T * sizeof(float);
+  // (rows and tiles rounded up to 32: the split GEMM may write M in whole 32 x 32 blocks, wino_output_blk_kernel)
+  pl->m_bytes = (size_t)pl->A2 * round_up(pl->rows, 32) * ((pl->T + 31) / 32 * 32) * sizeof(float);
   return true;
 }
 
@@ -1713,6 +1746,18 @@ static int wino_run(const WinoPlan& pl, int N, int in_ch, int H, int W, const fl
   ga.As = (const unsigned short*)(U + ga.as_plane);
   ga.b_ld = 32; ga.b_adv = (long long)pl.T * 32; ga.b_batch = (long long)pl.Q * pl.T * 32;   // V [xi][Q][T][32]
   ga.stages_per_split = pl.Q;
+  // [r3] M in 32 x 32 MFMA-native blocks whenever the split kernels run the GEMM (FCD_WINO_CBLK=0: row-major M, A/B)
+  static int cblk_on = -1;
+  if (cblk_on < 0) {
+    const char* e = getenv("FCD_WINO_CBLK");
+    const char* e2 = getenv("FCD_WINO_SPLIT_BIG");
+    cblk_on = ((e && e[0] == '0') || (e2 && atoi(e2) >= 4)) ? 0 : 1;      // (the ping-pong experiment kernel writes row-major)
+  }
+  const bool blk = cblk_on && pl.m == 4 && pl.rows > 64 && wino_split() && (pl.rows & 3) == 0;
+  if (blk) {
+    ga.c_blk = 1; ga.c_mblk = cdiv(pl.rows, 32); ga.c_tblk = (int)((pl.T + 31) / 32);
+    ga.c_batch = (long long)ga.c_mblk * ga.c_tblk * 1024;
+  }
   {
     const bool split = pl.rows > 64 && wino_split();
     FcdProfScope p2(split ? FCD_K_WINO_GEMM_SPLIT : FCD_K_WINO_GEMM, st, 2.0 * pl.A2 * pl.rows * (double)pl.Kc * (double)pl.T,
@@ -1731,7 +1776,10 @@ static int wino_run(const WinoPlan& pl, int N, int in_ch, int H, int W, const fl
     FcdProfScope p3(FCD_K_WINO_XFORM, st, 0.0,
                     (double)pl.m_bytes + (double)pl.m_bytes / pl.A2 * mm * (pool_y ? 0.3125 : 1.0),
                     fcd_prof_tagf("out pool=%d K=%d img=%dx%dx%d", pool_y ? 1 : 0, pl.rows, N, H, W));
-    if (pl.m == 2) hipLaunchKernelGGL(wino_output_kernel<2>, og, dim3(256), 0, st, oa);
+    if (blk) {
+      oa.tblk = ga.c_tblk; oa.xs_blk = ga.c_batch;
+      hipLaunchKernelGGL(wino_output_blk_kernel, dim3((unsigned)cdiv64(pl.T, 256), (unsigned)cdiv(pl.rows, 4)), dim3(256), 0, st, oa);
+    } else if (pl.m == 2) hipLaunchKernelGGL(wino_output_kernel<2>, og, dim3(256), 0, st, oa);
     else hipLaunchKernelGGL(wino_output_kernel<4>, og, dim3(256), 0, st, oa);
   }
   return 0;
