@@ -80,6 +80,9 @@ _SIGS = {
     'fcd_conv2d_bwd_weight_bias_cat': (c_int, [P, P, P, c_int, P, P, P, P, P, c_size_t, P]),
     'fcd_conv_wino_ws_bytes': (c_size_t, [POINTER(ConvDesc), c_int]),
     'fcd_conv_wino_keepv_bytes': (c_size_t, [POINTER(ConvDesc)]),
+    'fcd_conv_wino_relu_bits_bytes': (c_size_t, [POINTER(ConvDesc)]),
+    'fcd_conv2d_fwd_wino_relu_bits': (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, c_size_t, P]),
+    'fcd_conv2d_bwd_data_wino_bits': (c_int, [POINTER(ConvDesc), P, P, P, P, P, c_size_t, P]),
     'fcd_conv2d_fwd_wino_keepv': (c_int, [POINTER(ConvDesc), P, P, P, P, c_int, P, P, P, c_size_t, P, P]),
     'fcd_conv2d_fwd_wino_cat_keepv': (c_int, [P, P, P, c_int, P, P, P, c_int, P, c_size_t, P, P]),
     'fcd_conv2d_bwd_weight_bias_v': (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, c_size_t, P]),

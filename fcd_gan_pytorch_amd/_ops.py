@@ -210,28 +210,37 @@ class _Conv2d(torch.autograd.Function):
         d = _desc(x.shape, weight.shape, stride, pad)
         y = torch.empty((d.N, d.K, d.P, d.Q), dtype=torch.float32, device=x.device)
         b = _dev(bias, 'conv bias') if bias is not None else None
-        bits = None
+        bits = wbits = None
         if relu and not weight.requires_grad:
             nb = lib.fcd_conv2d_relu_bits_bytes(ctypes.byref(d))
             if nb:      # thin-channel frozen layer: the backward mask is kept as 4 bits per strip, not as y
                 bits = torch.empty(nb, dtype=torch.uint8, device=x.device)
                 check(lib.fcd_conv2d_fwd_relu_bits(ctypes.byref(d), _p(x), _p(packed_weight(weight, 0)), _p(b), _p(y),
                                                    _p(bits), _stream()), 'fcd_conv2d_fwd_relu_bits')
+            elif ctx.needs_input_grad[0] and not lib.fcd_conv_wino2_plan(ctypes.byref(d), 0):
+                nw = lib.fcd_conv_wino_relu_bits_bytes(ctypes.byref(d))
+                if nw and os.environ.get('FCD_WINO_RELU_BITS') != '0':
+                    # frozen F(4x4) layer (VGG16 of the perception term): 16 sign bits per output tile instead of y on the tape
+                    wbits = torch.empty(nw // 2, dtype=torch.int16, device=x.device)
+                    ws = _ws(lib.fcd_conv_wino_ws_bytes(ctypes.byref(d), 0), x.device)
+                    check(lib.fcd_conv2d_fwd_wino_relu_bits(ctypes.byref(d), _p(x), _p(wino_weight(weight, 0, 4)), _p(b), _p(y),
+                                                            _p(wbits), _p(ws), ws.numel(), _stream()),
+                          'fcd_conv2d_fwd_wino_relu_bits')
         vk = None
-        if bits is None:
+        if bits is None and wbits is None:
             vk = _keepv(d, ctx.needs_input_grad[1], x.device)
             _fwd_conv(d, x, weight, b, y, relu, v_keep=vk)
         # x is only needed for the weight gradient (or, on the wide F(4x4) layers, its transform V kept by the forward
         # pass instead); the fused-ReLU output doubles as the backward mask
         ctx.save_for_backward(x if (weight.requires_grad and vk is None) else None, weight,
-                              (y if relu and bits is None else None), bits, vk)
+                              (y if relu and bits is None and wbits is None else None), bits, vk, wbits)
         ctx.geom = (stride, pad, bias is not None, tuple(x.shape))
         ctx.bias_param = bias
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight, yrelu, bits, vk = ctx.saved_tensors
+        x, weight, yrelu, bits, vk, wbits = ctx.saved_tensors
         stride, pad, has_bias, xshape = ctx.geom
         dy = _dev(dy, 'conv grad')
         d = _desc(xshape, weight.shape, stride, pad)
@@ -241,6 +250,10 @@ class _Conv2d(torch.autograd.Function):
             if bits is not None:
                 check(lib.fcd_conv2d_bwd_data_bits(ctypes.byref(d), _p(dy), _p(bits), _p(packed_weight(weight, 1)), _p(dx),
                                                    _stream()), 'fcd_conv2d_bwd_data_bits')
+            elif wbits is not None:
+                ws = _ws(lib.fcd_conv_wino_ws_bytes(ctypes.byref(d), 1), dy.device)
+                check(lib.fcd_conv2d_bwd_data_wino_bits(ctypes.byref(d), _p(dy), _p(wbits), _p(wino_weight(weight, 1, 4)), _p(dx),
+                                                        _p(ws), ws.numel(), _stream()), 'fcd_conv2d_bwd_data_wino_bits')
             else:
                 _bwd_data_conv(d, dy, weight, dx, yrelu=yrelu)
         want_db = has_bias and ctx.needs_input_grad[2]

@@ -165,7 +165,9 @@ __device__ __forceinline__ const float* wino_cat_pick(const WinoCat& k, int& ch,
 
 struct WinoInArgs {
   const float* x;             // SRC 0/1: (N, C, H, W); SRC 2: pooled gradient (N, C, Hp, Wp)
-  const float* mask;          // SRC 1: ReLU output, same shape as x
+  const float* mask;          // SRC 1: ReLU output, same shape as x ...
+  const unsigned short* mbits;  // ... or [r3] its sign as 16 bits per (n, c, 4 x 4 tile), bit 4 i + j = [y(4 ty + i, 4 tx + j) > 0],
+                              // written by the forward pass's output transform (1 / 32 of the mask traffic)
   const unsigned char* code;  // SRC 2: argmax code of the pooled tensor
   float* V;                   // [xi][Q][T][32]
   int N, C, H, W, Hp, Wp, TH, TW, Q;
@@ -174,6 +176,20 @@ struct WinoInArgs {
   int xcd;                    // 1: blocks renumbered so that each XCD (own L2) walks a contiguous range
   WinoCat cat;                // plain source of the rolling kernel only: x = cat(cat.p[...]) (cat.n > 0)
 };
+
+// ReLU mask of source element (plane index pc = n * C + c, row ih, column iw .. iw + 3, iw % 4 == 0) as 0 / 1 floats: from
+// the fp32 activation (off = its element offset) or from the 16-bit tile words
+__device__ __forceinline__ f32x4 wino_mask4(const WinoInArgs& a, size_t off, size_t pc, int ih, int iw) {
+  if (a.mbits) {
+    const unsigned w = a.mbits[(pc * a.TH + (ih >> 2)) * a.TW + (iw >> 2)] >> (4 * (ih & 3));
+    return f32x4{(float)(w & 1u), (float)((w >> 1) & 1u), (float)((w >> 2) & 1u), (float)((w >> 3) & 1u)};
+  }
+  return *(const f32x4*)(a.mask + off);
+}
+__device__ __forceinline__ float wino_mask1(const WinoInArgs& a, size_t off, size_t pc, int ih, int iw) {
+  if (a.mbits) return (float)((a.mbits[(pc * a.TH + (ih >> 2)) * a.TW + (iw >> 2)] >> (4 * (ih & 3) + (iw & 3))) & 1u);
+  return a.mask[off];
+}
 
 // Workgroups are handed to the 8 XCDs round-robin in launch order, so neighbouring strips of one plane --
 // which share their halo rows -- would land on 8 different L2s and fetch the shared rows from HBM again.
@@ -222,7 +238,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(WinoInArgs a) {
       } else {
         const size_t off = img + (size_t)c * plane + (size_t)ih * a.W + iw;
         v = a.x[off];
-        if (SRC == 1 && !(a.mask[off] > 0.f)) v = 0.f;
+        if (SRC == 1 && !(wino_mask1(a, off, (size_t)n * a.C + q * 32 + c, ih, iw) > 0.f)) v = 0.f;
       }
     }
     return v;
@@ -276,7 +292,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(WinoInArgs a) {
         const size_t off = img + (size_t)c * plane + (size_t)ih * a.W + iw;
         v = *(const f32x4*)(a.x + off);
         if (SRC == 1) {
-          const f32x4 k = *(const f32x4*)(a.mask + off);
+          const f32x4 k = wino_mask4(a, off, (size_t)n * a.C + q * 32 + c, ih, iw);
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             if (!(k[e] > 0.f)) v[e] = 0.f;
@@ -402,7 +418,12 @@ __global__ __launch_bounds__(256) void wino_input_roll_kernel(WinoInArgs a, int 
       } else if (idx < 32 * RH * V4 && q * 32 + c < a.C && ih >= 0 && ih < a.H && iw < a.W) {
         const size_t off = img + (size_t)c * plane + (size_t)ih * a.W + iw;
         v = *(const f32x4*)(xsrc + off);
-        if (SRC == 1) m = *(const f32x4*)(a.mask + off);
+        if (SRC == 1) {
+          // bit mask: keep the RAW tile word in the register (decoded in commit): arithmetic on it here would wait for the
+          // load and serialise the strip's prefetch (measured: +2 ms per step with the decode at issue time)
+          if (a.mbits) m[0] = __uint_as_float((unsigned)a.mbits[(((size_t)n * a.C + q * 32 + c) * a.TH + (ih >> 2)) * a.TW + (iw >> 2)]);
+          else m = *(const f32x4*)(a.mask + off);
+        }
       }
       pre[k] = v;
       if (SRC == 1) msk[k] = m;
@@ -425,7 +446,10 @@ __global__ __launch_bounds__(256) void wino_input_roll_kernel(WinoInArgs a, int 
         } else {
           const size_t off = img + (size_t)c * plane + (size_t)ih * a.W + iw;
           v = xsrc[off];
-          if (SRC == 1) m = a.mask[off];
+          if (SRC == 1) {
+            if (a.mbits) m = __uint_as_float((unsigned)a.mbits[(((size_t)n * a.C + q * 32 + c) * a.TH + (ih >> 2)) * a.TW + (iw >> 2)]);
+            else m = a.mask[off];
+          }
         }
       }
       preh[k] = v;
@@ -448,8 +472,14 @@ __global__ __launch_bounds__(256) void wino_input_roll_kernel(WinoInArgs a, int 
         t[2] = c1 == rowbit ? pre[k][1] : 0.f;
         t[3] = c1 == (rowbit | 1u) ? pre[k][1] : 0.f;
       } else {
+        if (SRC == 1 && a.mbits) {
+          const unsigned wv = __float_as_uint(msk[k][0]) >> (4 * ((ty * MM - 1 + r) & 3));
 #pragma unroll
-        for (int e = 0; e < 4; ++e) t[e] = (SRC == 1 && !(msk[k][e] > 0.f)) ? 0.f : pre[k][e];
+          for (int e = 0; e < 4; ++e) t[e] = ((wv >> e) & 1u) ? pre[k][e] : 0.f;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) t[e] = (SRC == 1 && !(msk[k][e] > 0.f)) ? 0.f : pre[k][e];
+        }
       }
     }
 #pragma unroll
@@ -458,7 +488,12 @@ __global__ __launch_bounds__(256) void wino_input_roll_kernel(WinoInArgs a, int 
       if (idx >= 32 * RH * 2) continue;
       const int c = idx / (RH * 2), rem = idx % (RH * 2);
       const int r = rem >> 1, col = (rem & 1) ? CW - 1 : 0;
-      tile[c * PL + r * CW + col] = (SRC != 0 && !(mskh[k] > 0.f)) ? 0.f : preh[k];
+      if (SRC == 1 && a.mbits) {
+        const unsigned bit = (__float_as_uint(mskh[k]) >> (4 * ((ty * MM - 1 + r) & 3) + ((iw0 + col) & 3))) & 1u;
+        tile[c * PL + r * CW + col] = bit ? preh[k] : 0.f;
+      } else {
+        tile[c * PL + r * CW + col] = (SRC != 0 && !(mskh[k] > 0.f)) ? 0.f : preh[k];
+      }
     }
   };
 
@@ -1417,6 +1452,7 @@ struct WinoOutArgs {
   WinoCat cat;          // data gradient of a virtually concatenated input: channel k of dx goes to its own tensor (cat.n > 0)
   int tblk;             // wino_output_blk_kernel: Mb in the split GEMM's 32 x 32 blocks (WinoGemmArgs.c_blk): blocks per
   long long xs_blk;     // row block, floats per xi
+  unsigned short* bits; // [r3] m = 4, relu, no pooling: sign of the outputs, 16 bits per (n, k, tile) (WinoInArgs.mbits)
 };
 
 template <int MM>
@@ -1451,6 +1487,14 @@ __device__ __forceinline__ void wino_out_one(const WinoOutArgs& a, const float (
   const int tx = (int)(t % a.TW);
   const long long r2 = t / a.TW;
   const int ty = (int)(r2 % a.TH), n = (int)(r2 / a.TH);
+  if (MM == 4 && a.bits != nullptr) {
+    unsigned w = 0;
+#pragma unroll
+    for (int i = 0; i < MM; ++i)
+#pragma unroll
+      for (int j = 0; j < MM; ++j) w |= (o[i][j] > 0.f ? 1u : 0u) << (4 * i + j);
+    a.bits[(((size_t)n * a.K + k) * a.TH + ty) * a.TW + tx] = (unsigned short)w;
+  }
   const int p0 = ty * MM, q0 = tx * MM;
   if (a.pool_y != nullptr) {
     // The four outputs of a pooling window come out of the same transform-domain values through
@@ -1712,16 +1756,17 @@ static bool wino_cat_input_ok(const WinoPlan& pl, int W) {
 static int wino_run(const WinoPlan& pl, int N, int in_ch, int H, int W, const float* src, const float* mask,
                     const unsigned char* code_in, int Hp, int Wp, const float* U, const float* bias, int relu, float* y,
                     float* pool_y, unsigned char* code_out, void* ws, hipStream_t st,
-                    const WinoCat* in_cat = nullptr, const WinoCat* out_cat = nullptr, float* v_keep = nullptr) {
+                    const WinoCat* in_cat = nullptr, const WinoCat* out_cat = nullptr, float* v_keep = nullptr,
+                    const unsigned short* mask_bits = nullptr, unsigned short* relu_bits_out = nullptr) {
   float* V = v_keep ? v_keep : (float*)ws;       // v_keep: the caller keeps the transformed input for the weight gradient
   float* Mb = (float*)((char*)ws + ((pl.v_bytes + 255) & ~(size_t)255));
   WinoInArgs ia;
   memset(&ia, 0, sizeof(ia));
   if (in_cat) ia.cat = *in_cat;
-  ia.x = src; ia.mask = mask; ia.code = code_in; ia.V = V;
+  ia.x = src; ia.mask = mask; ia.mbits = mask_bits; ia.code = code_in; ia.V = V;
   ia.N = N; ia.C = in_ch; ia.H = H; ia.W = W; ia.Hp = Hp; ia.Wp = Wp;
   ia.TH = pl.TH; ia.TW = pl.TW; ia.Q = pl.Q; ia.T = pl.T;
-  const int srcmode = code_in ? 2 : (mask ? 1 : 0);
+  const int srcmode = code_in ? 2 : ((mask || mask_bits) ? 1 : 0);
   {
     static int exp = -1;
     if (exp < 0) { const char* e = getenv("FCD_WINO_IN_EXP"); exp = e ? atoi(e) : 0; }
@@ -1730,7 +1775,7 @@ static int wino_run(const WinoPlan& pl, int N, int in_ch, int H, int W, const fl
   }
   const double in_elems = (double)N * in_ch * H * W, mm = pl.m * pl.m;
   {
-    FcdProfScope p1(FCD_K_WINO_XFORM, st, 0.0, 4.0 * in_elems * (srcmode == 1 ? 2.0 : 1.0) + (double)pl.v_bytes,
+    FcdProfScope p1(FCD_K_WINO_XFORM, st, 0.0, 4.0 * in_elems * (srcmode == 1 ? (mask_bits ? 1.03125 : 2.0) : 1.0) + (double)pl.v_bytes,
                     fcd_prof_tagf("in src=%d C=%d img=%dx%dx%d", srcmode, in_ch, N, H, W));
     if (pl.m == 2) wino_launch_input<2>(ia, srcmode, st); else wino_launch_input<4>(ia, srcmode, st);
   }
@@ -1769,7 +1814,7 @@ static int wino_run(const WinoPlan& pl, int N, int in_ch, int H, int W, const fl
   WinoOutArgs oa;
   memset(&oa, 0, sizeof(oa));
   if (out_cat) oa.cat = *out_cat;
-  oa.Mb = Mb; oa.bias = bias; oa.y = y; oa.pool_y = pool_y; oa.code = code_out;
+  oa.Mb = Mb; oa.bias = bias; oa.y = y; oa.pool_y = pool_y; oa.code = code_out; oa.bits = relu_bits_out;
   oa.K = pl.rows; oa.P = H; oa.Q = W; oa.TH = pl.TH; oa.TW = pl.TW; oa.relu = relu; oa.T = pl.T;
   dim3 og((unsigned)cdiv64(pl.T, 256), (unsigned)pl.rows);
   {
@@ -1821,6 +1866,50 @@ extern "C" int fcd_conv2d_fwd_wino_keepv(const fcd_conv_desc* d, const float* x,
   wino_run(pl, d->N, d->C, d->H, d->W, x, nullptr, nullptr, 0, 0, U, bias, (fuse_relu || pool_y) ? 1 : 0,
            pool_y ? nullptr : y, pool_y, code, ws, (hipStream_t)stream, nullptr, nullptr, v_keep);
   FCD_LAUNCH_CHECK("conv2d_fwd_wino");
+  return FCD_OK;
+}
+
+// [r3] ReLU mask of a frozen F(4x4) layer as 16 bits per (n, k, 4 x 4 tile) instead of the fp32 activation: the forward
+// output transform writes it next to y, the gated input transform of the data gradient reads it (4.25 -> 3.28 tensor
+// passes on the gated transforms; y itself is free to go once the next layer has consumed it).  0 when the layer's
+// forward and data gradient do not both run as F(4x4).
+extern "C" size_t fcd_conv_wino_relu_bits_bytes(const fcd_conv_desc* d) {
+  WinoPlan pf, pd;
+  if (!d || !wino_plan(d, 0, &pf) || !wino_plan(d, 1, &pd) || pf.m != 4 || pd.m != 4) return 0;
+  return (size_t)d->N * d->K * pf.TH * pf.TW * sizeof(unsigned short);
+}
+
+extern "C" int fcd_conv2d_fwd_wino_relu_bits(const fcd_conv_desc* d, const float* x, const float* U, const float* bias, float* y,
+                                             unsigned short* relu_bits, void* ws, size_t ws_bytes, void* stream) {
+  FCD_CHECK_ARG(d && x && U && y && relu_bits, "fcd_conv2d_fwd_wino_relu_bits: null pointer");
+  FCD_CHECK_ARG(fcd_conv_wino_relu_bits_bytes(d) > 0, "fcd_conv2d_fwd_wino_relu_bits: fcd_conv_wino_relu_bits_bytes(d) == 0");
+  WinoPlan pl;
+  wino_plan(d, 0, &pl);
+  if (!ws || ws_bytes < fcd_conv_wino_ws_bytes(d, 0)) {
+    fcd_set_error("fcd_conv2d_fwd_wino_relu_bits: workspace %zu < %zu bytes", ws_bytes, fcd_conv_wino_ws_bytes(d, 0));
+    return FCD_ERR_WORKSPACE;
+  }
+  FcdProfScope prof(FCD_K_WINO_FWD, (hipStream_t)stream, conv_flops(d), wino_bytes(pl), fcd_prof_tag_desc("wino_fwd", d));
+  wino_run(pl, d->N, d->C, d->H, d->W, x, nullptr, nullptr, 0, 0, U, bias, 1, y, nullptr, nullptr, ws, (hipStream_t)stream,
+           nullptr, nullptr, nullptr, nullptr, relu_bits);
+  FCD_LAUNCH_CHECK("conv2d_fwd_wino_relu_bits");
+  return FCD_OK;
+}
+
+extern "C" int fcd_conv2d_bwd_data_wino_bits(const fcd_conv_desc* d, const float* dy, const unsigned short* relu_bits,
+                                             const float* U, float* dx, void* ws, size_t ws_bytes, void* stream) {
+  FCD_CHECK_ARG(d && dy && relu_bits && U && dx, "fcd_conv2d_bwd_data_wino_bits: null pointer");
+  FCD_CHECK_ARG(fcd_conv_wino_relu_bits_bytes(d) > 0, "fcd_conv2d_bwd_data_wino_bits: fcd_conv_wino_relu_bits_bytes(d) == 0");
+  WinoPlan pl;
+  wino_plan(d, 1, &pl);
+  if (!ws || ws_bytes < fcd_conv_wino_ws_bytes(d, 1)) {
+    fcd_set_error("fcd_conv2d_bwd_data_wino_bits: workspace %zu < %zu bytes", ws_bytes, fcd_conv_wino_ws_bytes(d, 1));
+    return FCD_ERR_WORKSPACE;
+  }
+  FcdProfScope prof(FCD_K_WINO_DGRAD, (hipStream_t)stream, conv_flops(d), wino_bytes(pl), fcd_prof_tag_desc("wino_dgrad", d));
+  wino_run(pl, d->N, d->K, d->P, d->Q, dy, nullptr, nullptr, 0, 0, U, nullptr, 0, dx, nullptr, nullptr, ws, (hipStream_t)stream,
+           nullptr, nullptr, nullptr, relu_bits, nullptr);
+  FCD_LAUNCH_CHECK("conv2d_bwd_data_wino_bits");
   return FCD_OK;
 }
 

@@ -132,6 +132,15 @@ int fcd_conv2d_fwd_wino_cat_keepv(const fcd_conv_desc* d, const float* const* sr
                                   void* stream);
 int fcd_conv2d_bwd_weight_bias_v(const fcd_conv_desc* d, const float* v_fwd, const float* dy, const float* relu_out, float* dw,
                                  float* db, void* ws, size_t ws_bytes, void* stream);
+/* ---- ReLU mask of a FROZEN F(4x4) layer as bits (round 3; the VGG16 stack of the perception term, reference Loss.py:25-27:
+ * requires_grad = False, so the backward pass needs of a layer's output only its sign).  fcd_conv2d_fwd_wino_relu_bits writes
+ * y = relu(conv + bias) AND 16 bits per (n, k, 4 x 4 output tile); fcd_conv2d_bwd_data_wino_bits gates dy with them instead
+ * of re-reading y.  fcd_conv_wino_relu_bits_bytes(d) = size of the mask, 0 when the layer does not run this way. */
+size_t fcd_conv_wino_relu_bits_bytes(const fcd_conv_desc* d);
+int fcd_conv2d_fwd_wino_relu_bits(const fcd_conv_desc* d, const float* x, const float* U, const float* bias, float* y,
+                                  unsigned short* relu_bits, void* ws, size_t ws_bytes, void* stream);
+int fcd_conv2d_bwd_data_wino_bits(const fcd_conv_desc* d, const float* dy, const unsigned short* relu_bits, const float* U,
+                                  float* dx, void* ws, size_t ws_bytes, void* stream);
 /* dx from dy, dy * [relu_out > 0] (relu_out != NULL) or the pooled gradient routed by pool_code */
 int fcd_conv2d_bwd_data_wino(const fcd_conv_desc* d, const float* dy, const float* relu_out,
                              const unsigned char* pool_code, const float* U, float* dx, void* ws,

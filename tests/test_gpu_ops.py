@@ -433,6 +433,40 @@ def test_wino_gemm_matrix_pipes(case):
             assert err[mode][q] <= 1.15 * err[0][q] + 1e-8, (mode, q, err)
 
 
+@pytest.mark.parametrize('case', [(2, 128, 32, 32, 256), (1, 256, 20, 36, 128), (3, 128, 13, 18, 128), (2, 512, 16, 16, 512)],
+                         ids=lambda c: 'x'.join(map(str, c)))
+def test_wino_frozen_relu_bit_mask(case, monkeypatch):
+    """Frozen F(4x4) layer with fused ReLU (the VGG16 stack of the perception term): the backward mask kept as 16 sign bits
+    per output tile (fcd_conv2d_fwd_wino_relu_bits / fcd_conv2d_bwd_data_wino_bits) must give the SAME data gradient, bit
+    for bit, as gating with the fp32 activation -- on all three gated input-transform kernels (strip / 2 x 8 / 4 x 4 blocks),
+    ragged maps included -- and both must match torch."""
+    ops = _ops()
+    N, C, H, W, K = case
+    x = rnd(N, C, H, W, seed=81)
+    w = rnd(K, C, 3, 3, seed=82, scale=(2.0 / (C * 9)) ** 0.5)
+    b = rnd(K, seed=83, scale=0.1)
+    g = rnd(N, K, H, W, seed=84)
+    d = ops._desc(x.shape, w.shape, 1, 1)
+    import ctypes
+    if not ops.lib.fcd_conv_wino_relu_bits_bytes(ctypes.byref(d)):
+        pytest.skip('layer is not planned F(4x4) in both directions')
+    res = {}
+    for tag, env in (('bits', '1'), ('y', '0')):
+        monkeypatch.setenv('FCD_WINO_RELU_BITS', env)
+        xg = x.cuda().requires_grad_(True)
+        wg = w.cuda()                                   # frozen
+        y = ops.conv2d(xg, wg, b.cuda(), 1, 1, relu=True)
+        y.backward(g.cuda())
+        res[tag] = (y.detach().cpu(), xg.grad.cpu())
+    assert torch.equal(res['bits'][0], res['y'][0]) and torch.equal(res['bits'][1], res['y'][1])
+    xr = x.double().requires_grad_(True)
+    yr = F.relu(F.conv2d(xr, w.double(), b.double(), padding=1))
+    yr.backward(g.double())
+    assert_close(res['bits'][0], yr, tol=6e-5, what='y')
+    dd = res['bits'][1].double() - xr.grad
+    assert (dd.norm() / xr.grad.norm()).item() < 2e-4           # (outputs within rounding of 0 may gate the other way)
+
+
 def _split_modes_conv(ops, x, w, b):
     """y of the 3x3 layer with the F(4x4) GEMMs on the fp32 matrix pipe (mode 0) and on the two split-bf16 kernels."""
     lib = ops.lib
