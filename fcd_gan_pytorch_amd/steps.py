@@ -63,7 +63,7 @@ def _side_stream(device):
     32x..16x16 maps that leave most of the 256 CUs idle -- is independent of the frozen-Generator forward and of the
     VGG feature passes of the Segmentor step, so it runs beside them; the Segmentor step's own Discriminator forward
     (which must see the UPDATED weights, Demo_RSSS.py:311) waits for it.  Measured on one MI355X: 98.9 -> 98.5 ms/step,
-    bit-identical results (tools/debug/dbg_overlap.py) -- once the packed-filter caches tell the caching allocator about
+    bit-identical results -- once the packed-filter caches tell the caching allocator about
     their cross-stream readers (_ops._shared; without that the optimizer's cache invalidation let the other stream's
     allocations overwrite filters a queued kernel was still reading).  Not the default: 0.4 % is not worth a second
     stream next to the RCCL stream on the multi-GPU path, which cannot be exercised here."""
