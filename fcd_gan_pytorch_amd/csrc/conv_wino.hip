@@ -965,6 +965,157 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void wino_gem
 #undef WS_DMA
 }
 
+// [r3] Filter-resident split GEMM for the ONE-row-tile launches with a short reduction (<= 128 rows, Kc <= 128: VGG conv2_x,
+// the Segmentor's 128-channel stages).  In the 128 x 128 kernel every column-tile workgroup streams the same 24-KB filter
+// planes per stage again -- 60 % of its L2 -> LDS bytes; with the A stream cut out (diagnostic build) conv2_2 ran 1.60
+// instead of 1.94 ms.  Here the planes of ALL Kc / 32 stages of a transform position stay in LDS (4 x 24 KB), the
+// workgroup (8 waves, 128 x 256 tile, each wave 64 x 64 as above) walks a contiguous range of column tiles of that
+// position and only V moves: two 32-KB B stages, 96 + 64 KB = the whole LDS, one workgroup per CU.
+__global__ __launch_bounds__(512, 1) void wino_gemm_split_res_kernel(WinoGemmArgs a) {
+  constexpr int KC = 32, WM = 2, WN = 4, NW = 8, BM = 128, BN = 256, QMAX = 4;
+  constexpr int UH = KC / 8;
+  constexpr int A_UNITS = 3 * 2 * BM * 2;          // per stage: [plane][half][row][2 units of 8 bf16]
+  constexpr int PPW_A = A_UNITS / 64 / NW;         // 3
+  constexpr int PPW_B = BN * UH * 2 / 64 / NW;     // 4
+  static_assert(PPW_A * NW * 64 == A_UNITS && PPW_B * NW * 64 == BN * UH * 2, "DMA split");
+  constexpr int SWS = 3;
+  __shared__ __attribute__((aligned(16))) unsigned short sa[QMAX * A_UNITS * 8];
+  __shared__ __attribute__((aligned(16))) float sb0[BN * KC];
+  __shared__ __attribute__((aligned(16))) float sb1[BN * KC];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wm = wave / WN, wn = wave % WN;
+  const int Q = a.Kc / KC;                          // <= QMAX
+  const int xi = blockIdx.y;
+  const int chunks = gridDim.x;
+  const int nt_beg = (int)((long long)a.n_tiles * blockIdx.x / chunks), nt_end = (int)((long long)a.n_tiles * (blockIdx.x + 1) / chunks);
+  if (nt_beg >= nt_end) return;
+  const unsigned short* Ab = a.As + (size_t)xi * a.a_batch;
+  const float* Bb = a.B + (size_t)xi * a.b_batch;
+
+  long long a_goff[PPW_A];
+  int b_row[PPW_B], b_in[PPW_B];
+#pragma unroll
+  for (int j = 0; j < PPW_A; ++j) {
+    const int u = (wave + NW * j) * 64 + lane;
+    const int plane = u / (2 * BM * 2), rem = u % (2 * BM * 2);
+    const int h = rem / (BM * 2), row = (rem >> 1) % BM, pj = rem & 1;
+    const int jl = pj ^ ((row >> 4) & 1);
+    a_goff[j] = plane * a.as_plane + (long long)min(row, a.M - 1) * a.a_ld + h * (KC / 2) + jl * 8;
+  }
+#pragma unroll
+  for (int j = 0; j < PPW_B; ++j) {
+    const int u = (wave + NW * j) * 64 + lane;
+    const int h = u / (BN * UH), row = (u / UH) % BN, pj = u % UH;
+    const int jl = pj ^ ((row >> SWS) & (UH - 1));
+    b_row[j] = row;
+    b_in[j] = h * (KC / 2) + jl * 4;
+  }
+  int aoff[2], boff[2];
+  const int swb = (l31 >> SWS) & (UH - 1), swa = (l31 >> 4) & 1;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    aoff[i] = ((half * BM + wm * 64 + i * 32 + l31) * 2) * 8;
+    boff[i] = (half * BN + wn * 64 + i * 32 + l31) * (UH * 4);
+  }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // all filter stages of this transform position, once
+  for (int q = 0; q < Q; ++q) {
+#pragma unroll
+    for (int j = 0; j < PPW_A; ++j)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(Ab + (size_t)q * KC + a_goff[j]),
+                                       (lds_void_t*)(sa + (size_t)q * (A_UNITS * 8) + (wave + NW * j) * 512), 16, 0, 0);
+  }
+  int fq = 0, fnt = nt_beg;             // next B stage to fetch
+#define R_DMA(SB)                                                                                \
+  {                                                                                              \
+    const float* bs_ = Bb + (size_t)fq * a.b_adv;                                                \
+    const int n0f = fnt * BN;                                                                    \
+    _Pragma("unroll") for (int j = 0; j < PPW_B; ++j)                                            \
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(bs_ + (size_t)min(n0f + b_row[j], a.N - 1) * a.b_ld + b_in[j]), \
+                                       (lds_void_t*)((SB) + (wave + NW * j) * 256), 16, 0, 0);   \
+    if (++fq == Q) { fq = 0; ++fnt; }                                                            \
+  }
+#define R_MFMA(AV, BV)                                                                           \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                  \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, AV[i]),     \
+                                                          __builtin_bit_cast(bf16x8, BV[j]), acc[i][j], 0, 0, 0);
+#define R_SIX(AH, AM, AL, BH, BM_, BL)                                                           \
+  R_MFMA(AL, BH) R_MFMA(AH, BL) R_MFMA(AM, BM_) R_MFMA(AM, BH) R_MFMA(AH, BM_) R_MFMA(AH, BH)
+#define R_STEP(SA, SB, SBN)                                                                      \
+  {                                                                                              \
+    if (fnt < nt_end) R_DMA(SBN)                                                                 \
+    f32x4 xr[2][2][2];                                                                           \
+    u32x4 ah[2][2], am[2][2], al[2][2], bh[2][2], bm[2][2], bl[2][2];                            \
+    _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                             \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                            \
+        xr[s_][i][0] = *(const f32x4*)((SB) + boff[i] + (((2 * s_) ^ swb) * 4));                 \
+        xr[s_][i][1] = *(const f32x4*)((SB) + boff[i] + (((2 * s_ + 1) ^ swb) * 4));             \
+      }                                                                                          \
+    _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                             \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                            \
+        const unsigned short* ap = (SA) + aoff[i] + ((s_ ^ swa) * 8);                            \
+        ah[s_][i] = *(const u32x4*)(ap);                                                         \
+        am[s_][i] = *(const u32x4*)(ap + 2 * BM * 2 * 8);                                        \
+        al[s_][i] = *(const u32x4*)(ap + 2 * (2 * BM * 2 * 8));                                  \
+      }                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) WS_SPLIT(xr[0][i][0], xr[0][i][1], bh[0][i], bm[0][i], bl[0][i]) \
+    R_SIX(ah[0], am[0], al[0], bh[0], bm[0], bl[0])                                              \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) WS_SPLIT(xr[1][i][0], xr[1][i][1], bh[1][i], bm[1][i], bl[1][i]) \
+    R_SIX(ah[1], am[1], al[1], bh[1], bm[1], bl[1])                                              \
+    __builtin_amdgcn_sched_group_barrier(0x100, 20, 0);                                          \
+    __builtin_amdgcn_sched_group_barrier(0x002, 88, 0);                                          \
+    _Pragma("unroll") for (int k = 0; k < 22; ++k) {                                             \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                         \
+      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                         \
+    }                                                                                            \
+    __builtin_amdgcn_sched_group_barrier(0x008, 26, 0);                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    __syncthreads();                                                                             \
+  }
+
+  R_DMA(sb0)
+  __syncthreads();
+  int par = 0;                          // parity of the B buffer holding the current stage
+#pragma unroll 1
+  for (int nt = nt_beg; nt < nt_end; ++nt) {
+#pragma unroll 1
+    for (int q = 0; q < Q; ++q) {
+      const unsigned short* saq = sa + (size_t)q * (A_UNITS * 8);
+      if (par == 0) R_STEP(saq, sb0, sb1) else R_STEP(saq, sb1, sb0)
+      par ^= 1;
+    }
+    // C tile of column tile nt, in 32 x 32 MFMA-native blocks (this kernel only runs with c_blk)
+    float* Cb = a.C + (size_t)xi * a.c_batch;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int mb = (wm * 64 + i * 32) >> 5, tb = (nt * BN + wn * 64 + j * 32) >> 5;
+        if (mb < a.c_mblk && tb < a.c_tblk) {
+          float* blk = Cb + ((size_t)mb * a.c_tblk + tb) * 1024 + (half * 4 * 32 + l31) * 4;
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *(f32x4*)(blk + g * 128) = f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      }
+  }
+#undef R_STEP
+#undef R_SIX
+#undef R_MFMA
+#undef R_DMA
+}
+
 // The split GEMM on 256 x 256 workgroup tiles.  With the matrix pipe 2.7x faster per fp32-equivalent FLOP the 128 x 128
 // kernel above is bound by the operand stream L2 -> LDS (40 KB and 40 LDS-DMA wave-instructions per 1 MFLOP stage); a
 // 256 x 256 tile halves both per FLOP.  8 waves (2 x 4), each 128 x 64 (4 x 2 MFMA blocks, 128 accumulator registers),
@@ -1394,6 +1545,16 @@ static void wino_gemm_launch(WinoGemmArgs ga, int batches, int splits, hipStream
       const dim3 grid((unsigned)(ga.m_tiles * ga.n_tiles), (unsigned)batches, (unsigned)splits);
       if (ga.bt) hipLaunchKernelGGL((wino_gemm_split_kernel<2, 2, true>), grid, dim3(256), 0, st, ga);
       else hipLaunchKernelGGL((wino_gemm_split_kernel<2, 2>), grid, dim3(256), 0, st, ga);
+      return;
+    }
+    // [r3] one row tile, short reduction, M in blocks: the filter-resident kernel (FCD_WINO_RES=0: off)
+    static int res = -1;
+    if (res < 0) { const char* e = getenv("FCD_WINO_RES"); res = (e && e[0] == '0') ? 0 : 1; }
+    if (res && ga.c_blk && ga.M <= 128 && ga.Kc <= 128 && (long long)cdiv(ga.N, 256) * batches >= 512) {
+      ga.m_tiles = 1; ga.n_tiles = cdiv(ga.N, 256);
+      ga.xb = 1;
+      const int chunks = std::max(1, std::min(ga.n_tiles, 256 / batches));
+      hipLaunchKernelGGL(wino_gemm_split_res_kernel, dim3((unsigned)chunks, (unsigned)batches), dim3(512), 0, st, ga);
       return;
     }
     // FCD_WINO_SPLIT_BIG: 0 = 128 x 128 tiles only; 1 (default) = 256 x 256 two-stage kernel for GEMMs with >= 256
