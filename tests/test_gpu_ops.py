@@ -68,6 +68,10 @@ CONV_CASES = [
     (2, 13, 96, 130, 64, 3, 2, 1),
     (4, 3, 64, 64, 64, 3, 2, 1),
     (1, 14, 66, 64, 33, 3, 1, 1),
+    # filter-resident split GEMM (one 128-row tile, Kc <= 128, >= 512 column-tile x position work items): two and three
+    # reduction stages, a ragged last column tile
+    (4, 64, 128, 128, 128, 3, 1, 1),
+    (6, 96, 100, 116, 128, 3, 1, 1),
 ]
 
 
