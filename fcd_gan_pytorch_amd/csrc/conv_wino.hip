@@ -26,6 +26,9 @@
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+#ifndef FCD_NT_EXP
+#define FCD_NT_EXP 0  // experiments with non-temporal hints: 2 input-transform x loads, 4 B stream of the filter-resident GEMM, 8 blocked C stores
+#endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -417,7 +420,7 @@ __global__ __launch_bounds__(256) void wino_input_roll_kernel(WinoInArgs a, int 
         v[2] = __uint_as_float(cc);
       } else if (idx < 32 * RH * V4 && q * 32 + c < a.C && ih >= 0 && ih < a.H && iw < a.W) {
         const size_t off = img + (size_t)c * plane + (size_t)ih * a.W + iw;
-        v = *(const f32x4*)(xsrc + off);
+        v = (FCD_NT_EXP & 2) ? __builtin_nontemporal_load((const f32x4*)(xsrc + off)) : *(const f32x4*)(xsrc + off);
         if (SRC == 1) {
           // bit mask: keep the RAW tile word in the register (decoded in commit): arithmetic on it here would wait for the
           // load and serialise the strip's prefetch (measured: +2 ms per step with the decode at issue time)
@@ -937,7 +940,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void wino_gem
             float* blk = Cb + ((size_t)mb * a.c_tblk + tb) * 1024 + (half * 4 * 32 + l31) * 4;
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-              *(f32x4*)(blk + g * 128) = f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+              { const f32x4 cv_ = f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                if (FCD_NT_EXP & 8) __builtin_nontemporal_store(cv_, (f32x4*)(blk + g * 128)); else *(f32x4*)(blk + g * 128) = cv_; }
           }
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
@@ -1040,7 +1044,7 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split_res_kernel(WinoGemmArg
     const int n0f = fnt * BN;                                                                    \
     _Pragma("unroll") for (int j = 0; j < PPW_B; ++j)                                            \
       __builtin_amdgcn_global_load_lds((gbl_void_t*)(bs_ + (size_t)min(n0f + b_row[j], a.N - 1) * a.b_ld + b_in[j]), \
-                                       (lds_void_t*)((SB) + (wave + NW * j) * 256), 16, 0, 0);   \
+                                       (lds_void_t*)((SB) + (wave + NW * j) * 256), 16, 0, (FCD_NT_EXP & 4) ? 2 : 0);   \
     if (++fq == Q) { fq = 0; ++fnt; }                                                            \
   }
 #define R_MFMA(AV, BV)                                                                           \
@@ -1104,7 +1108,8 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split_res_kernel(WinoGemmArg
           float* blk = Cb + ((size_t)mb * a.c_tblk + tb) * 1024 + (half * 4 * 32 + l31) * 4;
 #pragma unroll
           for (int g = 0; g < 4; ++g)
-            *(f32x4*)(blk + g * 128) = f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+            { const f32x4 cv_ = f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+              if (FCD_NT_EXP & 8) __builtin_nontemporal_store(cv_, (f32x4*)(blk + g * 128)); else *(f32x4*)(blk + g * 128) = cv_; }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
@@ -1285,7 +1290,8 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split256_kernel(WinoGemmArgs
             float* blk = Cb + ((size_t)mb * a.c_tblk + tb) * 1024 + (half * 4 * 32 + l31) * 4;
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-              *(f32x4*)(blk + g * 128) = f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+              { const f32x4 cv_ = f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                __builtin_nontemporal_store(cv_, (f32x4*)(blk + g * 128)); }      /* M is consumed once, by the output transform: measured -2 ... -4 % on the 256-row launches and their output transforms; the 128-row kernels lose with the same hint */
           }
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
@@ -1739,7 +1745,9 @@ __global__ __launch_bounds__(256) void wino_output_blk_kernel(WinoOutArgs a) {
                     ((((k0 >> 2) & 1) * 4 + ((k0 >> 3) & 3)) * 32 + (int)(t & 31)) * 4;
   f32x4 m4[A * A];
 #pragma unroll
-  for (int q = 0; q < A * A; ++q) m4[q] = *(const f32x4*)(mp + (size_t)q * a.xs_blk);
+  // M is read exactly once: non-temporal loads (measured 5.1 -> 5.6 ... 6.0 TB/s on the 64 x 64 ... 32 x 32 maps; the same hint on
+  // the input transform's V STORES lost 10 - 25 %: dword stores want the L2's write combining)
+  for (int q = 0; q < A * A; ++q) m4[q] = __builtin_nontemporal_load((const f32x4*)(mp + (size_t)q * a.xs_blk));
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     if (k0 + c >= a.K) break;
