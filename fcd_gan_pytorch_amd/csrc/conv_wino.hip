@@ -1559,7 +1559,9 @@ static void wino_gemm_launch(WinoGemmArgs ga, int batches, int splits, hipStream
     if (res && ga.c_blk && ga.M <= 128 && ga.Kc <= 128 && (long long)cdiv(ga.N, 256) * batches >= 512) {
       ga.m_tiles = 1; ga.n_tiles = cdiv(ga.N, 256);
       ga.xb = 1;
-      const int chunks = std::max(1, std::min(ga.n_tiles, 256 / batches));
+      static int wgs = -1;           // workgroups in flight: one per CU (FCD_WINO_RES_WGS for A/B)
+      if (wgs < 0) { const char* e = getenv("FCD_WINO_RES_WGS"); wgs = e ? atoi(e) : 256; }
+      const int chunks = std::max(1, std::min(ga.n_tiles, wgs / batches));
       hipLaunchKernelGGL(wino_gemm_split_res_kernel, dim3((unsigned)chunks, (unsigned)batches), dim3(512), 0, st, ga);
       return;
     }
