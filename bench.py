@@ -166,9 +166,9 @@ def write_layer_tables(path, detail, psteps, args):
                        ('conv_igemm_dgrad', 'direct convolution, data gradient (algorithmic FLOPs)'),
                        ('conv_wino2_fwd', 'fused Winograd F(2x2,3x3) kernel, forward (algorithmic conv FLOPs; executed MFMA FLOPs = x 16/36)'),
                        ('conv_wino2_dgrad', 'fused Winograd F(2x2,3x3) kernel, data gradient (algorithmic conv FLOPs; executed = x 16/36)'),
-                       ('conv_wgrad', 'weight gradient, whole call incl. re-layout / transforms / reduce (ALGORITHMIC FLOPs = direct count; the wide layers execute a quarter of them in Winograd form, so 'of peak' can exceed 1 here -- the bench line prices the family on executed FLOPs)'),
-                       ('conv_wino_fwd', 'Winograd layer calls, forward: three kernels (ALGORITHMIC conv FLOPs: 4x the executed GEMM FLOPs, 'of peak' > 1 is expected)'),
-                       ('conv_wino_dgrad', 'Winograd layer calls, data gradient: three kernels (ALGORITHMIC conv FLOPs: 4x the executed GEMM FLOPs, 'of peak' > 1 is expected)')):
+                       ('conv_wgrad', 'weight gradient, whole call incl. re-layout / transforms / reduce (ALGORITHMIC FLOPs = direct count; the wide layers execute a quarter of them in Winograd form, so "of peak" can exceed 1 here -- the bench line prices the family on executed FLOPs)'),
+                       ('conv_wino_fwd', 'Winograd layer calls, forward: three kernels (ALGORITHMIC conv FLOPs: 4x the executed GEMM FLOPs, "of peak" > 1 is expected)'),
+                       ('conv_wino_dgrad', 'Winograd layer calls, data gradient: three kernels (ALGORITHMIC conv FLOPs: 4x the executed GEMM FLOPs, "of peak" > 1 is expected)')):
         rr = rows(fam)
         if not rr:
             continue
