@@ -25,9 +25,9 @@ __all__ = ['DoubleConv', 'Down', 'Up', 'OutConv', 'Segmentor', 'Generator', 'Res
            'Discriminator_SRGAN_simple']
 
 
-def _conv(holder, x):
-    """Apply an nn.Conv2d parameter holder through the MFMA implicit-GEMM kernel."""
-    return ops.conv2d(x, holder.weight, holder.bias, holder.stride[0], holder.padding[0])
+def _conv(holder, x, bn_groups=0):
+    """Apply an nn.Conv2d parameter holder through the HIP convolution kernels (``bn_groups``: see ops.conv2d)."""
+    return ops.conv2d(x, holder.weight, holder.bias, holder.stride[0], holder.padding[0], bn_groups=bn_groups)
 
 
 class DoubleConv(nn.Module):
@@ -50,8 +50,9 @@ class DoubleConv(nn.Module):
             # conv+BN+ReLU becomes ONE kernel (MFMA conv with the bias+ReLU epilogue)
             (w0, b0), (w1, b1) = self._folded_params()
             return ops.conv2d(ops.conv2d(x, w0, b0, 1, 1, relu=True), w1, b1, 1, 1, relu=True)
-        x = ops.bn_act(_conv(s[0], x), s[1], ops.ACT_RELU, groups=groups)
-        return ops.bn_act(_conv(s[3], x), s[4], ops.ACT_RELU, groups=groups)
+        g = groups if self.training else 0        # train-mode BatchNorm behind the conv: statistics out of its output transform
+        x = ops.bn_act(_conv(s[0], x, bn_groups=g), s[1], ops.ACT_RELU, groups=groups)
+        return ops.bn_act(_conv(s[3], x, bn_groups=g), s[4], ops.ACT_RELU, groups=groups)
 
     def forward_pair_cat(self, f2n, up):
         """``forward(torch.cat([f2n[:n], f2n[n:], up], dim=1))`` with the first convolution reading the three tensors in
@@ -60,8 +61,9 @@ class DoubleConv(nn.Module):
         if not self.training and not torch.is_grad_enabled():
             (w0, b0), (w1, b1) = self._folded_params()
             return ops.conv2d(ops.conv3x3_pair_cat(f2n, up, w0, b0, relu=True), w1, b1, 1, 1, relu=True)
-        x = ops.bn_act(ops.conv3x3_pair_cat(f2n, up, s[0].weight, s[0].bias), s[1], ops.ACT_RELU)
-        return ops.bn_act(_conv(s[3], x), s[4], ops.ACT_RELU)
+        g = 1 if self.training else 0
+        x = ops.bn_act(ops.conv3x3_pair_cat(f2n, up, s[0].weight, s[0].bias, bn_groups=g), s[1], ops.ACT_RELU)
+        return ops.bn_act(_conv(s[3], x, bn_groups=g), s[4], ops.ACT_RELU)
 
     def _folded_params(self):
         s = self.double_conv

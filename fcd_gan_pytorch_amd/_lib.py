@@ -55,6 +55,10 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+class WinoFwdExtras(Structure):
+    _fields_ = [('v_keep', c_void_p), ('bn_part', c_void_p), ('bn_groups', c_int32)]
+
+
 class ConvDesc(Structure):
     _fields_ = [(n, c_int32) for n in ('N', 'C', 'H', 'W', 'K', 'R', 'S', 'stride', 'pad', 'P', 'Q')]
 
@@ -80,6 +84,10 @@ _SIGS = {
     'fcd_conv2d_bwd_weight_bias_cat': (c_int, [P, P, P, c_int, P, P, P, P, P, c_size_t, P]),
     'fcd_conv_wino_ws_bytes': (c_size_t, [POINTER(ConvDesc), c_int]),
     'fcd_conv_wino_keepv_bytes': (c_size_t, [POINTER(ConvDesc)]),
+    'fcd_conv_wino_bn_split': (c_int, [POINTER(ConvDesc), c_int]),
+    'fcd_conv_wino_bn_part_bytes': (c_size_t, [POINTER(ConvDesc), c_int]),
+    'fcd_conv2d_fwd_wino_x': (c_int, [POINTER(ConvDesc), P, P, P, P, c_int, P, P, P, c_size_t, P, P]),
+    'fcd_conv2d_fwd_wino_cat_x': (c_int, [P, P, P, c_int, P, P, P, c_int, P, c_size_t, P, P]),
     'fcd_conv_wino_relu_bits_bytes': (c_size_t, [POINTER(ConvDesc)]),
     'fcd_conv2d_fwd_wino_relu_bits': (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, c_size_t, P]),
     'fcd_conv2d_bwd_data_wino_bits': (c_int, [POINTER(ConvDesc), P, P, P, P, P, c_size_t, P]),
@@ -112,6 +120,8 @@ _SIGS = {
                                P, P, c_int, P, c_float, P, c_size_t, P]),
     'fcd_bn_act_bwd': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_float, c_int, P, P,
                                c_int, P, c_float, P, P, P, P, c_size_t, P]),
+    'fcd_bn_act_fwd_parts': (c_int, [P, P, c_int, c_int, c_int, c_int, P, c_int, P, P, P, P, c_float, c_float, P, P, c_int, P, c_float,
+                                     P, c_size_t, P]),
     'fcd_bn_partial_stats': (c_int, [P, P, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     'fcd_bn_act_fwd_from_stats': (c_int, [P, P, c_int, c_int, c_int, c_int, P, c_double, P, P, P, P, c_float, c_float,
                                           P, P, c_int, P, c_float, P, c_size_t, P]),

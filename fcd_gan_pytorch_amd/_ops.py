@@ -112,6 +112,21 @@ def wino2_weight(weight, mode):
     return _shared(U)
 
 
+def _bn_part(d, groups, relu, device):
+    """Buffer for the per-workgroup BatchNorm partial sums the F(4x4) output transform can leave behind for the BatchNorm
+    that follows this convolution (fcd_conv_wino_bn_part_bytes > 0), else None."""
+    if not groups or relu or device.type != 'cuda':
+        return None
+    nb = lib.fcd_conv_wino_bn_part_bytes(ctypes.byref(d), int(groups))
+    return torch.empty(nb // 8, dtype=torch.float64, device=device) if nb else None
+
+
+def _tag_bn(y, d, part, groups):
+    if part is not None:
+        y._fcd_bn = (part, int(lib.fcd_conv_wino_bn_split(ctypes.byref(d), int(groups))), int(groups))
+    return y
+
+
 def _keepv(d, want_dw, device):
     """Buffer for the forward pass's transformed input when this layer's weight gradient can consume it
     (fcd_conv_wino_keepv_bytes > 0 and a weight gradient will be asked for: ``ctx.needs_input_grad``), else None."""
@@ -121,9 +136,15 @@ def _keepv(d, want_dw, device):
     return torch.empty(nb // 4, dtype=torch.float32, device=device) if nb else None
 
 
-def _fwd_conv(d, x, weight, bias, y, relu, pool_y=None, code=None, v_keep=None):
+def _extras(v_keep, bn_part, bn_groups):
+    ex = _lib.WinoFwdExtras(v_keep.data_ptr() if v_keep is not None else None,
+                            bn_part.data_ptr() if bn_part is not None else None, int(bn_groups))
+    return ctypes.byref(ex)
+
+
+def _fwd_conv(d, x, weight, bias, y, relu, pool_y=None, code=None, v_keep=None, bn_part=None, bn_groups=0):
     """Forward launch: fused F(2x2) kernel for the 64-row layers, three-kernel F(4x4) for the wide ones when the
-    library plans them so, else direct.  ``v_keep``: see :func:`_keepv`."""
+    library plans them so, else direct.  ``v_keep``: see :func:`_keepv`; ``bn_part``: see :func:`_bn_part`."""
     if lib.fcd_conv_wino2_plan(ctypes.byref(d), 0):
         check(lib.fcd_conv2d_fwd_wino2(ctypes.byref(d), _p(x), _p(wino2_weight(weight, 0)), _p(bias), _p(y),
                                        ACT_RELU if relu else ACT_NONE, None, 0.0, None, _p(pool_y), _p(code), _stream()),
@@ -132,8 +153,8 @@ def _fwd_conv(d, x, weight, bias, y, relu, pool_y=None, code=None, v_keep=None):
     m = lib.fcd_conv_wino_plan(ctypes.byref(d), 0)
     if m:
         ws = _ws(lib.fcd_conv_wino_ws_bytes(ctypes.byref(d), 0), x.device)
-        check(lib.fcd_conv2d_fwd_wino_keepv(ctypes.byref(d), _p(x), _p(wino_weight(weight, 0, m)), _p(bias), _p(y), int(relu),
-                                            _p(pool_y), _p(code), _p(ws), ws.numel(), _p(v_keep), _stream()),
+        check(lib.fcd_conv2d_fwd_wino_x(ctypes.byref(d), _p(x), _p(wino_weight(weight, 0, m)), _p(bias), _p(y), int(relu),
+                                        _p(pool_y), _p(code), _p(ws), ws.numel(), _extras(v_keep, bn_part, bn_groups), _stream()),
               'fcd_conv2d_fwd_wino')
     elif pool_y is not None:
         check(lib.fcd_conv2d_fwd_relu_pool(ctypes.byref(d), _p(x), _p(packed_weight(weight, 0)), _p(bias), _p(pool_y),
@@ -204,7 +225,7 @@ def _channel_sum(t, mask, N, C, HW):
 
 class _Conv2d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, relu):
+    def forward(ctx, x, weight, bias, stride, pad, relu, bn_part=None, bn_groups=0):
         x = _dev(x, 'conv input')
         _dev(weight, 'conv weight')
         d = _desc(x.shape, weight.shape, stride, pad)
@@ -229,7 +250,7 @@ class _Conv2d(torch.autograd.Function):
         vk = None
         if bits is None and wbits is None:
             vk = _keepv(d, ctx.needs_input_grad[1], x.device)
-            _fwd_conv(d, x, weight, b, y, relu, v_keep=vk)
+            _fwd_conv(d, x, weight, b, y, relu, v_keep=vk, bn_part=bn_part, bn_groups=bn_groups)
         # x is only needed for the weight gradient (or, on the wide F(4x4) layers, its transform V kept by the forward
         # pass instead); the fused-ReLU output doubles as the backward mask
         ctx.save_for_backward(x if (weight.requires_grad and vk is None) else None, weight,
@@ -270,7 +291,7 @@ class _Conv2d(torch.autograd.Function):
                                                      ws.numel(), _stream()), 'fcd_conv2d_bwd_weight_bias')
         elif want_db:
             db = _channel_sum(dy, yrelu, d.N, d.K, d.P * d.Q)
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
 def _ptr_list(ptrs):
@@ -285,7 +306,7 @@ class _ConvPairCat(torch.autograd.Function):
     order as ``conv2d(torch.cat(...))`` => bit-identical results."""
 
     @staticmethod
-    def forward(ctx, f2n, up, weight, bias, relu):
+    def forward(ctx, f2n, up, weight, bias, relu, bn_part=None, bn_groups=0):
         f2n, up = _dev(f2n, 'skip pair'), _dev(up, 'upsampled input')
         n, cu, H, W = up.shape
         c = f2n.shape[1]
@@ -297,8 +318,8 @@ class _ConvPairCat(torch.autograd.Function):
         ws = _ws(lib.fcd_conv_wino_ws_bytes(ctypes.byref(d), 0), up.device)
         b = _dev(bias, 'conv bias') if bias is not None else None
         vk = _keepv(d, ctx.needs_input_grad[2], up.device)
-        check(lib.fcd_conv2d_fwd_wino_cat_keepv(ctypes.byref(d), srcs, chans, 3, _p(wino_weight(weight, 0, 4)), _p(b), _p(y),
-                                                1 if relu else 0, _p(ws), ws.numel(), _p(vk), _stream()),
+        check(lib.fcd_conv2d_fwd_wino_cat_x(ctypes.byref(d), srcs, chans, 3, _p(wino_weight(weight, 0, 4)), _p(b), _p(y),
+                                            1 if relu else 0, _p(ws), ws.numel(), _extras(vk, bn_part, bn_groups), _stream()),
               'fcd_conv2d_fwd_wino_cat')
         keep_x = weight.requires_grad and vk is None
         ctx.save_for_backward(f2n if keep_x else None, up if keep_x else None, weight, y if relu else None, vk)
@@ -340,7 +361,7 @@ class _ConvPairCat(torch.autograd.Function):
                       'fcd_conv2d_bwd_weight_bias_cat')
         elif want_db:
             db = _channel_sum(dy, yrelu, d.N, d.K, d.P * d.Q)
-        return df, du, dw, db, None
+        return df, du, dw, db, None, None, None
 
 
 def conv3x3_pair_cat_ok(f2n, up, weight):
@@ -357,14 +378,25 @@ def conv3x3_pair_cat_ok(f2n, up, weight):
     return bool(lib.fcd_conv_wino_cat_ok(ctypes.byref(d)))
 
 
-def conv3x3_pair_cat(f2n, up, weight, bias=None, relu=False):
+def conv3x3_pair_cat(f2n, up, weight, bias=None, relu=False, bn_groups=0):
     """conv3x3(cat([f2n[:n], f2n[n:], up], dim=1)) (+bias, + fused ReLU) without building the concatenation; check with
-    :func:`conv3x3_pair_cat_ok` first."""
-    return _ConvPairCat.apply(f2n, up, weight, bias, bool(relu))
+    :func:`conv3x3_pair_cat_ok` first.  ``bn_groups``: see :func:`conv2d`."""
+    n, cu, H, W = up.shape
+    d = _desc((n, 2 * f2n.shape[1] + cu, H, W), weight.shape, 1, 1)
+    part = _bn_part(d, bn_groups, relu, up.device)
+    return _tag_bn(_ConvPairCat.apply(f2n, up, weight, bias, bool(relu), part, int(bn_groups)), d, part, bn_groups)
 
 
-def conv2d(x, weight, bias=None, stride=1, padding=0, relu=False):
-    """conv2d (+bias) (+fused ReLU epilogue when ``relu``)."""
+def conv2d(x, weight, bias=None, stride=1, padding=0, relu=False, bn_groups=0):
+    """conv2d (+bias) (+fused ReLU epilogue when ``relu``).  ``bn_groups`` > 0: a train-mode BatchNorm with that many sample
+    groups follows (reference Module.py:25-31); where the layer runs as F(4x4) its output transform also leaves the
+    BatchNorm's partial sums behind (tagged on the result, picked up by :func:`bn_act`: no statistics pass over y)."""
+    part = None
+    if bn_groups and not relu and x.is_cuda:
+        d = _desc(x.shape, weight.shape, int(stride), int(padding))
+        part = _bn_part(d, bn_groups, relu, x.device)
+        if part is not None:
+            return _tag_bn(_Conv2d.apply(x, weight, bias, int(stride), int(padding), False, part, int(bn_groups)), d, part, bn_groups)
     return _Conv2d.apply(x, weight, bias, int(stride), int(padding), bool(relu))
 
 
@@ -503,7 +535,14 @@ class _BnAct(torch.autograd.Function):
             save_invstd = torch.empty(groups * C, dtype=torch.float32, device=x.device)
         ws = _ws(lib.fcd_bn_act_ws_bytes(C, groups), x.device)
         world = _sync_world() if (has_bn and training) else 0
-        if world:
+        parts = getattr(x, '_fcd_bn', None) if (has_bn and training and not world) else None
+        if parts is not None and parts[2] == groups and parts[1] > 0:
+            # the producing convolution's output transform already summed y and y^2 per workgroup (conv2d(bn_groups=...))
+            check(lib.fcd_bn_act_fwd_parts(_p(x), _p(y), N, C, H * W, groups, _p(parts[0]), parts[1], _p(gamma), _p(beta),
+                                           _p(running_mean), _p(running_var), float(momentum), float(eps), _p(save_mean),
+                                           _p(save_invstd), act, _p(slope), float(slope_imm), _p(ws), ws.numel(), _stream()),
+                  'fcd_bn_act_fwd_parts')
+        elif world:
             import torch.distributed as dist
             sums = torch.empty(groups * C * 2, dtype=torch.float64, device=x.device)
             check(lib.fcd_bn_partial_stats(_p(x), _p(sums), N, C, H * W, groups, _p(ws), ws.numel(), _stream()),

@@ -1622,11 +1622,14 @@ struct WinoOutArgs {
   int tblk;             // wino_output_blk_kernel: Mb in the split GEMM's 32 x 32 blocks (WinoGemmArgs.c_blk): blocks per
   long long xs_blk;     // row block, floats per xi
   unsigned short* bits; // [r3] m = 4, relu, no pooling: sign of the outputs, 16 bits per (n, k, tile) (WinoInArgs.mbits)
+  double* bn_part;      // [r3] wino_output_blk_kernel: per-workgroup {sum y, sum y^2} of each channel for the BatchNorm that follows
+  int bn_bpg;           //      (reference Module.py:25-31: Conv2d -> BatchNorm2d): part[((g K + k) bn_bpg + block in group) 3 + {0, 1}],
+                        //      bn_bpg = workgroups per sample group (a workgroup's 256 tiles never straddle two groups: host-checked)
 };
 
 template <int MM>
 __device__ __forceinline__ void wino_out_one(const WinoOutArgs& a, const float (&mv)[WinoMat<MM>::A][WinoMat<MM>::A], int k,
-                                             long long t) {
+                                             long long t, double* s1 = nullptr, double* s2 = nullptr) {
   constexpr int A = WinoMat<MM>::A;
   float t1[MM][A];   // A^T M
 #pragma unroll
@@ -1656,6 +1659,15 @@ __device__ __forceinline__ void wino_out_one(const WinoOutArgs& a, const float (
   const int tx = (int)(t % a.TW);
   const long long r2 = t / a.TW;
   const int ty = (int)(r2 % a.TH), n = (int)(r2 / a.TH);
+  if (s1 != nullptr) {           // statistics of the outputs that exist (ragged last tile row / column left out)
+    double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < MM; ++i)
+#pragma unroll
+      for (int j = 0; j < MM; ++j)
+        if (ty * MM + i < a.P && tx * MM + j < a.Q) { a1 += (double)o[i][j]; a2 += (double)o[i][j] * (double)o[i][j]; }
+    *s1 = a1; *s2 = a2;
+  }
   if (MM == 4 && a.bits != nullptr) {
     unsigned w = 0;
 #pragma unroll
@@ -1757,6 +1769,50 @@ __global__ __launch_bounds__(256) void wino_output_blk_kernel(WinoOutArgs a) {
 #pragma unroll
     for (int q = 0; q < A * A; ++q) mv[q / A][q % A] = m4[q][c];
     wino_out_one<4>(a, mv, k0 + c, t);
+  }
+}
+
+// the same with the BatchNorm partial sums: every thread stays to the end (block reduction), fp64, fixed order
+__global__ __launch_bounds__(256) void wino_output_blk_bn_kernel(WinoOutArgs a) {
+  constexpr int A = 6;
+  __shared__ double red[4][8];
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int k0 = blockIdx.y * 4;
+  const bool live = t < a.T;
+  double bs[4][2];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) bs[c][0] = bs[c][1] = 0.0;
+  if (live) {
+    const float* mp = a.Mb + ((size_t)(k0 >> 5) * a.tblk + (size_t)(t >> 5)) * 1024 +
+                      ((((k0 >> 2) & 1) * 4 + ((k0 >> 3) & 3)) * 32 + (int)(t & 31)) * 4;
+    f32x4 m4[A * A];
+#pragma unroll
+    for (int q = 0; q < A * A; ++q) m4[q] = __builtin_nontemporal_load((const f32x4*)(mp + (size_t)q * a.xs_blk));
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (k0 + c >= a.K) break;
+      float mv[A][A];
+#pragma unroll
+      for (int q = 0; q < A * A; ++q) mv[q / A][q % A] = m4[q][c];
+      wino_out_one<4>(a, mv, k0 + c, t, &bs[c][0], &bs[c][1]);
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const double v = wave_sum_d(bs[c][e]);
+      if (lane == 0) red[wave][c * 2 + e] = v;
+    }
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    const int c = threadIdx.x >> 1, e = threadIdx.x & 1;
+    if (k0 + c < a.K) {
+      const double v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+      const int g = (int)(blockIdx.x / a.bn_bpg), bi = (int)(blockIdx.x % a.bn_bpg);
+      a.bn_part[(((size_t)g * a.K + (k0 + c)) * a.bn_bpg + bi) * 3 + e] = v;
+    }
   }
 }
 
@@ -1924,11 +1980,23 @@ static bool wino_cat_input_ok(const WinoPlan& pl, int W) {
 
 // shared by forward and data gradient: src tensor (in_ch channels, H x W logical extent) -> out tensor
 // (rows channels, H x W)
+// [r3] M in 32 x 32 MFMA-native blocks whenever the split kernels run the GEMM (FCD_WINO_CBLK=0: row-major M, A/B)
+static bool wino_blk_path(const WinoPlan& pl) {
+  static int cblk_on = -1;
+  if (cblk_on < 0) {
+    const char* e = getenv("FCD_WINO_CBLK");
+    const char* e2 = getenv("FCD_WINO_SPLIT_BIG");
+    cblk_on = ((e && e[0] == '0') || (e2 && atoi(e2) >= 4)) ? 0 : 1;      // (the ping-pong experiment kernel writes row-major)
+  }
+  return cblk_on && pl.m == 4 && pl.rows > 64 && wino_split() && (pl.rows & 3) == 0;
+}
+
 static int wino_run(const WinoPlan& pl, int N, int in_ch, int H, int W, const float* src, const float* mask,
                     const unsigned char* code_in, int Hp, int Wp, const float* U, const float* bias, int relu, float* y,
                     float* pool_y, unsigned char* code_out, void* ws, hipStream_t st,
                     const WinoCat* in_cat = nullptr, const WinoCat* out_cat = nullptr, float* v_keep = nullptr,
-                    const unsigned short* mask_bits = nullptr, unsigned short* relu_bits_out = nullptr) {
+                    const unsigned short* mask_bits = nullptr, unsigned short* relu_bits_out = nullptr,
+                    double* bn_part = nullptr, int bn_bpg = 0) {
   float* V = v_keep ? v_keep : (float*)ws;       // v_keep: the caller keeps the transformed input for the weight gradient
   float* Mb = (float*)((char*)ws + ((pl.v_bytes + 255) & ~(size_t)255));
   WinoInArgs ia;
@@ -1962,14 +2030,7 @@ static int wino_run(const WinoPlan& pl, int N, int in_ch, int H, int W, const fl
   ga.As = (const unsigned short*)(U + ga.as_plane);
   ga.b_ld = 32; ga.b_adv = (long long)pl.T * 32; ga.b_batch = (long long)pl.Q * pl.T * 32;   // V [xi][Q][T][32]
   ga.stages_per_split = pl.Q;
-  // [r3] M in 32 x 32 MFMA-native blocks whenever the split kernels run the GEMM (FCD_WINO_CBLK=0: row-major M, A/B)
-  static int cblk_on = -1;
-  if (cblk_on < 0) {
-    const char* e = getenv("FCD_WINO_CBLK");
-    const char* e2 = getenv("FCD_WINO_SPLIT_BIG");
-    cblk_on = ((e && e[0] == '0') || (e2 && atoi(e2) >= 4)) ? 0 : 1;      // (the ping-pong experiment kernel writes row-major)
-  }
-  const bool blk = cblk_on && pl.m == 4 && pl.rows > 64 && wino_split() && (pl.rows & 3) == 0;
+  const bool blk = wino_blk_path(pl);
   if (blk) {
     ga.c_blk = 1; ga.c_mblk = cdiv(pl.rows, 32); ga.c_tblk = (int)((pl.T + 31) / 32);
     ga.c_batch = (long long)ga.c_mblk * ga.c_tblk * 1024;
@@ -1994,7 +2055,13 @@ static int wino_run(const WinoPlan& pl, int N, int in_ch, int H, int W, const fl
                     fcd_prof_tagf("out pool=%d K=%d img=%dx%dx%d", pool_y ? 1 : 0, pl.rows, N, H, W));
     if (blk) {
       oa.tblk = ga.c_tblk; oa.xs_blk = ga.c_batch;
-      hipLaunchKernelGGL(wino_output_blk_kernel, dim3((unsigned)cdiv64(pl.T, 256), (unsigned)cdiv(pl.rows, 4)), dim3(256), 0, st, oa);
+      const dim3 ogb((unsigned)cdiv64(pl.T, 256), (unsigned)cdiv(pl.rows, 4));
+      if (bn_part) {
+        oa.bn_part = bn_part; oa.bn_bpg = bn_bpg;
+        hipLaunchKernelGGL(wino_output_blk_bn_kernel, ogb, dim3(256), 0, st, oa);
+      } else {
+        hipLaunchKernelGGL(wino_output_blk_kernel, ogb, dim3(256), 0, st, oa);
+      }
     } else if (pl.m == 2) hipLaunchKernelGGL(wino_output_kernel<2>, og, dim3(256), 0, st, oa);
     else hipLaunchKernelGGL(wino_output_kernel<4>, og, dim3(256), 0, st, oa);
   }
@@ -2014,6 +2081,9 @@ static double wino_bytes(const WinoPlan& pl) {
 // again (fcd_conv2d_fwd_wino_keepv -> fcd_conv2d_bwd_weight_bias_v); 0 when the layer's passes do not line up that way
 extern "C" size_t fcd_conv_wino_keepv_bytes(const fcd_conv_desc* d);
 
+extern "C" int fcd_conv2d_fwd_wino_x(const fcd_conv_desc* d, const float* x, const float* U, const float* bias, float* y,
+                                     int fuse_relu, float* pool_y, unsigned char* code, void* ws, size_t ws_bytes,
+                                     const fcd_wino_fwd_extras* ex, void* stream);
 extern "C" int fcd_conv2d_fwd_wino_keepv(const fcd_conv_desc* d, const float* x, const float* U, const float* bias, float* y,
                                          int fuse_relu, float* pool_y, unsigned char* code, void* ws, size_t ws_bytes,
                                          float* v_keep, void* stream);
@@ -2025,7 +2095,36 @@ extern "C" int fcd_conv2d_fwd_wino(const fcd_conv_desc* d, const float* x, const
 extern "C" int fcd_conv2d_fwd_wino_keepv(const fcd_conv_desc* d, const float* x, const float* U, const float* bias, float* y,
                                          int fuse_relu, float* pool_y, unsigned char* code, void* ws, size_t ws_bytes,
                                          float* v_keep, void* stream) {
+  fcd_wino_fwd_extras ex;
+  memset(&ex, 0, sizeof(ex));
+  ex.v_keep = v_keep;
+  return fcd_conv2d_fwd_wino_x(d, x, U, bias, y, fuse_relu, pool_y, code, ws, ws_bytes, &ex, stream);
+}
+
+// workgroups of the output transform per BatchNorm sample group, 0 when the statistics cannot come out of it (layer not
+// on the blocked F(4x4) path, or a workgroup's 256 tiles would straddle two groups)
+extern "C" int fcd_conv_wino_bn_split(const fcd_conv_desc* d, int groups) {
+  WinoPlan pl;
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("FCD_WINO_BNSTATS"); on = (e && e[0] == '0') ? 0 : 1; }
+  if (!d || !on || groups < 1 || !wino_plan(d, 0, &pl) || !wino_blk_path(pl) || d->N % groups) return 0;
+  const long long per_group = pl.T / groups;
+  if (per_group < 256 || per_group % 256) return 0;
+  return (int)(per_group / 256);
+}
+extern "C" size_t fcd_conv_wino_bn_part_bytes(const fcd_conv_desc* d, int groups) {
+  return (size_t)fcd_conv_wino_bn_split(d, groups) * groups * d->K * 3 * sizeof(double);
+}
+
+extern "C" int fcd_conv2d_fwd_wino_x(const fcd_conv_desc* d, const float* x, const float* U, const float* bias, float* y,
+                                     int fuse_relu, float* pool_y, unsigned char* code, void* ws, size_t ws_bytes,
+                                     const fcd_wino_fwd_extras* ex, void* stream) {
+  float* v_keep = ex ? ex->v_keep : nullptr;
+  double* bn_part = ex ? ex->bn_part : nullptr;
+  const int bn_bpg = bn_part ? fcd_conv_wino_bn_split(d, ex->bn_groups) : 0;
   FCD_CHECK_ARG(d && x && U && (y || (pool_y && code)), "fcd_conv2d_fwd_wino: null pointer");
+  FCD_CHECK_ARG(!bn_part || (bn_bpg > 0 && !pool_y && !fuse_relu), "fcd_conv2d_fwd_wino_x: BatchNorm partial sums not available for this call "
+                "(fcd_conv_wino_bn_split(d, groups) == 0, or a fused ReLU / pool in front of the BatchNorm)");
   FCD_CHECK_ARG(!v_keep || fcd_conv_wino_keepv_bytes(d) > 0, "fcd_conv2d_fwd_wino_keepv: fcd_conv_wino_keepv_bytes(d) == 0 for this layer");
   WinoPlan pl;
   FCD_CHECK_ARG(wino_plan(d, 0, &pl), "fcd_conv2d_fwd_wino: layer is not planned for the Winograd path");
@@ -2035,7 +2134,7 @@ extern "C" int fcd_conv2d_fwd_wino_keepv(const fcd_conv_desc* d, const float* x,
   }
   FcdProfScope prof(FCD_K_WINO_FWD, (hipStream_t)stream, conv_flops(d), wino_bytes(pl), fcd_prof_tag_desc("wino_fwd", d));
   wino_run(pl, d->N, d->C, d->H, d->W, x, nullptr, nullptr, 0, 0, U, bias, (fuse_relu || pool_y) ? 1 : 0,
-           pool_y ? nullptr : y, pool_y, code, ws, (hipStream_t)stream, nullptr, nullptr, v_keep);
+           pool_y ? nullptr : y, pool_y, code, ws, (hipStream_t)stream, nullptr, nullptr, v_keep, nullptr, nullptr, bn_part, bn_bpg);
   FCD_LAUNCH_CHECK("conv2d_fwd_wino");
   return FCD_OK;
 }
@@ -2536,10 +2635,25 @@ extern "C" int fcd_conv2d_fwd_wino_cat(const fcd_conv_desc* d, const float* cons
                                        void* stream) {
   return fcd_conv2d_fwd_wino_cat_keepv(d, src, chans, nsrc, U, bias, y, fuse_relu, ws, ws_bytes, nullptr, stream);
 }
+extern "C" int fcd_conv2d_fwd_wino_cat_x(const fcd_conv_desc* d, const float* const* src, const int* chans, int nsrc,
+                                         const float* U, const float* bias, float* y, int fuse_relu, void* ws,
+                                         size_t ws_bytes, const fcd_wino_fwd_extras* ex, void* stream);
 extern "C" int fcd_conv2d_fwd_wino_cat_keepv(const fcd_conv_desc* d, const float* const* src, const int* chans, int nsrc,
                                              const float* U, const float* bias, float* y, int fuse_relu, void* ws,
                                              size_t ws_bytes, float* v_keep, void* stream) {
+  fcd_wino_fwd_extras ex;
+  memset(&ex, 0, sizeof(ex));
+  ex.v_keep = v_keep;
+  return fcd_conv2d_fwd_wino_cat_x(d, src, chans, nsrc, U, bias, y, fuse_relu, ws, ws_bytes, &ex, stream);
+}
+extern "C" int fcd_conv2d_fwd_wino_cat_x(const fcd_conv_desc* d, const float* const* src, const int* chans, int nsrc,
+                                         const float* U, const float* bias, float* y, int fuse_relu, void* ws,
+                                         size_t ws_bytes, const fcd_wino_fwd_extras* ex, void* stream) {
+  float* v_keep = ex ? ex->v_keep : nullptr;
+  double* bn_part = ex ? ex->bn_part : nullptr;
+  const int bn_bpg = bn_part ? fcd_conv_wino_bn_split(d, ex->bn_groups) : 0;
   FCD_CHECK_ARG(d && U && y, "fcd_conv2d_fwd_wino_cat: null pointer");
+  FCD_CHECK_ARG(!bn_part || (bn_bpg > 0 && !fuse_relu), "fcd_conv2d_fwd_wino_cat_x: BatchNorm partial sums not available for this call");
   FCD_CHECK_ARG(!v_keep || fcd_conv_wino_keepv_bytes(d) > 0, "fcd_conv2d_fwd_wino_cat_keepv: fcd_conv_wino_keepv_bytes(d) == 0 for this layer");
   WinoCat cat;
   FCD_CHECK_ARG(wino_cat_fill(&cat, src, chans, nsrc, d->C),
@@ -2553,7 +2667,7 @@ extern "C" int fcd_conv2d_fwd_wino_cat_keepv(const fcd_conv_desc* d, const float
   }
   FcdProfScope prof(FCD_K_WINO_FWD, (hipStream_t)stream, conv_flops(d), wino_bytes(pl), fcd_prof_tag_desc("wino_fwd", d));
   wino_run(pl, d->N, d->C, d->H, d->W, cat.p[0], nullptr, nullptr, 0, 0, U, bias, fuse_relu ? 1 : 0, y, nullptr, nullptr, ws,
-           (hipStream_t)stream, &cat, nullptr, v_keep);
+           (hipStream_t)stream, &cat, nullptr, v_keep, nullptr, nullptr, bn_part, bn_bpg);
   FCD_LAUNCH_CHECK("conv2d_fwd_wino_cat");
   return FCD_OK;
 }

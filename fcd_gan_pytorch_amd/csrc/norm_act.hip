@@ -446,6 +446,30 @@ extern "C" int fcd_bn_act_fwd_from_stats(const float* x, float* y, int N, int C,
   return FCD_OK;
 }
 
+// [r3] train-mode y = act(BN(x)) from per-workgroup partial sums the PRODUCING convolution left behind
+// (fcd_conv2d_fwd_wino_x: part[(g C + c) split + s][3], {sum, sum of squares, -}): the statistics pass over x is gone.
+extern "C" int fcd_bn_act_fwd_parts(const float* x, float* y, int N, int C, int HW, int groups, const double* part, int split,
+                                    const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                    float momentum, float eps, float* save_mean, float* save_invstd, int act,
+                                    const float* slope, float slope_imm, void* ws, size_t ws_bytes, void* stream) {
+  FCD_CHECK_ARG(x && y && part && split > 0 && gamma && beta && save_mean && save_invstd && groups > 0 && N % groups == 0,
+                "fcd_bn_act_fwd_parts: bad arguments");
+  if (!ws || ws_bytes < fcd_bn_act_ws_bytes(C, groups)) {
+    fcd_set_error("fcd_bn_act_fwd_parts: workspace too small");
+    return FCD_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  BnWs w = carve(ws, C, groups);
+  const int Ng = N / groups;
+  FcdProfScope prof(FCD_K_NORM, st, 0.0, 8.0 * N * C * (double)HW);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, part, C, groups, split, (double)Ng * HW, gamma,
+                     beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, w.scale, w.shift);
+  hipLaunchKernelGGL(bn_act_apply_kernel, plane_grid(N * C, HW), dim3(256), 0, st, x, y, C, HW, Ng, 1,
+                     (const float*)w.scale, (const float*)w.shift, act, slope, slope_imm);
+  FCD_LAUNCH_CHECK("bn_act_fwd_parts");
+  return FCD_OK;
+}
+
 extern "C" int fcd_bn_bwd_partial(const float* dz, const float* x, double* out, int N, int C, int HW, int groups,
                                   const float* gamma, const float* beta, const float* save_mean,
                                   const float* save_invstd, int act, const float* slope, float slope_imm, void* ws,

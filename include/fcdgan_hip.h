@@ -123,6 +123,25 @@ int fcd_conv2d_bwd_weight_bias_cat(const fcd_conv_desc* d, const float* const* s
  * the weight gradient's own input transform, 1.6 ms per Demo_RSSS step, disappears; the GEMM reads V transposed).  The
  * autograd tape of reference Module.py:25-31 keeps x for the weight gradient; here it keeps V instead.  Workspace of the
  * _v call: fcd_conv2d_bwd_weight_ws_bytes(d). */
+/* Optional outputs of the F(4x4) forward calls (fcd_conv2d_fwd_wino_x / _cat_x; NULL pointers = not wanted):
+ *   v_keep   the transformed input V for the weight gradient (above; fcd_conv_wino_keepv_bytes)
+ *   bn_part  per-workgroup {sum y, sum y^2} of every output channel and BatchNorm sample group -- the statistics pass of the
+ *            BatchNorm2d that follows the convolution (reference Module.py:25-31, 177-181) done by the output transform while
+ *            y is in registers; hand it to fcd_bn_act_fwd_parts.  Layout [(g K + k) split + s][3] doubles with
+ *            split = fcd_conv_wino_bn_split(d, groups) (0: not available for this layer / grouping), no fused ReLU. */
+typedef struct fcd_wino_fwd_extras {
+  float* v_keep;
+  double* bn_part;
+  int32_t bn_groups;
+} fcd_wino_fwd_extras;
+int fcd_conv_wino_bn_split(const fcd_conv_desc* d, int groups);
+size_t fcd_conv_wino_bn_part_bytes(const fcd_conv_desc* d, int groups);
+int fcd_conv2d_fwd_wino_x(const fcd_conv_desc* d, const float* x, const float* U, const float* bias, float* y, int fuse_relu,
+                          float* pool_y, unsigned char* code, void* ws, size_t ws_bytes, const fcd_wino_fwd_extras* ex,
+                          void* stream);
+int fcd_conv2d_fwd_wino_cat_x(const fcd_conv_desc* d, const float* const* src, const int* chans, int nsrc, const float* U,
+                              const float* bias, float* y, int fuse_relu, void* ws, size_t ws_bytes,
+                              const fcd_wino_fwd_extras* ex, void* stream);
 size_t fcd_conv_wino_keepv_bytes(const fcd_conv_desc* d);
 int fcd_conv2d_fwd_wino_keepv(const fcd_conv_desc* d, const float* x, const float* U, const float* bias, float* y,
                               int fuse_relu, float* pool_y, unsigned char* code, void* ws, size_t ws_bytes, float* v_keep,
@@ -221,6 +240,12 @@ int fcd_bn_act_fwd_from_stats(const float* x, float* y, int N, int C, int HW, in
                               float momentum, float eps, float* save_mean, float* save_invstd,
                               int act, const float* slope, float slope_imm, void* ws,
                               size_t ws_bytes, void* stream);
+/* train-mode BN + activation from the per-workgroup partial sums of the producing convolution (fcd_wino_fwd_extras.bn_part,
+ * split = fcd_conv_wino_bn_split): no statistics pass over x */
+int fcd_bn_act_fwd_parts(const float* x, float* y, int N, int C, int HW, int groups, const double* part, int split,
+                         const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
+                         float eps, float* save_mean, float* save_invstd, int act, const float* slope, float slope_imm,
+                         void* ws, size_t ws_bytes, void* stream);
 int fcd_bn_bwd_partial(const float* dz, const float* x, double* out, int N, int C, int HW,
                        int groups, const float* gamma, const float* beta, const float* save_mean,
                        const float* save_invstd, int act, const float* slope, float slope_imm,

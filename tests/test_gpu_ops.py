@@ -471,6 +471,41 @@ def test_wino_frozen_relu_bit_mask(case, monkeypatch):
     assert (dd.norm() / xr.grad.norm()).item() < 2e-4           # (outputs within rounding of 0 may gate the other way)
 
 
+@pytest.mark.parametrize('case', [(4, 64, 64, 64, 128, 2), (2, 128, 128, 128, 128, 1), (4, 128, 32, 64, 256, 2)],
+                         ids=lambda c: 'x'.join(map(str, c)))
+def test_bn_statistics_from_the_output_transform(case, monkeypatch):
+    """Conv2d -> BatchNorm2d(train) -> ReLU (reference Module.py:25-31): the BatchNorm's statistics summed by the F(4x4) output
+    transform (conv2d(bn_groups=...) + fcd_bn_act_fwd_parts) against the separate statistics pass over y -- outputs, saved
+    statistics through the backward pass (input / filter / affine gradients) and the running statistics, Siamese sample
+    groups included.  Both sum in fp64; they differ only in summation order."""
+    ops = _ops()
+    N, C, H, W, K, G = case
+    import ctypes
+    d = ops._desc((N, C, H, W), (K, C, 3, 3), 1, 1)
+    if not ops.lib.fcd_conv_wino_bn_split(ctypes.byref(d), G):
+        pytest.skip('statistics not available from this layer / grouping')
+    x = rnd(N, C, H, W, seed=91)
+    w = rnd(K, C, 3, 3, seed=92, scale=(2.0 / (C * 9)) ** 0.5)
+    b = rnd(K, seed=93, scale=0.1)
+    g = rnd(N, K, H, W, seed=94)
+    res = {}
+    for tag, env in (('fused', '1'), ('separate', '0')):
+        bn = torch.nn.BatchNorm2d(K).cuda().train()
+        with torch.no_grad():
+            bn.weight.copy_(rnd(K, seed=95).cuda() * 0.2 + 1.0)
+            bn.bias.copy_(rnd(K, seed=96).cuda() * 0.1)
+        xg, wg, bg = (t.cuda().requires_grad_(True) for t in (x, w, b))
+        y = ops.conv2d(xg, wg, bg, 1, 1, bn_groups=G if env == '1' else 0)
+        assert (getattr(y, '_fcd_bn', None) is not None) == (env == '1')
+        z = ops.bn_act(y, bn, ops.ACT_RELU, groups=G)
+        z.backward(g.cuda())
+        res[tag] = [t.detach().cpu().double() for t in (z, xg.grad, wg.grad, bn.weight.grad, bn.bias.grad, bn.running_mean, bn.running_var)]
+        assert int(bn.num_batches_tracked) == G
+    for a, r, what in zip(res['fused'], res['separate'], ('z', 'dx', 'dw', 'dgamma', 'dbeta', 'running_mean', 'running_var')):
+        err = (a - r).abs().max().item() / max(r.abs().max().item(), 1e-12)
+        assert err < 2e-6, (what, err)
+
+
 def _split_modes_conv(ops, x, w, b):
     """y of the 3x3 layer with the F(4x4) GEMMs on the fp32 matrix pipe (mode 0) and on the two split-bf16 kernels."""
     lib = ops.lib
