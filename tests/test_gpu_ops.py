@@ -616,6 +616,8 @@ def test_conv3x3_pair_cat_equals_conv_of_concatenation(case, relu):
     w = rnd(K, 2 * c + cu, 3, 3, seed=43, scale=(2.0 / ((2 * c + cu) * 9)) ** 0.5).cuda()
     b = rnd(K, seed=44, scale=0.1).cuda()
     g = rnd(n, K, H, W, seed=45).cuda()
+    if ops.lib.fcd_conv_wino_set(-1) == 0:
+        pytest.skip('direct kernels only (FCD_WINO=0): the tensor-list convolution is an F(4x4) path')
     assert ops.conv3x3_pair_cat_ok(f, u, w)
     f1, u1, w1, b1 = (t.clone().requires_grad_(True) for t in (f, u, w, b))
     y1 = ops.conv3x3_pair_cat(f1, u1, w1, b1, relu=relu)
