@@ -738,12 +738,14 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  // low half << 16 through v_perm_b32: written as a shift, LLVM narrows the packed conversion to its low element and emits
+  // a second v_cvt_pk_bf16_f32 for it (13 instead of 11 VALU per pair)
   const bf16x2 hp = {(__bf16)x0, (__bf16)x1};
   h = __builtin_bit_cast(unsigned, hp);
-  const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+  const float r0 = x0 - __uint_as_float(__builtin_amdgcn_perm(h, 0u, 0x05040c0cu)), r1 = x1 - __uint_as_float(h & 0xffff0000u);
   const bf16x2 mp = {(__bf16)r0, (__bf16)r1};
   m = __builtin_bit_cast(unsigned, mp);
-  const float q0 = r0 - __uint_as_float(m << 16), q1 = r1 - __uint_as_float(m & 0xffff0000u);
+  const float q0 = r0 - __uint_as_float(__builtin_amdgcn_perm(m, 0u, 0x05040c0cu)), q1 = r1 - __uint_as_float(m & 0xffff0000u);
   const bf16x2 lp = {(__bf16)q0, (__bf16)q1};
   l = __builtin_bit_cast(unsigned, lp);
 }
@@ -984,8 +986,8 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split_res_kernel(WinoGemmArg
   static_assert(PPW_A * NW * 64 == A_UNITS && PPW_B * NW * 64 == BN * UH * 2, "DMA split");
   constexpr int SWS = 3;
   __shared__ __attribute__((aligned(16))) unsigned short sa[QMAX * A_UNITS * 8];
-  __shared__ __attribute__((aligned(16))) float sb0[BN * KC];
-  __shared__ __attribute__((aligned(16))) float sb1[BN * KC];
+  __shared__ __attribute__((aligned(16))) float sb0[BN * KC];          // two arrays, not one ring: the waitcnt pass only lets a
+  __shared__ __attribute__((aligned(16))) float sb1[BN * KC];          // ds_read pass an LDS-DMA in flight to a DIFFERENT object
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int wm = wave / WN, wn = wave % WN;
@@ -1086,35 +1088,42 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split_res_kernel(WinoGemmArg
     __syncthreads();                                                                             \
   }
 
+  // Stage stream of the whole column range, two stages per trip (B buffers alternate; a tile's Q may be odd, so the tile end
+  // is tested after every stage).  An `if (parity) STEP(sb0, sb1) else STEP(sb1, sb0)` diamond inside the q loop made LLVM
+  // give the two copies different accumulator registers and move all 64 across every stage (7.5 VALU per MFMA, PMC).
+#define R_TAIL                                                                                   \
+  if (++q == Q) {                                                                                \
+    q = 0;                                                                                       \
+    /* C tile of column tile nt, in 32 x 32 MFMA-native blocks (this kernel only runs with c_blk) */ \
+    float* Cb = a.C + (size_t)xi * a.c_batch;                                                    \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                            \
+        const int mb = (wm * 64 + i * 32) >> 5, tb = (nt * BN + wn * 64 + j * 32) >> 5;          \
+        if (mb < a.c_mblk && tb < a.c_tblk) {                                                    \
+          float* blk = Cb + ((size_t)mb * a.c_tblk + tb) * 1024 + (half * 4 * 32 + l31) * 4;     \
+          _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                        \
+            const f32x4 cv_ = f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]}; \
+            if (FCD_NT_EXP & 8) __builtin_nontemporal_store(cv_, (f32x4*)(blk + g * 128)); else *(f32x4*)(blk + g * 128) = cv_; \
+          }                                                                                      \
+        }                                                                                        \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;                       \
+      }                                                                                          \
+    ++nt;                                                                                        \
+  }
   R_DMA(sb0)
   __syncthreads();
-  int par = 0;                          // parity of the B buffer holding the current stage
+  const int S = (nt_end - nt_beg) * Q;
+  int q = 0, nt = nt_beg;
 #pragma unroll 1
-  for (int nt = nt_beg; nt < nt_end; ++nt) {
-#pragma unroll 1
-    for (int q = 0; q < Q; ++q) {
-      const unsigned short* saq = sa + (size_t)q * (A_UNITS * 8);
-      if (par == 0) R_STEP(saq, sb0, sb1) else R_STEP(saq, sb1, sb0)
-      par ^= 1;
+  for (int st = 0; st < S; st += 2) {
+    R_STEP(sa + (size_t)q * (A_UNITS * 8), sb0, sb1)
+    R_TAIL
+    if (st + 1 < S) {
+      R_STEP(sa + (size_t)q * (A_UNITS * 8), sb1, sb0)
+      R_TAIL
     }
-    // C tile of column tile nt, in 32 x 32 MFMA-native blocks (this kernel only runs with c_blk)
-    float* Cb = a.C + (size_t)xi * a.c_batch;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int mb = (wm * 64 + i * 32) >> 5, tb = (nt * BN + wn * 64 + j * 32) >> 5;
-        if (mb < a.c_mblk && tb < a.c_tblk) {
-          float* blk = Cb + ((size_t)mb * a.c_tblk + tb) * 1024 + (half * 4 * 32 + l31) * 4;
-#pragma unroll
-          for (int g = 0; g < 4; ++g)
-            { const f32x4 cv_ = f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-              if (FCD_NT_EXP & 8) __builtin_nontemporal_store(cv_, (f32x4*)(blk + g * 128)); else *(f32x4*)(blk + g * 128) = cv_; }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-      }
   }
+#undef R_TAIL
 #undef R_STEP
 #undef R_SIX
 #undef R_MFMA

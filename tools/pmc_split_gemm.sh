@@ -18,7 +18,7 @@ d, split = sys.argv[1], sys.argv[2]
 ctr = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
-        m = re.search(r'(wino_gemm\w*kernel<[^>]*>)', r['Kernel_Name'])
+        m = re.search(r'(wino_gemm\w*kernel(?:<[^>]*>)?)', r['Kernel_Name'])
         if m:
             # one row per (kernel, grid): the three layers launch different grids
             k = '%s grid=%s' % (m.group(1), r.get('Grid_Size', r.get('Grid_Size_X', '?')))
