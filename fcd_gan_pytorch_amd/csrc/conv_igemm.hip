@@ -189,6 +189,20 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_kernel(ConvArgs a) {
     }                                                                                                 \
   }
 
+  // Sub-pixel data gradient of the stride-2 layers (fcd_conv2d_bwd_data_s2): output row block cls * shuf_C .. holds phase
+  // (pi, pj) = (cls >> 1, cls & 1) of dx, whose 2 x 2 pseudo-filter has a tap (u, v) only if (pi || !u) && (pj || !v) -- 9 real
+  // taps out of 16 over the four phases.  A wave skips the taps that are zero for every phase its 32 MI rows touch [r3].
+  constexpr bool TAP_SKIP = (R == 2 && S == 2 && STRIDE == 1 && DIL == 1);
+  unsigned tapmask = 0xFu;                   // bit u * 2 + v
+  if (TAP_SKIP && a.shuf_C) {
+    const int lo = ko0 + wm * (32 * MI), hi = min(lo + 32 * MI, a.K) - 1;
+    unsigned m = 0;
+    if (lo <= hi)
+      for (int cls = lo / a.shuf_C; cls <= hi / a.shuf_C; ++cls)
+        m |= 1u | ((cls & 1) ? 2u : 0u) | ((cls & 2) ? 4u : 0u) | ((cls & 3) == 3 ? 8u : 0u);
+    tapmask = (unsigned)__builtin_amdgcn_readfirstlane((int)m);
+  }
+
   const int nsteps = a.nchunks * NR;
   FCD_LOAD_X(0)
   FCD_LOAD_W(0, 0)
@@ -214,6 +228,7 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_kernel(ConvArgs a) {
       for (int rl = 0; rl < RCH; ++rl) {
 #pragma unroll
         for (int s = 0; s < S; ++s) {
+          if (TAP_SKIP && !((tapmask >> (rl * S + s)) & 1u)) continue;
           float av[MI], bv[NI];
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi) av[mi] = wl[((cc2 * 2) * (RCH * S) + rl * S + s) * BM + mi * 32];

@@ -42,6 +42,7 @@ CONV_CASES = [
     (2, 4, 32, 32, 64, 3, 2, 1),
     (3, 64, 24, 20, 128, 3, 2, 1),
     (2, 128, 19, 25, 256, 3, 2, 1),
+    (2, 40, 18, 22, 48, 3, 2, 1),       # sub-pixel data gradient: phase blocks of 40 rows straddle the waves' 64-row tiles
     (2, 4, 32, 32, 64, 9, 1, 4),
     (1, 13, 24, 40, 64, 9, 1, 4),
     (2, 64, 24, 40, 13, 9, 1, 4),
