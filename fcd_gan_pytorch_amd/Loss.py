@@ -172,8 +172,42 @@ class PerceptionLoss(nn.Module):
         for i in sorted(self.feature_layer_list):
             f = feats[i]
             # sum over bands of per-band MSE / C  ==  MSE over the band-batched tensor
-            total = total + F.mse_loss(f[:nb], f[nb:]) / nl
+            total = total + mse_halves(f, nb) / nl
         return total
+
+
+class _MseHalves(torch.autograd.Function):
+    """``F.mse_loss(f[:nb], f[nb:])`` of a band-batched feature tensor as ONE node.  Through autograd the two slices cost a
+    ``slice_backward`` each (a zero-filled full-size tensor plus a copy) and an add of the two: ten launches and five passes over
+    the 208-image tap per step; here the backward writes both halves of ``grad f`` directly (reference Loss.py:57-59 computes
+    the same mean over separate tensors)."""
+
+    @staticmethod
+    def forward(ctx, f, nb):
+        d = f[:nb] - f[nb:]
+        ctx.save_for_backward(d)
+        ctx.n_total = f.shape[0]
+        flat = d.reshape(-1)
+        return torch.dot(flat, flat) / flat.numel()
+
+    @staticmethod
+    def backward(ctx, gout):
+        d, = ctx.saved_tensors
+        nb = d.shape[0]
+        c = gout * (2.0 / d.numel())
+        g = torch.empty((ctx.n_total,) + tuple(d.shape[1:]), dtype=d.dtype, device=d.device)
+        torch.mul(d, c, out=g[:nb])
+        torch.mul(d, -c, out=g[nb:])
+        return g, None
+
+
+def mse_halves(f, nb):
+    """mean((f[:nb] - f[nb:]) ** 2); ``f`` holds exactly ``2 * nb`` rows."""
+    if f.shape[0] != 2 * nb:
+        raise ValueError('mse_halves: %d rows for two halves of %d' % (f.shape[0], nb))
+    if os.environ.get('FCD_FUSED_GLUE', '1') == '0' or not f.is_cuda:
+        return F.mse_loss(f[:nb], f[nb:])
+    return _MseHalves.apply(f, nb)
 
 
 def _per_sample_ratio(num, wsum, scale, skip_zero):

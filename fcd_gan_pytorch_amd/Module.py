@@ -157,6 +157,8 @@ class OutConv(nn.Module):
         self.Sigmoid = nn.Sigmoid()
 
     def forward(self, x):
+        if ops.conv1x1_head_supported(x, self.conv.weight):      # one output channel: streaming kernels, sigmoid fused
+            return ops.conv1x1_head(x, self.conv.weight, self.conv.bias, sigmoid=True)
         return torch.sigmoid(_conv(self.conv, x))
 
 
@@ -352,14 +354,21 @@ class Discriminator_SRGAN_simple(nn.Module):
         return z
 
     def classify(self, diff):
+        """Classifier on a feature difference (N, 512, h, w) -- or on its global average (N, 512, 1, 1)."""
         c = self.classifier
-        d = diff.mean(dim=(2, 3), keepdim=True)
+        d = diff if diff.shape[2:] == (1, 1) else diff.mean(dim=(2, 3), keepdim=True)
         d = ops.bn_act(_conv(c[1], d), None, ops.ACT_LEAKY, slope_imm=0.2)
         return torch.sigmoid(_conv(c[3], d).view(diff.shape[0]))
 
+    def _pooled(self, f):
+        """AdaptiveAvgPool2d(1) of the whole batched feature tensor BEFORE the per-pair difference: the pool is linear, so
+        pool(f_x - f_y) = pool(f_x) - pool(f_y), and the slices / differences (and their backward: a zero-filled full-size
+        gradient, a copy and an add per slice) then act on (N, 512, 1, 1) instead of (N, 512, 16, 16)."""
+        return f.mean(dim=(2, 3), keepdim=True)
+
     def forward(self, x, y):
         n = x.shape[0]
-        f = self.features(torch.cat([x, y], dim=0), groups=2)
+        f = self._pooled(self.features(torch.cat([x, y], dim=0), groups=2))
         return self.classify(f[:n] - f[n:])
 
     def forward_pairs(self, pairs):
@@ -367,6 +376,6 @@ class Discriminator_SRGAN_simple(nn.Module):
         ``forward`` on each pair in order (BN running stats see x1,y1,x2,y2,...)."""
         n = pairs[0][0].shape[0]
         z = torch.cat([t for p in pairs for t in p], dim=0)
-        f = self.features(z, groups=2 * len(pairs))
+        f = self._pooled(self.features(z, groups=2 * len(pairs)))
         return [self.classify(f[(2 * i) * n:(2 * i + 1) * n] - f[(2 * i + 1) * n:(2 * i + 2) * n])
                 for i in range(len(pairs))]

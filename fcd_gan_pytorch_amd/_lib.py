@@ -75,6 +75,10 @@ _SIGS = {
     'fcd_conv2d_relu_bits_bytes': (c_size_t, [POINTER(ConvDesc)]),
     'fcd_conv2d_fwd_relu_bits': (c_int, [POINTER(ConvDesc), P, P, P, P, P, P]),
     'fcd_conv2d_bwd_data_bits': (c_int, [POINTER(ConvDesc), P, P, P, P, P]),
+    'fcd_conv1x1_head_plan': (c_int, [c_int, c_int, c_int, c_int]),
+    'fcd_conv1x1_head_fwd': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    'fcd_conv1x1_head_bwd_ws_bytes': (c_size_t, [c_int, c_int]),
+    'fcd_conv1x1_head_bwd': (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, P, c_size_t, P]),
     'fcd_conv_wino_plan': (c_int, [POINTER(ConvDesc), c_int]),
     'fcd_conv_wino_set': (c_int, [c_int]),
     'fcd_conv_wino_split_set': (c_int, [c_int]),

@@ -621,6 +621,64 @@ def bn_act(x, bn=None, act=ACT_NONE, slope=None, slope_imm=0.0, groups=1):
                         bn.momentum if bn.momentum is not None else 0.1, bn.eps, groups, act, slope_imm)
 
 
+# ------------------------------------------------ 1x1 head (one output channel + sigmoid)
+class _Conv1x1Head(torch.autograd.Function):
+    """``act(conv1x1(x; w, b))`` with ONE output channel (reference Module.py:82-90 ``OutConv``) on the streaming kernels of
+    csrc/conv_head.hip; the sigmoid and its derivative live in the kernels' epilogue / prologue."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, sigmoid):
+        x = _dev(x, 'head input')
+        N, C, H, W = x.shape
+        w = weight.detach().reshape(-1).contiguous()
+        y = torch.empty((N, 1, H, W), dtype=torch.float32, device=x.device)
+        check(lib.fcd_conv1x1_head_fwd(_p(x), _p(w), _p(bias) if bias is not None else None, _p(y), N, C, H * W,
+                                       1 if sigmoid else 0, _stream()), 'fcd_conv1x1_head_fwd')
+        ctx.sigmoid = bool(sigmoid)
+        ctx.has_bias = bias is not None
+        ctx.wshape = tuple(weight.shape)
+        need_x = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        ctx.save_for_backward(x if need_x else None, w, y if sigmoid else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        dy = _dev(dy, 'head grad')
+        N, _, H, W = dy.shape
+        C = w.numel()
+        want_dx = ctx.needs_input_grad[0]
+        want_dw = ctx.needs_input_grad[1]
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        dx = torch.empty((N, C, H, W), dtype=torch.float32, device=dy.device) if want_dx else None
+        dw = torch.empty(C, dtype=torch.float32, device=dy.device) if want_dw else None
+        db = torch.empty(1, dtype=torch.float32, device=dy.device) if want_db else None
+        ws = None
+        nbytes = 0
+        if want_dw or want_db:
+            nbytes = int(lib.fcd_conv1x1_head_bwd_ws_bytes(N, C))
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dy.device)
+        if want_dx or want_dw or want_db:
+            check(lib.fcd_conv1x1_head_bwd(_p(x) if x is not None else None, _p(w), _p(dy), _p(y) if y is not None else None,
+                                           _p(dx) if dx is not None else None, _p(dw) if dw is not None else None,
+                                           _p(db) if db is not None else None, N, C, H * W,
+                                           _p(ws) if ws is not None else None, nbytes, _stream()), 'fcd_conv1x1_head_bwd')
+        return dx, (dw.view(ctx.wshape) if dw is not None else None), db, None
+
+
+def conv1x1_head_supported(x, weight):
+    """True when ``conv1x1_head`` can take this layer (a 1x1 filter with one output channel on a wide map)."""
+    if not (x.is_cuda and x.dim() == 4 and weight.dim() == 4 and weight.shape[0] == 1 and weight.shape[2:] == (1, 1)):
+        return False
+    N, C, H, W = x.shape
+    return bool(lib.fcd_conv1x1_head_plan(N, C, H * W, 1))
+
+
+def conv1x1_head(x, weight, bias, sigmoid=True):
+    """sigmoid(conv2d(x, weight, bias)) (``sigmoid=False``: the bare 1x1 convolution) for a (1, C, 1, 1) filter."""
+    return _Conv1x1Head.apply(x, weight, bias, sigmoid)
+
+
 # -------------------------------------------------------------- pooling / resize
 class _MaxPool2(torch.autograd.Function):
     @staticmethod

@@ -1,0 +1,158 @@
+// 1x1 convolution to ONE output channel with the sigmoid in its epilogue: the Segmentor's change-density head
+// (reference Module.py:82-90 `OutConv`: Conv2d(128, 1, 1) + Sigmoid on 256 x 256 maps).  As a GEMM this layer has one
+// row: on the implicit-GEMM MFMA tiles it used 1 of 32 rows and ran at 1.1 (weight gradient) .. 3.3 TB/s (forward) of
+// its only real cost, ONE pass over the (N, C, HW) activation.  Three streaming kernels instead [r3]:
+//   forward   y[n, p]     = sigmoid(b + sum_c w[c] x[n, c, p])            reads x once, 4 pixels per thread
+//   data grad dx[n, c, p] = w[c] g[n, p],  g = dy * y (1 - y)             writes dx once
+//   weight    dw[c]       = sum_{n, p} g[n, p] x[n, c, p],  db = sum g    one block per (c, n) plane -> fp64 partial,
+//                                                                          summed over n in a fixed order (deterministic)
+#include "common.h"
+#include <stdlib.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + __expf(-v)); }
+
+// grid (HW / 4 / 256 rounded up, N)
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ y, int C, int HW4,
+                                                        int sigmoid) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= HW4) return;
+  const int n = blockIdx.y;
+  const f32x4* xp = (const f32x4*)(x + (size_t)n * C * HW4 * 4) + i;
+  const float b = bias ? bias[0] : 0.f;
+  f32x4 acc = {b, b, b, b};
+  int c = 0;
+  for (; c + 8 <= C; c += 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(xp + (size_t)(c + u) * HW4);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += v[u] * w[c + u];
+  }
+  for (; c < C; ++c) acc += __builtin_nontemporal_load(xp + (size_t)c * HW4) * w[c];
+  if (sigmoid) acc = f32x4{sigmoidf_(acc[0]), sigmoidf_(acc[1]), sigmoidf_(acc[2]), sigmoidf_(acc[3])};
+  ((f32x4*)(y + (size_t)n * HW4 * 4))[i] = acc;
+}
+
+__device__ __forceinline__ f32x4 head_grad(const float* __restrict__ dy, const float* __restrict__ ys, size_t off4) {
+  f32x4 g = ((const f32x4*)dy)[off4];
+  if (ys) {
+    const f32x4 s = ((const f32x4*)ys)[off4];
+    g = g * s * (1.f - s);
+  }
+  return g;
+}
+
+// grid (HW / 4 / 256 rounded up, N)
+__global__ __launch_bounds__(256) void head_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ ys,
+                                                          const float* __restrict__ w, float* __restrict__ dx, int C, int HW4) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= HW4) return;
+  const int n = blockIdx.y;
+  const f32x4 g = head_grad(dy, ys, (size_t)n * HW4 + i);
+  f32x4* dp = (f32x4*)(dx + (size_t)n * C * HW4 * 4) + i;
+  for (int c = 0; c < C; ++c) dp[(size_t)c * HW4] = g * w[c];
+}
+
+// grid (C + 1, N): block (c, n) -> part[c * N + n] = sum_p g[n, p] x[n, c, p]; row c == C: sum_p g[n, p]
+__global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          const float* __restrict__ ys, double* __restrict__ part, int C,
+                                                          int HW4) {
+  const int c = blockIdx.x, n = blockIdx.y, N = gridDim.y;
+  const f32x4* xp = (c < C) ? (const f32x4*)(x + ((size_t)n * C + c) * HW4 * 4) : nullptr;
+  double s = 0.0;
+  for (int i0 = threadIdx.x; i0 < HW4; i0 += 256 * 8) {      // fp32 over <= 32 products, then fp64
+    float a = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * 256;
+      if (i < HW4) {
+        const f32x4 g = head_grad(dy, ys, (size_t)n * HW4 + i);
+        if (xp) {
+          const f32x4 v = __builtin_nontemporal_load(xp + i);
+          a += g[0] * v[0] + g[1] * v[1] + g[2] * v[2] + g[3] * v[3];
+        } else {
+          a += g[0] + g[1] + g[2] + g[3];
+        }
+      }
+    }
+    s += (double)a;
+  }
+  __shared__ double red[256];
+  red[threadIdx.x] = s;
+  __syncthreads();
+#pragma unroll
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[(size_t)c * N + n] = red[0];
+}
+
+__global__ void head_wgrad_final_kernel(const double* __restrict__ part, float* __restrict__ dw, float* __restrict__ db, int C,
+                                        int N) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > C) return;
+  double s = 0.0;
+  for (int n = 0; n < N; ++n) s += part[(size_t)c * N + n];
+  if (c < C) { if (dw) dw[c] = (float)s; }
+  else if (db) db[0] = (float)s;
+}
+
+}  // namespace
+
+extern "C" int fcd_conv1x1_head_plan(int N, int C, int HW, int K) {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("FCD_CONV_HEAD");
+    on = (e && e[0] == '0') ? 0 : 1;
+  }
+  return (on && K == 1 && N > 0 && N <= 65535 && C >= 8 && C <= 65534 && HW >= 1024 && (HW & 3) == 0) ? 1 : 0;
+}
+
+extern "C" int fcd_conv1x1_head_fwd(const float* x, const float* w, const float* bias, float* y, int N, int C, int HW, int sigmoid,
+                                    void* stream) {
+  FCD_CHECK_ARG(x && w && y, "fcd_conv1x1_head_fwd: null pointer");
+  FCD_CHECK_ARG(fcd_conv1x1_head_plan(N, C, HW, 1), "fcd_conv1x1_head_fwd: unsupported shape N=%d C=%d HW=%d", N, C, HW);
+  const int HW4 = HW >> 2;
+  FcdProfScope prof(FCD_K_CONV_FWD, (hipStream_t)stream, 2.0 * N * C * (double)HW, 4.0 * N * (C + 1.0) * HW,
+                    fcd_prof_tagf("head_fwd N=%d C=%d HW=%d", N, C, HW));
+  hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)cdiv(HW4, 256), (unsigned)N), dim3(256), 0, (hipStream_t)stream, x, w, bias, y,
+                     C, HW4, sigmoid);
+  FCD_LAUNCH_CHECK("conv1x1_head_fwd");
+  return FCD_OK;
+}
+
+extern "C" size_t fcd_conv1x1_head_bwd_ws_bytes(int N, int C) { return (size_t)(C + 1) * (size_t)N * sizeof(double); }
+
+// g = dy * y_sig (1 - y_sig) when y_sig != NULL (the forward's sigmoid output), else g = dy.  Any of dx / (dw, db) may be NULL.
+extern "C" int fcd_conv1x1_head_bwd(const float* x, const float* w, const float* dy, const float* y_sig, float* dx, float* dw,
+                                    float* db, int N, int C, int HW, void* ws, size_t ws_bytes, void* stream) {
+  FCD_CHECK_ARG(dy && (dx || dw || db), "fcd_conv1x1_head_bwd: null pointer");
+  FCD_CHECK_ARG(fcd_conv1x1_head_plan(N, C, HW, 1), "fcd_conv1x1_head_bwd: unsupported shape N=%d C=%d HW=%d", N, C, HW);
+  hipStream_t st = (hipStream_t)stream;
+  const int HW4 = HW >> 2;
+  if (dx) {
+    FCD_CHECK_ARG(w, "fcd_conv1x1_head_bwd: dx needs the filter");
+    FcdProfScope prof(FCD_K_CONV_DGRAD, st, 2.0 * N * C * (double)HW, 4.0 * N * (C + 1.0) * HW,
+                      fcd_prof_tagf("head_dgrad N=%d C=%d HW=%d", N, C, HW));
+    hipLaunchKernelGGL(head_dgrad_kernel, dim3((unsigned)cdiv(HW4, 256), (unsigned)N), dim3(256), 0, st, dy, y_sig, w, dx, C, HW4);
+  }
+  if (dw || db) {
+    FCD_CHECK_ARG(x, "fcd_conv1x1_head_bwd: dw needs the input");
+    if (!ws || ws_bytes < fcd_conv1x1_head_bwd_ws_bytes(N, C)) {
+      fcd_set_error("fcd_conv1x1_head_bwd: workspace too small");
+      return FCD_ERR_WORKSPACE;
+    }
+    FcdProfScope prof(FCD_K_CONV_WGRAD, st, 2.0 * N * C * (double)HW, 4.0 * N * (C + 1.0) * HW,
+                      fcd_prof_tagf("head_wgrad N=%d C=%d HW=%d", N, C, HW));
+    hipLaunchKernelGGL(head_wgrad_kernel, dim3((unsigned)(C + 1), (unsigned)N), dim3(256), 0, st, x, dy, y_sig, (double*)ws, C, HW4);
+    hipLaunchKernelGGL(head_wgrad_final_kernel, dim3((unsigned)cdiv(C + 1, 128)), dim3(128), 0, st, (const double*)ws, dw, db, C, N);
+  }
+  FCD_LAUNCH_CHECK("conv1x1_head_bwd");
+  return FCD_OK;
+}

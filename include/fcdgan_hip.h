@@ -80,6 +80,20 @@ int fcd_conv2d_fwd_relu_bits(const fcd_conv_desc* d, const float* x, const float
                              float* y, unsigned char* bits, void* stream);
 int fcd_conv2d_bwd_data_bits(const fcd_conv_desc* d, const float* dy, const unsigned char* bits,
                              const float* wp_bwd, float* dx, void* stream);
+/* 1x1 convolution to ONE output channel (+ sigmoid): the Segmentor's change-density head, reference Module.py:82-90
+ * (`OutConv`: nn.Conv2d(in, 1, kernel_size=1) followed by nn.Sigmoid), as streaming kernels -- one pass over the
+ * (N, C, HW) activation per direction instead of a 1-row MFMA GEMM.  fcd_conv1x1_head_plan(): 1 when the shape is
+ * supported (K == 1, HW % 4 == 0, HW >= 1024, C >= 8; FCD_CONV_HEAD=0 turns the path off).
+ * forward:  y[n, p] = act(bias + sum_c w[c] x[n, c, p]),  act = sigmoid when `sigmoid` != 0.
+ * backward: g = dy * y_sig * (1 - y_sig) with y_sig = the forward's sigmoid output (NULL: g = dy);
+ *           dx[n, c, p] = w[c] g[n, p];  dw[c] = sum_{n,p} g x;  db = sum g.  dx or (dw, db) may be NULL.
+ *           ws: fcd_conv1x1_head_bwd_ws_bytes(N, C) bytes (fp64 partial sums, reduced in a fixed order). */
+int fcd_conv1x1_head_plan(int N, int C, int HW, int K);
+int fcd_conv1x1_head_fwd(const float* x, const float* w, const float* bias, float* y, int N, int C, int HW,
+                         int sigmoid, void* stream);
+size_t fcd_conv1x1_head_bwd_ws_bytes(int N, int C);
+int fcd_conv1x1_head_bwd(const float* x, const float* w, const float* dy, const float* y_sig, float* dx, float* dw,
+                         float* db, int N, int C, int HW, void* ws, size_t ws_bytes, void* stream);
 /* ---- Winograd F(m x m, 3 x 3) path for wide 3x3 / stride-1 / pad-1 layers (m = 2 or 4) ------------
  * fcd_conv_wino_plan(): tile size the library uses for this layer and direction (mode 0 forward,
  * 1 data gradient), 0 = the layer runs on the direct kernels (then none of the *_wino calls apply).

@@ -244,6 +244,34 @@ def test_bare_activation(act):
         assert_close(sg.grad, sr.grad, tol=5e-5, what='dslope')
 
 
+@pytest.mark.parametrize('case', [(2, 128, 64, 64, True), (3, 21, 32, 36, True), (1, 8, 32, 32, False), (2, 130, 48, 40, True)],
+                         ids=lambda c: 'x'.join(map(str, c)))
+def test_conv1x1_head(case):
+    """One-output-channel 1x1 convolution + sigmoid (csrc/conv_head.hip; reference Module.py:82-90 OutConv) vs the ATen
+    composition in fp64: forward, dx, dw, db; channel counts off the unroll of 8, with and without the sigmoid, and the
+    frozen-filter case (dx only)."""
+    ops = _ops()
+    N, C, H, W, sig = case
+    x, w, b, g = rnd(N, C, H, W, seed=71), rnd(1, C, 1, 1, seed=72, scale=C ** -0.5), rnd(1, seed=73), rnd(N, 1, H, W, seed=74)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    yr = F.conv2d(xr, wr, br)
+    yr = torch.sigmoid(yr) if sig else yr
+    yr.backward(g.double())
+    xg, wg, bg = (t.cuda().requires_grad_(True) for t in (x, w, b))
+    assert ops.conv1x1_head_supported(xg, wg)
+    y = ops.conv1x1_head(xg, wg, bg, sigmoid=sig)
+    y.backward(g.cuda())
+    assert_close(y, yr, what='y')
+    assert_close(xg.grad, xr.grad, what='dx')
+    assert_close(wg.grad, wr.grad, what='dw')
+    assert_close(bg.grad, br.grad, what='db')
+    xf = x.cuda().requires_grad_(True)                     # frozen filter: no weight-gradient pass, x is not kept
+    ops.conv1x1_head(xf, w.cuda(), b.cuda(), sigmoid=sig).backward(g.cuda())
+    assert_close(xf.grad, xr.grad, what='dx (frozen filter)')
+    assert not ops.conv1x1_head_supported(rnd(2, 16, 1, 1).cuda(), rnd(1, 16, 1, 1).cuda())       # 1 x 1 maps: small-FC kernel
+    assert not ops.conv1x1_head_supported(xg, rnd(2, C, 1, 1).cuda())                              # two output channels
+
+
 @pytest.mark.parametrize('shape', [(2, 3, 8, 8), (1, 5, 11, 13), (2, 4, 27, 55), (1, 2, 2, 2), (1, 2, 3, 3)])
 def test_maxpool_upsample_avgpool(shape):
     ops = _ops()
