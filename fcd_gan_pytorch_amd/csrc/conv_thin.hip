@@ -10,6 +10,7 @@
 // input window in registers across the three taps of a row; filter taps are wave-uniform
 // scalar loads.
 #include "common.h"
+#include <stdlib.h>
 
 #define TH_ROWS 16
 #define TH_COLS 64
@@ -306,6 +307,97 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_thin_kernel(const float* __re
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// [r3] ONE input channel, 64 filters (VGG conv1_1 on single bands: 208 images of 256 x 256 per step), matrix-core form.
+// The VALU kernel above spends 576 FMAs per pixel and ran at 3.2 TB/s of the gradient it reads.  Here the channel
+// reduction of every tap is an MFMA and only the 3 x 3 shift-and-add stays on the VALU:
+//   res_t[y][x] = sum_k wf[k][t] dy'[k][y][x]          v_mfma_f32_16x16x4_f32: rows = 9 taps (of 16), 4 channels per step
+//   dx[h][w]    = sum_{r,s} res_{3r+s}[h + r - 1][w + s - 1]
+// A wave owns a 64-pixel row segment: lane (l15, kq) loads float4 dy[4 i + kq][y][4 l15 ..] (+ the strip's mask byte) for
+// i = 0 .. 15 -- 256 contiguous bytes per channel row -- and runs 16 x 4 MFMAs (B operand = element j of the float4: MFMA j
+// covers pixels 4 l + j), after which lane (l15, kq) holds taps 4 kq .. 4 kq + 3 of its four pixels.  The workgroup (one wave
+// per 64 columns, the whole image width) walks TH + 2 gradient rows; the tap planes of the last rows sit in a 4-slot LDS
+// ring (one barrier per row), from which thread x sums the nine shifted values of output pixel (y - 1, x).
+template <bool BITS>
+__global__ __launch_bounds__(256, 2) void conv3x3_dgrad_c1_mfma_kernel(const float* __restrict__ dy,
+                                                                       const unsigned char* __restrict__ bits,
+                                                                       const float* __restrict__ wf, float* __restrict__ dx,
+                                                                       int H, int W, int Cpad, int TH, int blocks_h) {
+  constexpr int K = 64, KQ = K / 4, PITCH = 256 + 8;
+  __shared__ __attribute__((aligned(16))) float res[4][9][PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, seg = tid >> 6;
+  const int l15 = lane & 15, kq = lane >> 4;
+  const int n = blockIdx.x / blocks_h, h0 = (blockIdx.x % blocks_h) * TH, h1 = min(h0 + TH, H);
+  float a[KQ];
+#pragma unroll
+  for (int i = 0; i < KQ; ++i) {
+    const float wv_ = wf[(size_t)((4 * i + kq) * 9 + min(l15, 8)) * Cpad];
+    a[i] = l15 < 9 ? wv_ : 0.f;
+  }
+  for (int i = tid; i < 4 * 9 * 8; i += blockDim.x) {          // the zero columns left and right of the image
+    const int e = i & 7;
+    res[i / 72][(i >> 3) % 9][e < 4 ? e : W + e] = 0.f;
+  }
+  const size_t plane = (size_t)H * W;
+  const float* src = dy + ((size_t)n * K + kq) * plane + seg * 64 + 4 * l15;
+  // the gradient row after the current one is in flight (registers) while the current one is multiplied
+  f32x4_t dv[KQ], dn[KQ];
+  unsigned mb[KQ], mn[KQ];
+#define C1_LOAD(Y, DV, MB)          /* rows outside the image: any valid row, the products are zeroed below */ \
+  {                                                                                             \
+    const int yc_ = min(max((Y), 0), H - 1);                                                    \
+    _Pragma("unroll") for (int i = 0; i < KQ; ++i) {                                            \
+      const size_t off = (size_t)(4 * i) * plane + (size_t)yc_ * W;                             \
+      DV[i] = __builtin_nontemporal_load((const f32x4_t*)(src + off));                          \
+      MB[i] = BITS ? bits[(size_t)((src - dy) + off) >> 2] : 0xFu;                              \
+    }                                                                                           \
+  }
+#define C1_ROW(Y, DV, MB, DN, MN)                                                               \
+  {                                                                                             \
+    const int yy_ = (Y);                                                                          \
+    C1_LOAD(yy_ + 1, DN, MN)                                                                      \
+    f32x4_t acc[4];                                                                             \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};         \
+    const unsigned rowm_ = (yy_ >= 0 && yy_ < H) ? 0xFu : 0u;                                       \
+    _Pragma("unroll") for (int i = 0; i < KQ; ++i)                                              \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                           \
+        const float b = ((MB[i] & rowm_) >> j) & 1u ? DV[i][j] : 0.f;                           \
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b, acc[j], 0, 0, 0);                \
+      }                                                                                         \
+    const int slot = (yy_ + 1) & 3;                                                               \
+    _Pragma("unroll") for (int r = 0; r < 4; ++r)                                               \
+      if (4 * kq + r < 9)                                                                       \
+        *(f32x4_t*)&res[slot][4 * kq + r][4 + seg * 64 + 4 * l15] = f32x4_t{acc[0][r], acc[1][r], acc[2][r], acc[3][r]}; \
+    __syncthreads();                                                                            \
+    const int h = yy_ - 1;                                                                        \
+    if (h >= h0 && h < h1) {                                                                    \
+      float sum = 0.f;                                                                          \
+      _Pragma("unroll") for (int r = 0; r < 3; ++r)                                             \
+        _Pragma("unroll") for (int s2 = 0; s2 < 3; ++s2) sum += res[(h + r) & 3][r * 3 + s2][4 + tid + s2 - 1]; \
+      dx[((size_t)n * H + h) * W + tid] = sum;                                                  \
+    }                                                                                           \
+  }
+  C1_LOAD(h0 - 1, dv, mb)
+  for (int y = h0 - 1; y <= h1; y += 2) {
+    C1_ROW(y, dv, mb, dn, mn)
+    if (y + 1 <= h1) C1_ROW(y + 1, dn, mn, dv, mb)
+  }
+#undef C1_ROW
+#undef C1_LOAD
+}
+
+// FCD_THIN_MFMA=0: VALU kernel; =<n>: output rows per workgroup.  conv1_1 data gradient of the headline step (N = 208, bit
+// mask): VALU 1.14 ms; MFMA 8 rows 0.84, 16 rows 0.76, 32 rows 0.74 (4.7 TB/s of the gradient it reads)
+static int thin_mfma_rows() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("FCD_THIN_MFMA");
+    v = e ? atoi(e) : 32;
+    if (v < 0) v = 0;
+  }
+  return v;
+}
+
 // returns 0 when handled, 1 when the shape is not a thin-channel case
 int fcd_try_dgrad_thin(const fcd_conv_desc* d, const float* dy, const float* relu_out, const float* wp_bwd, float* dx,
                        hipStream_t st, int mask_is_bits) {
@@ -315,6 +407,18 @@ int fcd_try_dgrad_thin(const fcd_conv_desc* d, const float* dy, const float* rel
   dim3 grid((unsigned)(tiles_w * tiles_h), (unsigned)d->N);
 #define THIN_LAUNCH(KERNEL, CS_)                                                                              \
   hipLaunchKernelGGL(KERNEL<CS_>, grid, dim3(256), 0, st, dy, relu_out, wp_bwd, dx, d->K, d->H, d->W, Cpad, tiles_w)
+  if (d->C == 1 && d->K == 64 && (d->W & 63) == 0 && d->W <= 256 && thin_mfma_rows() > 0 && (mask_is_bits || !relu_out) &&
+      (long long)d->N * cdiv(d->H, thin_mfma_rows()) < (1LL << 31)) {
+    const int TH = thin_mfma_rows(), blocks_h = cdiv(d->H, TH);
+    const dim3 g((unsigned)(d->N * blocks_h));
+    if (mask_is_bits)
+      hipLaunchKernelGGL(conv3x3_dgrad_c1_mfma_kernel<true>, g, dim3(d->W), 0, st, dy, (const unsigned char*)relu_out, wp_bwd, dx,
+                         d->H, d->W, Cpad, TH, blocks_h);
+    else
+      hipLaunchKernelGGL(conv3x3_dgrad_c1_mfma_kernel<false>, g, dim3(d->W), 0, st, dy, (const unsigned char*)nullptr, wp_bwd, dx,
+                         d->H, d->W, Cpad, TH, blocks_h);
+    return 0;
+  }
   if ((d->W & 3) == 0 && (d->K % TH_KC) == 0) {     // float4 rows, whole 8-channel chunks
 #define THIN_V4(CS_, B_) \
   hipLaunchKernelGGL((conv3x3_dgrad_thin_v4_kernel<CS_, B_>), grid, dim3(256), 0, st, dy, relu_out, wp_bwd, dx, d->K, d->H, d->W, Cpad, tiles_w)

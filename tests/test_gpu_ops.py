@@ -57,6 +57,8 @@ CONV_CASES = [
     # thin (<= 4 input channels) VALU kernels: forward (K > 32) and data gradient, float4 rows
     # (W % 4 == 0, K % 8 == 0) and the generic variants, tile edges in both directions
     (2, 1, 40, 72, 64, 3, 1, 1),
+    (2, 1, 35, 128, 64, 3, 1, 1),      # one band, 64 filters, W % 64 == 0: matrix-core data gradient (no mask)
+    (1, 1, 9, 256, 64, 3, 1, 1),
     (1, 1, 19, 21, 64, 3, 1, 1),
     (2, 2, 17, 132, 72, 3, 1, 1),
     (1, 4, 33, 68, 40, 3, 1, 1),
@@ -683,7 +685,8 @@ def test_conv_winograd_matches_direct_kernels():
     assert (outs[4] - outs[0]).abs().max().item() <= 6e-5 * sc
 
 
-@pytest.mark.parametrize('case', [(2, 1, 36, 68, 64), (1, 3, 17, 132, 72), (3, 4, 16, 64, 40), (2, 1, 21, 30, 64)],
+@pytest.mark.parametrize('case', [(2, 1, 36, 68, 64), (1, 3, 17, 132, 72), (3, 4, 16, 64, 40), (2, 1, 21, 30, 64),
+                                  (2, 1, 37, 64, 64), (1, 1, 16, 128, 64), (2, 1, 50, 256, 64)],      # one band, 64 filters, W % 64 == 0: MFMA data gradient
                          ids=lambda c: 'x'.join(map(str, c)))
 def test_thin_conv_relu_bitmask_path(case):
     """Frozen thin-channel layer (VGG conv1_1 on single bands): conv + bias + ReLU whose backward mask is kept as
