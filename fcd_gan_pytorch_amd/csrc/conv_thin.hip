@@ -11,6 +11,7 @@
 // scalar loads.
 #include "common.h"
 #include <stdlib.h>
+#include <algorithm>
 
 #define TH_ROWS 16
 #define TH_COLS 64
@@ -387,7 +388,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dgrad_c1_mfma_kernel(const flo
 }
 
 // FCD_THIN_MFMA=0: VALU kernel; =<n>: output rows per workgroup.  conv1_1 data gradient of the headline step (N = 208, bit
-// mask): VALU 1.14 ms; MFMA 8 rows 0.84, 16 rows 0.76, 32 rows 0.74 (4.7 TB/s of the gradient it reads)
+// mask): VALU 1.14 ms; MFMA 8 rows 0.84, 16 rows 0.76, 32 rows 0.74 (4.7 TB/s of the gradient it reads).  The same idea for
+// the FORWARD of this layer (taps as the MFMA's k dimension, 48 MFMAs per 64-pixel row segment) lost: 1.03 vs 0.85 ms --
+// that kernel is bound by its 64 scattered output planes, not by the 576 FMAs per pixel
 static int thin_mfma_rows() {
   static int v = -1;
   if (v < 0) {
