@@ -252,6 +252,9 @@ def test_conv1x1_head(case):
     """One-output-channel 1x1 convolution + sigmoid (csrc/conv_head.hip; reference Module.py:82-90 OutConv) vs the ATen
     composition in fp64: forward, dx, dw, db; channel counts off the unroll of 8, with and without the sigmoid, and the
     frozen-filter case (dx only)."""
+    import os
+    if os.environ.get('FCD_CONV_HEAD') == '0':
+        pytest.skip('head kernels switched off')
     ops = _ops()
     N, C, H, W, sig = case
     x, w, b, g = rnd(N, C, H, W, seed=71), rnd(1, C, 1, 1, seed=72, scale=C ** -0.5), rnd(1, seed=73), rnd(N, 1, H, W, seed=74)
