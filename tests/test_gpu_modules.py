@@ -248,6 +248,24 @@ def test_criteria_vs_reference_fixture(tag, conv_path):
     grad_close(cg.grad, cr.grad, 'd/dcmap', l2_tol=l2, bad_frac=3e-2)
 
 
+def test_mse_halves_is_mse_loss_of_the_two_halves():
+    """Loss.mse_halves (one autograd node writing both halves of the tap gradient) vs F.mse_loss on the slices in fp64
+    (reference Loss.py:57-59: MSE between the target's and the generated image's features)."""
+    L = pkg().Loss
+    torch.manual_seed(5)
+    f = torch.randn(6, 7, 9, 11)
+    fr = f.double().requires_grad_(True)
+    ref = torch.nn.functional.mse_loss(fr[:3], fr[3:])
+    (ref * 1.7).backward()
+    fg = f.to(DEV).requires_grad_(True)
+    got = L.mse_halves(fg * 1.0, 3)              # a non-leaf input, as in the criterion
+    (got * 1.7).backward()
+    np.testing.assert_allclose(got.item(), ref.item(), rtol=2e-6)
+    np.testing.assert_allclose(fg.grad.cpu().double().numpy(), fr.grad.numpy(), rtol=1e-5, atol=1e-9)
+    with pytest.raises(ValueError):
+        L.mse_halves(fg, 2)
+
+
 def test_region_loss_vs_reference_fixture():
     z = np.load(os.path.join(G, 'losses.npz'))
     L = pkg().Loss
