@@ -34,11 +34,13 @@ def main():
     s = ops._stream()
     for tag, N, C, HW, K in (SHAPES[:1] if os.environ.get('W2_ONLY') else SHAPES):
         x = torch.randn(N, C, HW, HW, device='cuda').relu_()
+        if os.environ.get('W2_ZERO'):      # all-zero activations: how much of the kernel time is the chip's power management?
+            x.zero_()
         w = torch.randn(K, C, 3, 3, device='cuda') * 0.05
         b = torch.zeros(K, device='cuda')
         d = ops._desc(x.shape, w.shape, 1, 1)
         y = torch.empty(N, K, HW, HW, device='cuda')
-        dy = torch.randn_like(y)
+        dy = torch.zeros_like(y) if os.environ.get('W2_ZERO') else torch.randn_like(y)
         dx = torch.empty_like(x)
         fl = 2.0 * N * K * HW * HW * C * 9
         line = '%-40s' % tag
@@ -49,7 +51,7 @@ def main():
                                                                None, None, None, s)))
             y2 = y.clone()
             t1 = timeit(lambda: check(lib.fcd_conv2d_fwd(ctypes.byref(d), ops._p(x), ops._p(wp), ops._p(b), ops._p(y), 1, s)))
-            err = (y2 - y).abs().max().item() / y.abs().max().item()
+            err = (y2 - y).abs().max().item() / max(y.abs().max().item(), 1e-30)
             line += ' fwd: fused %.3f ms (%.0f TF alg) direct %.3f ms (%.0f TF)  rel diff %.1e |' % (t2, fl / t2 / 1e9, t1, fl / t1 / 1e9, err)
         if lib.fcd_conv_wino2_plan(ctypes.byref(d), 1):
             U = ops.wino2_weight(w, 1)
@@ -57,7 +59,7 @@ def main():
             t2 = timeit(lambda: check(lib.fcd_conv2d_bwd_data_wino2(ctypes.byref(d), ops._p(dy), ops._p(y), None, ops._p(U), ops._p(dx), s)))
             d2 = dx.clone()
             t1 = timeit(lambda: check(lib.fcd_conv2d_bwd_data(ctypes.byref(d), ops._p(dy), ops._p(y), ops._p(wp), ops._p(dx), s)))
-            err = (d2 - dx).abs().max().item() / dx.abs().max().item()
+            err = (d2 - dx).abs().max().item() / max(dx.abs().max().item(), 1e-30)
             line += ' gated dgrad: fused %.3f ms (%.0f TF alg) direct %.3f ms (%.0f TF)  rel diff %.1e' % (t2, fl / t2 / 1e9, t1, fl / t1 / 1e9, err)
         print(line)
         del x, y, dy, dx
