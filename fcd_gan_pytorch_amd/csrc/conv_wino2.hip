@@ -39,6 +39,9 @@ int fcd_wino_mode_now();   // conv_wino.hip: 0 = direct kernels only (tests' A/B
 #ifndef W2_EXP
 #define W2_EXP 0
 #endif
+#ifndef W2_DEEP
+#define W2_DEEP 1
+#endif
 namespace {
 constexpr int W2_ROWS = 64;                 // GEMM rows per workgroup (all of them)
 constexpr int W2_LP = 12;                   // floats per lane row in the filter slab: the ROW-transformed filter G g (4 x 3),
@@ -167,7 +170,10 @@ __global__ __launch_bounds__(64 * NW) void conv_wino2_kernel(Wino2Args a) {
 #pragma unroll
   for (int pg = 0; pg < PG; ++pg) boff[pg] = kc * W2_PL + (4 * (hrow * PG + pg)) * W2_RP + 4 * ln;   // pair rows of group pg
 
-  float xr[X_PER_T], mr[X_PER_T];
+  // DEEP [r3]: plain sources keep TWO chunks of patch loads in flight (the chunk two stages ahead is requested while the next
+  // one is still on its way): a stage lasts ~3.6 us, an HBM round trip under load is not much shorter.  Costs X_PER_T registers.
+  constexpr bool DEEP = (SRC == 0) && (W2_DEEP != 0);
+  float xr[X_PER_T], xr2[DEEP ? X_PER_T : 1], mr[X_PER_T];
   unsigned mcode[X_PER_T], x_want[X_PER_T], x_boff[X_PER_T];
   // per staged element: byte offset in the source chunk + ONE packed word {LDS offset of the .x copy : 16, channel : 4,
   // .x copy exists : 1, .y copy exists : 1} -- staging registers are what pushes this kernel against the 256-VGPR limit
@@ -207,7 +213,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wino2_kernel(Wino2Args a) {
         __builtin_amdgcn_global_load_lds((gbl_void_t*)(usrc + ins * 256), (lds_void_t*)((DST) + ins * 256), 16, 0, 0); \
     }                                                                                                \
   }
-#define W2_LOAD_X(CH)                                                                                \
+#define W2_LOAD_X(CH, XR)                                                                            \
   {                                                                                                  \
     const int cleft = a.C - (CH) * W2_CB;                                                            \
     const bool tail = cleft < W2_CB;                                                                 \
@@ -217,12 +223,12 @@ __global__ __launch_bounds__(64 * NW) void conv_wino2_kernel(Wino2Args a) {
     _Pragma("unroll") for (int i = 0; i < X_PER_T; ++i) {                                            \
       unsigned off = x_boff[i];                                                                      \
       if (tail) off = ((int)((x_pk[i] >> 16) & 15u) < cleft) ? off : 0u;                             \
-      xr[i] = *(const float*)(xsrc + off);                                                           \
+      XR[i] = *(const float*)(xsrc + off);                                                           \
       if (SRC == 1) mr[i] = *(const float*)(msrc + off);                                             \
       if (SRC == 2) mcode[i] = csrc[off >> 2];                                                       \
     }                                                                                                \
   }
-#define W2_STORE_X(BUF, CH)                                                                          \
+#define W2_STORE_X(BUF, CH, XR)                                                                      \
   {                                                                                                  \
     const int cleft = a.C - (CH) * W2_CB;                                                            \
     _Pragma("unroll") for (int i = 0; i < X_PER_T; ++i) {                                            \
@@ -230,22 +236,23 @@ __global__ __launch_bounds__(64 * NW) void conv_wino2_kernel(Wino2Args a) {
         bool keep = ((x_pk[i] >> 16) & 15u) < (unsigned)min(cleft, 15);                              \
         if (SRC == 2) keep = keep && mcode[i] == x_want[i];                                          \
         if (SRC == 1) keep = keep && mr[i] > 0.f;                                                    \
-        const float xv = keep ? xr[i] : 0.f;                                                         \
+        const float xv = keep ? XR[i] : 0.f;                                                         \
         const int lo_ = (int)(x_pk[i] & 0xFFFFu);                                                    \
         if (x_pk[i] & (1u << 20)) sx[(BUF) * XS_SZ + lo_] = xv;                                      \
         if (x_pk[i] & (1u << 21)) sx[(BUF) * XS_SZ + lo_ - 2 * W2_RP + 1] = xv;                      \
       }                                                                                              \
     }                                                                                                \
   }
-#define W2_STEP(CH, UCUR, UNXT)                                                                      \
+#define W2_STEP(CH, UCUR, UNXT, XNEXT, XFAR)      /* XNEXT: registers of chunk CH + 1; XFAR (DEEP): loaded now with CH + 2 */ \
   {                                                                                                  \
     const int cch = (CH);                                                                             \
     const bool have_next = cch + 1 < a.nchunks;                                                       \
     const int xb = (W2_EXP & 64) ? 0 : (cch & 1);                                                     \
     if (have_next && !(W2_EXP & 1)) {                                                                \
       W2_DMA(cch + 1, UNXT)                                                                           \
-      W2_LOAD_X(cch + 1)                                                                              \
+      if (!DEEP) W2_LOAD_X(cch + 1, XNEXT)                                                            \
     }                                                                                                \
+    if (DEEP && cch + 2 < a.nchunks) W2_LOAD_X(cch + 2, XFAR)                                         \
     const float* xl = sx + xb * XS_SZ;                                                               \
     _Pragma("unroll") for (int ks = 0; ks < W2_KS; ++ks) {                                           \
     float av[16];                                                                                    \
@@ -298,24 +305,32 @@ __global__ __launch_bounds__(64 * NW) void conv_wino2_kernel(Wino2Args a) {
       }                                                                                              \
     }                                                                                                \
     }                                                                                                \
-    if (have_next && !(W2_EXP & 1)) W2_STORE_X(((W2_EXP & 64) ? 0 : (xb ^ 1)), cch + 1)               \
+    if (have_next && !(W2_EXP & 1)) W2_STORE_X(((W2_EXP & 64) ? 0 : (xb ^ 1)), cch + 1, XNEXT)        \
     if (!(W2_EXP & 2)) __syncthreads();                                                                                 \
   }
 
   W2_DMA(0, su0)
-  W2_LOAD_X(0)
-  W2_STORE_X(0, 0)
+  W2_LOAD_X(0, xr)
+  if (DEEP && 1 < a.nchunks) W2_LOAD_X(1, xr2)
+  W2_STORE_X(0, 0, xr)
   __syncthreads();
   // (loop peeled rather than "if (ch + 1 < n) STEP" inside the body: that form was MIScompiled by this toolchain --
   // the second step's contributions vanished -- tools/debug/dbg_wino2*.py)
   {
     int ch = 0;
 #pragma unroll 1
-    for (; ch + 1 < a.nchunks; ch += 2) {
-      W2_STEP(ch, su0, su1)
-      W2_STEP(ch + 1, su1, su0)
+    for (; ch + 1 < a.nchunks; ch += 2) {        // DEEP: chunk ch + 1 sits in xr2 (ch even), chunk ch + 2 goes to xr
+      if (DEEP) {
+        W2_STEP(ch, su0, su1, xr2, xr)
+        W2_STEP(ch + 1, su1, su0, xr, xr2)
+      } else {
+        W2_STEP(ch, su0, su1, xr, xr)
+        W2_STEP(ch + 1, su1, su0, xr, xr)
+      }
     }
-    if (ch < a.nchunks) W2_STEP(ch, su0, su1)
+    if (ch < a.nchunks) {
+      if (DEEP) W2_STEP(ch, su0, su1, xr2, xr) else W2_STEP(ch, su0, su1, xr, xr)
+    }
   }
 #undef W2_STEP
 #undef W2_STORE_X
