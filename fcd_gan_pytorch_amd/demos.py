@@ -32,7 +32,14 @@ class _Epoch:
         for i, batch in enumerate(tiles.Prefetcher(it, self.device)):
             n = batch[0].shape[0]
             real = n - self.sampler.pads[i]
-            yield batch, real, real / float(len(self.ds))
+            w = _Weight(real / float(len(self.ds)))
+            w.loss_scale = self.sampler.scales[i]         # != 1 only in the last batch under ragged='weighted' (pass to the step)
+            yield batch, real, w
+
+
+class _Weight(float):
+    """The batch's epoch weight (a float) that also carries the loss scale of the step (``dp`` ragged='weighted')."""
+    loss_scale = 1.0
 
 
 def _real_mask(like, real):
@@ -69,7 +76,7 @@ def demo_usss(scene_x, scene_y, ref=None, device='cuda', patch_size=(220, 220), 
               epochs_g=50, epochs_s=50, epochs_joint=100, batch_size=10, learning_rate=2e-4,
               perception_weight=0.4, l1_weight=0.65, ssim_weight=0, perception_perBand=True,
               prob_thresh=0.5, gt_map=(1, 2), pre_map=(0, 1), seed=0, out_density=None, out_color=None,
-              log=None, allow_seeded=False, stats_txt=None, save_s=None, save_g=None):
+              log=None, allow_seeded=False, stats_txt=None, save_s=None, save_g=None, ragged='pad'):
     """Demo_USSS.py:29-501: G pre-train -> S pre-train -> joint training -> inference with centre write-back, with the
     reference's LR schedules (Demo_USSS.py:133,201,298-299) and per-tile dataset statistics (:88-95).
     ``scene_x/scene_y/ref``: (bands,H,W) arrays or TIFF paths; ``save_s`` / ``save_g``: ``.pkl`` paths
@@ -101,8 +108,8 @@ def demo_usss(scene_x, scene_y, ref=None, device='cuda', patch_size=(220, 220), 
     for ep in range(epochs_g):                                                   # Demo_USSS.py:126-189
         optim.adjust_learning_rate(optG, ep, lr_start=1e-5, lr_max=3e-4, lr_warm_up_epoch=10, lr_sustain_epochs=10)
         tot = torch.zeros((), device=dev)
-        for (x, y, item, r), real, w in _Epoch(ds, batch_size, seed * 1000 + ep, dev):
-            out = steps.usss_g_pretrain_step(netG, crit, optG, x, y, **kw)
+        for (x, y, item, r), real, w in _Epoch(ds, batch_size, seed * 1000 + ep, dev, ragged=ragged):
+            out = steps.usss_g_pretrain_step(netG, crit, optG, x, y, **kw, loss_scale=w.loss_scale)
             tot += out['loss'].detach() * w
         hist['g'].append(float(_epoch_mean(tot)))
         if log:
@@ -110,8 +117,8 @@ def demo_usss(scene_x, scene_y, ref=None, device='cuda', patch_size=(220, 220), 
     for ep in range(epochs_s):                                                   # Demo_USSS.py:194-286
         optim.adjust_learning_rate(optS, ep, lr_start=1e-5, lr_max=3e-4, lr_warm_up_epoch=10, lr_sustain_epochs=10)
         tot = torch.zeros((), device=dev)
-        for (x, y, item, r), real, w in _Epoch(ds, batch_size, seed * 1000 + 1000 + ep, dev):
-            out = steps.usss_s_pretrain_step(netS, netG, crit, optS, x, y, l1_weight=l1_weight, **kw)
+        for (x, y, item, r), real, w in _Epoch(ds, batch_size, seed * 1000 + 1000 + ep, dev, ragged=ragged):
+            out = steps.usss_s_pretrain_step(netS, netG, crit, optS, x, y, l1_weight=l1_weight, **kw, loss_scale=w.loss_scale)
             tot += out['net_loss'].detach() * w
         hist['s'].append(float(_epoch_mean(tot)))
         if log:
@@ -121,8 +128,8 @@ def demo_usss(scene_x, scene_y, ref=None, device='cuda', patch_size=(220, 220), 
         optim.adjust_learning_rate(optG, ep, lr_start=1e-5, lr_max=1e-4)
         tot = torch.zeros((), device=dev)
         acc.reset()
-        for (x, y, item, r), real, w in _Epoch(ds, batch_size, seed * 1000 + 2000 + ep, dev):
-            out = steps.usss_joint_step(netS, netG, crit, optS, optG, x, y, l1_weight=l1_weight, **kw)
+        for (x, y, item, r), real, w in _Epoch(ds, batch_size, seed * 1000 + 2000 + ep, dev, ragged=ragged):
+            out = steps.usss_joint_step(netS, netG, crit, optS, optG, x, y, l1_weight=l1_weight, **kw, loss_scale=w.loss_scale)
             tot += out['net_loss'].detach() * w
             if ref is not None:
                 acc.add_batch_map(r, metrics.threshold_map(out['cmap'].detach(), prob_thresh), gt_map, pre_map,
@@ -197,7 +204,7 @@ def _valid_centres(dataset, like, items, real):
 def demo_rsss(dataset, device='cuda', n_channels=4, epochs_g=50, epochs_adv=100, init_batch_size=20, batch_size=12,
               learning_rate=5e-5, perception_weight=0.1, ssim_weight=0, perception_perBand=True, l1_weight=0.02,
               g_weight=0.5, d_weight=1, r_weight=2, prob_thresh=0.5, gt_map=(1, 2), pre_map=(0, 1), seed=0,
-              netG_state=None, log=None, allow_seeded=False, load_g=None, save_s=None, save_g=None, save_d=None):
+              netG_state=None, log=None, allow_seeded=False, load_g=None, save_s=None, save_g=None, save_d=None, ragged='pad'):
     """Demo_RSSS.py:27-538 on a ``datasets.MultiSceneDataset`` / ``RegionTileDataset`` (tuples
     ``(x, y, item, ref, region)``): G pre-training on the region-masked reconstruction (skipped when a
     generator checkpoint is given -- ``load_g``: path of a ``GModel.pkl`` as the reference writes it,
@@ -225,8 +232,8 @@ def demo_rsss(dataset, device='cuda', n_channels=4, epochs_g=50, epochs_adv=100,
     for ep in range(epochs_g):                                                   # Demo_RSSS.py:175-236
         optim.adjust_learning_rate(optG, ep, lr_start=1e-5, lr_max=3e-4, lr_warm_up_epoch=10, lr_sustain_epochs=10)
         tot = torch.zeros((), device=dev)
-        for (x, y, item, r, region), real, w in _Epoch(dataset, init_batch_size, seed * 1000 + ep, dev):
-            out = steps.rsss_g_pretrain_step(netG, crit, optG, x, y, region, perception_weight, ssim_weight)
+        for (x, y, item, r, region), real, w in _Epoch(dataset, init_batch_size, seed * 1000 + ep, dev, ragged=ragged):
+            out = steps.rsss_g_pretrain_step(netG, crit, optG, x, y, region, perception_weight, ssim_weight, loss_scale=w.loss_scale)
             tot += out['g_loss'].detach() * w
         hist['g'].append(float(_epoch_mean(tot)))
         if log:
@@ -238,11 +245,11 @@ def demo_rsss(dataset, device='cuda', n_channels=4, epochs_g=50, epochs_adv=100,
         optim.adjust_learning_rate(optD, ep, lr_start=5e-6, lr_max=5e-5, lr_min=5e-7, lr_warm_up_epoch=5)
         acc.reset()
         sums = torch.zeros(3, device=dev)
-        for (x, y, item, r, region), real, w in _Epoch(dataset, batch_size, seed * 1000 + 500 + ep, dev):
+        for (x, y, item, r, region), real, w in _Epoch(dataset, batch_size, seed * 1000 + 500 + ep, dev, ragged=ragged):
             out = steps.rsss_adversarial_step(netS, netD, netG, crit, optS, optD, x, y, region,
                                               perception_weight=perception_weight, ssim_weight=ssim_weight,
                                               l1_weight=l1_weight, g_weight=g_weight, d_weight=d_weight,
-                                              r_weight=r_weight)
+                                              r_weight=r_weight, loss_scale=w.loss_scale)
             sums += torch.stack([out['d_loss'].detach(), out['s_loss'].detach(), out['g_loss'].detach()]) * w
             valid = _valid_centres(dataset, out['cmap'], item.tolist(), real)
             acc.add_batch_map(r, metrics.threshold_map(out['cmap'].detach(), prob_thresh), gt_map, pre_map, valid=valid)
@@ -260,7 +267,7 @@ def demo_rsss(dataset, device='cuda', n_channels=4, epochs_g=50, epochs_adv=100,
 def demo_wsss(changed_ds, unchanged_ds, device='cuda', n_channels=3, epochs_g=50, epochs_adv=50, unc_batch_size=50,
               batch_size=15, perception_weight=0.5, ssim_weight=0, g_weight=0.2, l1_weight=1.6, d_weight=1,
               nc_weight=1.5, seed=0, netG_state=None, log=None, allow_seeded=False, load_g=None, save_s=None,
-              save_g=None, save_d=None):
+              save_g=None, save_d=None, ragged='pad'):
     """Demo_WSSS.py:27-483 on datasets of (x, y, ...) tuples: G pre-training on UNCHANGED pairs
     with cmap = 0 (Demo_WSSS.py:152-176; skipped with ``load_g`` / ``netG_state``, :131-135), netG.eval(),
     adversarial loop over (changed, unchanged) pairs re-matched every epoch (``PairingDataset.order_reset``,
@@ -289,7 +296,7 @@ def demo_wsss(changed_ds, unchanged_ds, device='cuda', n_channels=3, epochs_g=50
     for ep in range(epochs_g):
         optim.adjust_learning_rate(optG, ep, lr_start=1e-5, lr_max=3e-4, lr_warm_up_epoch=10, lr_sustain_epochs=10)
         tot = torch.zeros((), device=dev)
-        for batch, real, w in _Epoch(unchanged_ds, unc_batch_size, seed * 1000 + ep, dev):
+        for batch, real, w in _Epoch(unchanged_ds, unc_batch_size, seed * 1000 + ep, dev, ragged=ragged):
             x, y = batch[0], batch[1]
             optG.zero_grad()
             y_fake = netG(x)
@@ -297,7 +304,7 @@ def demo_wsss(changed_ds, unchanged_ds, device='cuda', n_channels=3, epochs_g=50
             gen, ssim, perc = crit(y, y_fake, cmap)
             g_loss = gen + perception_weight * perc + ssim_weight * ssim
             optG.begin_overlap()
-            g_loss.backward()
+            steps._backward(g_loss, w.loss_scale)
             optG.allreduce_grads()
             optG.step()
             tot += g_loss.detach() * w
@@ -315,11 +322,11 @@ def demo_wsss(changed_ds, unchanged_ds, device='cuda', n_channels=3, epochs_g=50
         optim.adjust_learning_rate(optD, ep, lr_start=1e-6, lr_max=1e-5, lr_min=1e-8, lr_warm_up_epoch=5)
         pairs.order_reset(seed=seed * 7919 + ep)                                   # same pairing on every rank
         sums = torch.zeros(2, device=dev)
-        for (x, y, x_nc, y_nc), real, w in _Epoch(pairs, batch_size, seed * 1000 + 700 + ep, dev, wrap=flat):
+        for (x, y, x_nc, y_nc), real, w in _Epoch(pairs, batch_size, seed * 1000 + 700 + ep, dev, wrap=flat, ragged=ragged):
             out = steps.wsss_adversarial_step(netS, netD, netG, crit, optS, optD, x, y, x_nc, y_nc,
                                               perception_weight=perception_weight, ssim_weight=ssim_weight,
                                               g_weight=g_weight, l1_weight=l1_weight, d_weight=d_weight,
-                                              nc_weight=nc_weight)
+                                              nc_weight=nc_weight, loss_scale=w.loss_scale)
             sums += torch.stack([out['d_loss'].detach(), out['s_loss'].detach()]) * w
         hist['adv'].append([float(v) for v in _epoch_mean(sums)])
         if log:

@@ -6,6 +6,9 @@ across ranks, no data-path collective except the gradient exchange of ``optim`` 
    ``rank, rank + world, ...`` of each.  With one rank this is exactly the reference's
    ``DataLoader(ds, batch_size, shuffle=True)`` (Demo_RSSS.py:242, Demo_USSS.py:102, Demo_WSSS.py:208): batches of
    ``batch_size`` and a shorter last one (the reference has no ``drop_last``).
+ * ``ragged='weighted'`` (opt-in): no padded duplicates at all -- the last global batch is dealt out as it is, ranks hold
+   ceil / floor(L / world) samples and scale their loss by ``n_local * world / L`` (``scales[i]``, ``steps._backward``), so the
+   averaged gradient is exactly the gradient of the mean over the L samples (the reference's shorter last batch).
  * Ragged last batch under DP: every loss is a batch mean, so mean-of-local-gradients equals the global-batch
    gradient only if all ranks hold the same number of samples.  Rule (``ragged='pad'``, default): the last global
    batch is cut into equal local batches of ``ceil(L / world)`` samples; the (< world) missing samples are taken from
@@ -36,14 +39,15 @@ class RankStridedBatches:
     (duplicate) samples in this rank's i-th batch of the current epoch."""
 
     def __init__(self, n, batch_size, seed=0, shuffle=True, rank=None, world=None, ragged='pad', group=None):
-        if ragged not in ('pad', 'drop'):
-            raise ValueError("ragged must be 'pad' or 'drop'")
+        if ragged not in ('pad', 'drop', 'weighted'):
+            raise ValueError("ragged must be 'pad', 'drop' or 'weighted'")
         r, w = world_info(group)
         self.n, self.batch_size, self.shuffle, self.ragged = int(n), int(batch_size), shuffle, ragged
         self.rank = r if rank is None else int(rank)
         self.world = w if world is None else int(world)
         self.seed = int(seed)
         self.pads = []
+        self.scales = []      # loss scale of this rank's i-th batch (ragged='weighted': n_local * world / L for the last one)
 
     def set_epoch(self, seed):
         """Same value on every rank (e.g. ``base_seed * 1000 + epoch``)."""
@@ -64,6 +68,18 @@ class RankStridedBatches:
             batches.append(chunk[self.rank::self.world])
             pads.append(0)
         rest = order[full * gb:]
+        scales = [1.0] * len(batches)
+        if rest and self.ragged == 'weighted' and self.world > 1:
+            # no duplicates: the L remaining samples are dealt round-robin, ranks end up with ceil or floor(L / world) of them
+            # and weight their loss by n_local * world / L (steps._backward).  A rank left without a sample still has to take
+            # part in the step's collectives: it runs ONE flagged filler sample with loss scale 0.
+            mine = rest[self.rank::self.world]
+            if mine:
+                batches.append(mine); pads.append(0); scales.append(len(mine) * self.world / float(len(rest)))
+            else:
+                batches.append([order[0]]); pads.append(1); scales.append(0.0)
+            self._scales = scales
+            return batches, pads
         if rest and (self.ragged == 'pad' or self.world == 1):
             local = math.ceil(len(rest) / self.world)
             need = local * self.world - len(rest)
@@ -73,16 +89,19 @@ class RankStridedBatches:
             npad = sum(1 for j in range(self.rank, len(chunk), self.world) if j >= len(rest))
             batches.append(mine)
             pads.append(npad)
+            scales.append(1.0)
+        self._scales = scales
         return batches, pads
 
     def __iter__(self):
         batches, self.pads = self._plan()
+        self.scales = self._scales
         return iter(batches)
 
     def __len__(self):
         gb = self.batch_size * self.world
         full, rest = divmod(self.n, gb)
-        return full + (1 if rest and (self.ragged == 'pad' or self.world == 1) else 0)
+        return full + (1 if rest and (self.ragged in ('pad', 'weighted') or self.world == 1) else 0)
 
 
 def sync_start(nets=(), optimizers=(), src=0, group=None):

@@ -83,15 +83,26 @@ def _side_stream(device):
     return s
 
 
+def _backward(loss, loss_scale=1.0, **kw):
+    """``loss.backward()`` with the gradient scaled by ``loss_scale``.  Under data parallelism with
+    ``dp.RankStridedBatches(ragged='weighted')`` the ranks hold DIFFERENT numbers of samples in the last batch of an epoch;
+    every loss is a mean over the local batch and the exchange averages over ranks, so a rank with n_r of the L samples
+    scales its loss by n_r * world / L: the averaged gradient is then the gradient of the mean over the L samples, the
+    reference's shorter last batch (Demo_RSSS.py:242: no drop_last).  The reported loss values stay unscaled."""
+    if loss_scale != 1.0:
+        loss = loss * loss_scale
+    loss.backward(**kw)
+
+
 # ------------------------------------------------------------------------ RSSS
-def rsss_g_pretrain_step(netG, crit, optG, x, y, region, perception_weight=0.1, ssim_weight=0, group=None):
+def rsss_g_pretrain_step(netG, crit, optG, x, y, region, perception_weight=0.1, ssim_weight=0, group=None, loss_scale=1.0):
     """Demo_RSSS.py:190-208."""
     optG.zero_grad()
     y_fake = netG(x)
     generator_loss, ssim_loss, perception_loss = crit(y, y_fake, region)
     g_loss = generator_loss + perception_weight * perception_loss + ssim_weight * ssim_loss
     optG.begin_overlap(group)
-    g_loss.backward()
+    _backward(g_loss, loss_scale)
     optG.allreduce_grads(group)
     optG.step()
     return dict(g_loss=g_loss, generator_loss=generator_loss, perception_loss=perception_loss, ssim_loss=ssim_loss)
@@ -99,7 +110,7 @@ def rsss_g_pretrain_step(netG, crit, optG, x, y, region, perception_weight=0.1, 
 
 def rsss_adversarial_step(netS, netD, netG, crit, optS, optD, x, y, region, perception_weight=0.1,
                           ssim_weight=0, l1_weight=0.02, g_weight=0.5, d_weight=1, r_weight=2,
-                          discriminator_continuous=True, literal=False, group=None):
+                          discriminator_continuous=True, literal=False, group=None, loss_scale=1.0):
     """Demo_RSSS.py:285-332 (netG in eval mode, Demo_RSSS.py:240)."""
     cmap = netS(x, y)
     cmask = cmap if discriminator_continuous else (torch.sign(cmap - 0.5) + 1) / 2
@@ -113,7 +124,7 @@ def rsss_adversarial_step(netS, netD, netG, crit, optS, optD, x, y, region, perc
         optD.zero_grad()
         d_loss = 1 + nc_out.mean() - c_out.mean()
         optD.begin_overlap(group)
-        d_loss.backward(retain_graph=True)
+        _backward(d_loss, loss_scale, retain_graph=True)
     else:
         side = _side_stream(x.device)
         main = torch.cuda.current_stream(x.device) if side is not None else None
@@ -126,7 +137,7 @@ def rsss_adversarial_step(netS, netD, netG, crit, optS, optD, x, y, region, perc
             optD.zero_grad()
             d_loss = 1 + nc_out.mean() - c_out.mean()
             optD.begin_overlap(group)
-            d_loss.backward()
+            _backward(d_loss, loss_scale)
     if literal or side is None:
         optD.allreduce_grads(group)
         optD.step()
@@ -156,7 +167,7 @@ def rsss_adversarial_step(netS, netD, netG, crit, optS, optD, x, y, region, perc
     s_loss = d_weight * s_d_loss + l1_weight * l1_loss + g_weight * g_loss + r_weight * r_loss
     optS.zero_grad()
     optS.begin_overlap(group)
-    s_loss.backward()
+    _backward(s_loss, loss_scale)
     optS.allreduce_grads(group)
     optS.step()
     return dict(d_loss=d_loss, s_loss=s_loss, s_d_loss=s_d_loss, g_loss=g_loss, l1_loss=l1_loss, r_loss=r_loss,
@@ -166,7 +177,7 @@ def rsss_adversarial_step(netS, netD, netG, crit, optS, optD, x, y, region, perc
 # ------------------------------------------------------------------------ WSSS
 def wsss_adversarial_step(netS, netD, netG, crit, optS, optD, x, y, x_nc, y_nc, perception_weight=0.5,
                           ssim_weight=0, g_weight=0.2, l1_weight=1.6, d_weight=1, nc_weight=1.5,
-                          discriminator_continuous=True, literal=False, group=None):
+                          discriminator_continuous=True, literal=False, group=None, loss_scale=1.0):
     """Demo_WSSS.py:249-323 (netG in eval mode, Demo_WSSS.py:206).  The unchanged pair
     is masked with the CHANGED pair's map (:278-279)."""
     cmap = netS(x, y)
@@ -180,7 +191,7 @@ def wsss_adversarial_step(netS, netD, netG, crit, optS, optD, x, y, x_nc, y_nc, 
         optD.zero_grad()
         d_loss = 1 + nc_out.mean() - c_out.mean()
         optD.begin_overlap(group)
-        d_loss.backward(retain_graph=True)
+        _backward(d_loss, loss_scale, retain_graph=True)
     else:
         ncmap = netS(x_nc, y_nc)
         keep_d = _bcast_keep(cmask.detach(), x.shape[1])
@@ -188,7 +199,7 @@ def wsss_adversarial_step(netS, netD, netG, crit, optS, optD, x, y, x_nc, y_nc, 
         optD.zero_grad()
         d_loss = 1 + nc_out.mean() - c_out.mean()
         optD.begin_overlap(group)
-        d_loss.backward()
+        _backward(d_loss, loss_scale)
     optD.allreduce_grads(group)
     optD.step()
     nc_loss = torch.mean(torch.pow(ncmap, 2))
@@ -213,7 +224,7 @@ def wsss_adversarial_step(netS, netD, netG, crit, optS, optD, x, y, x_nc, y_nc, 
     s_loss = d_weight * s_d_loss + l1_weight * l1_loss + g_weight * g_loss + nc_weight * nc_loss
     optS.zero_grad()
     optS.begin_overlap(group)
-    s_loss.backward()
+    _backward(s_loss, loss_scale)
     optS.allreduce_grads(group)
     optS.step()
     return dict(d_loss=d_loss, s_loss=s_loss, s_d_loss=s_d_loss, g_loss=g_loss, l1_loss=l1_loss, nc_loss=nc_loss,
@@ -222,7 +233,7 @@ def wsss_adversarial_step(netS, netD, netG, crit, optS, optD, x, y, x_nc, y_nc, 
 
 
 # ------------------------------------------------------------------------ USSS
-def usss_g_pretrain_step(netG, crit, optG, x, y, perception_weight=0.4, ssim_weight=0, group=None):
+def usss_g_pretrain_step(netG, crit, optG, x, y, perception_weight=0.4, ssim_weight=0, group=None, loss_scale=1.0):
     """Demo_USSS.py:142-159 (cmap = 0)."""
     optG.zero_grad()
     y_fake = netG(x)
@@ -230,14 +241,14 @@ def usss_g_pretrain_step(netG, crit, optG, x, y, perception_weight=0.4, ssim_wei
     generator_loss, l1_loss, perception_loss, ssim_loss = crit(y, y_fake, cmap)
     loss = generator_loss + perception_weight * perception_loss + ssim_weight * ssim_loss
     optG.begin_overlap(group)
-    loss.backward()
+    _backward(loss, loss_scale)
     optG.allreduce_grads(group)
     optG.step()
     return dict(loss=loss, generator_loss=generator_loss, perception_loss=perception_loss, ssim_loss=ssim_loss)
 
 
 def usss_s_pretrain_step(netS, netG, crit, optS, x, y, perception_weight=0.4, l1_weight=0.65, ssim_weight=0,
-                         literal=False, group=None):
+                         literal=False, group=None, loss_scale=1.0):
     """Demo_USSS.py:219-228: G forward in train mode (its BN running stats keep moving),
     only S is stepped."""
     if literal:
@@ -250,7 +261,7 @@ def usss_s_pretrain_step(netS, netG, crit, optS, x, y, perception_weight=0.4, l1
     net_loss = generator_loss + l1_weight * l1_loss + perception_weight * perception_loss + ssim_weight * ssim_loss
     optS.zero_grad()
     optS.begin_overlap(group)
-    net_loss.backward()
+    _backward(net_loss, loss_scale)
     optS.allreduce_grads(group)
     optS.step()
     return dict(net_loss=net_loss, generator_loss=generator_loss, l1_loss=l1_loss, perception_loss=perception_loss,
@@ -258,7 +269,7 @@ def usss_s_pretrain_step(netS, netG, crit, optS, x, y, perception_weight=0.4, l1
 
 
 def usss_joint_step(netS, netG, crit, optS, optG, x, y, perception_weight=0.4, l1_weight=0.65, ssim_weight=0,
-                    literal=False, group=None):
+                    literal=False, group=None, loss_scale=1.0):
     """Demo_USSS.py:310-341.  The reference backpropagates ``Loss`` (retain_graph) and then
     ``NetLoss = Loss + l1_weight*l1`` over the same graph: G ends with grad(Loss)+grad(NetLoss)
     = 2*grad(Loss) (l1 does not depend on G), S with grad(NetLoss) only (zero_grad in
@@ -270,16 +281,16 @@ def usss_joint_step(netS, netG, crit, optS, optG, x, y, perception_weight=0.4, l
     loss = generator_loss + perception_weight * perception_loss + ssim_weight * ssim_loss
     net_loss = generator_loss + l1_weight * l1_loss + perception_weight * perception_loss + ssim_weight * ssim_loss
     if literal:
-        loss.backward(retain_graph=True)
+        _backward(loss, loss_scale, retain_graph=True)
         optS.zero_grad()
         optS.begin_overlap(group)          # G collects gradients from BOTH backward passes: exchanged afterwards
-        net_loss.backward()
+        _backward(net_loss, loss_scale)
         optG.allreduce_grads(group)
     else:
         optS.zero_grad()
         optG.begin_overlap(group)
         optS.begin_overlap(group)
-        net_loss.backward()
+        _backward(net_loss, loss_scale)
         optG.allreduce_grads(group)         # (waits for G's buckets before the in-place doubling)
         optG.flat_g.mul_(2.0)
     optS.allreduce_grads(group)

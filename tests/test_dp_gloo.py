@@ -152,6 +152,42 @@ def test_rank_strided_batches_partition_every_epoch():
     assert list(s) == a and list(RankStridedBatches(n, bs, seed=2, rank=0, world=2)) != a
 
 
+def test_weighted_ragged_last_batch_reproduces_the_short_batch_gradient():
+    """ragged='weighted': the last global batch is dealt out without duplicates; with the per-rank loss scale
+    n_local * world / L (steps._backward) the rank-averaged gradient of batch-mean losses IS the gradient of the mean over
+    the L samples of the reference's shorter last batch (Demo_RSSS.py:242: DataLoader without drop_last)."""
+    from fcd_gan_pytorch_amd.dp import RankStridedBatches
+    from fcd_gan_pytorch_amd.steps import _backward
+    n, bs = 23, 3
+    torch.manual_seed(3)
+    data = torch.randn(n, 5)
+    w0 = torch.randn(5)
+    for world in (2, 4, 8):
+        per_rank = [RankStridedBatches(n, bs, seed=4, rank=r, world=world, ragged='weighted') for r in range(world)]
+        plans = [list(s) for s in per_rank]
+        assert len({len(p) for p in plans}) == 1 and len(plans[0]) == len(per_rank[0])
+        last = len(plans[0]) - 1
+        assert all(per_rank[r].scales[:last] == [1.0] * last for r in range(world))
+        rest = [i for r in range(world) for i in plans[r][last][:len(plans[r][last]) - per_rank[r].pads[last]]]
+        L = n - (n // (bs * world)) * bs * world
+        assert len(rest) == L and len(set(rest)) == L, 'every remaining tile exactly once, no duplicates'
+        assert abs(sum(per_rank[r].scales[last] for r in range(world)) - world) < 1e-12
+        for r in range(world):      # a rank left without a tile runs one flagged filler with weight 0
+            k = len(plans[r][last]) - per_rank[r].pads[last]
+            assert per_rank[r].scales[last] == k * world / float(L) and (k > 0 or (per_rank[r].pads[last] == 1 and len(plans[r][last]) == 1))
+        # gradient identity on a batch-mean loss
+        wr = w0.clone().requires_grad_(True)
+        ((data[rest] @ wr) ** 2).mean().backward()
+        acc = torch.zeros(5)
+        for r in range(world):
+            wl = w0.clone().requires_grad_(True)
+            _backward(((data[plans[r][last]] @ wl) ** 2).mean(), per_rank[r].scales[last])
+            acc += wl.grad / world                               # what the all-reduce (mean over ranks) leaves
+        assert torch.allclose(acc, wr.grad, rtol=1e-5, atol=1e-6)
+    one = RankStridedBatches(n, bs, seed=4, rank=0, world=1, ragged='weighted')      # one rank: the reference's loader
+    assert [len(b) for b in one] == [3] * 7 + [2] and one.scales == [1.0] * 8 and one.pads == [0] * 8
+
+
 # ------------------------------------------------- RSSS-shaped exchange through the bucket path
 def _rsss_shaped_backward(S, D, optS, optD, x, y, region, literal=False):
     """Control flow of steps.rsss_adversarial_step (minimal mode) on the PRODUCT's parameter objects and
