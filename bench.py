@@ -63,7 +63,7 @@ def build_workload(args, dev, rank):
             crit = fcd.Loss.CGeneratorLoss(channel=C, perception_layer=1, perception_perBand=args.workload == 'rsss', allow_seeded=True)
     for m in (netD, netS, netG, crit):
         m.to(dev)
-    multi = dist.is_initialized() and dist.get_world_size() > 1
+    multi = dist.is_initialized()          # (a forced one-rank group runs the broadcasts too)
     x, y, region = (t.to(dev) for t in synthetic_tiles(1234 + rank, N, C, H, W))
 
     if args.workload == 'usss_g':
@@ -76,7 +76,7 @@ def build_workload(args, dev, rank):
 
         def step():
             return fcd.steps.usss_g_pretrain_step(netG, crit, optG, x, y)
-        return step
+        return step, {'G': optG}
 
     netS.train(); netD.train(); netG.eval()          # Demo_RSSS.py:146-148,240 / Demo_WSSS.py:206
     optS = fcd.optim.RMSprop(netS.parameters(), lr=5e-5)
@@ -96,11 +96,11 @@ def build_workload(args, dev, rank):
 
         def step():
             return fcd.steps.wsss_adversarial_step(netS, netD, netG, crit, optS, optD, x, y, x_nc, y_nc)
-        return step
+        return step, {'S': optS, 'D': optD}
 
     def step():
         return fcd.steps.rsss_adversarial_step(netS, netD, netG, crit, optS, optD, x, y, region)
-    return step
+    return step, {'S': optS, 'D': optD}
 
 
 def write_layer_tables(path, detail, psteps, args):
@@ -322,6 +322,8 @@ def main():
     ap.add_argument('--no-alt', action='store_true', help='skip the extra pass with the Winograd GEMMs on the fp32 matrix pipe')
     ap.add_argument('--prof-steps', type=int, default=3, help='steps of the profiled pass (HIP events around every launch)')
     ap.add_argument('--layers-md', default=None, help='write per-layer tables of the profiled pass to this markdown file')
+    ap.add_argument('--force-exchange', action='store_true', help='with --gpus 1: create a ONE-rank process group and run every '
+                    'data-parallel collective through it (dp.force_exchange) -- the RCCL rehearsal a 1-GPU box allows')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend: 'nccl' (= RCCL over xGMI); "
                     "'gloo' only for functional tests of the multi-rank path on a single-GPU box")
     args = ap.parse_args()
@@ -342,19 +344,26 @@ def main():
     dev_index = local_rank if args.backend == 'nccl' else local_rank % ndev
     torch.cuda.set_device(dev_index)
     dev = torch.device('cuda', dev_index)
-    if world > 1:
+    forced = world == 1 and args.force_exchange
+    if world > 1 or forced:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if forced:
+            import socket
+            s = socket.socket(); s.bind(('127.0.0.1', 0)); os.environ['MASTER_PORT'] = str(s.getsockname()[1]); s.close()
+            os.environ['RANK'], os.environ['WORLD_SIZE'] = '0', '1'
         if args.backend == 'nccl':
             dist.init_process_group('nccl', device_id=dev)
         else:
             dist.init_process_group(args.backend)
     n_gpus = world
 
-    from fcd_gan_pytorch_amd import _lib
-    step = build_workload(args, dev, rank)
+    from fcd_gan_pytorch_amd import _lib, dp as fdp
+    if forced:
+        fdp.force_exchange(True)
+    step, opts = build_workload(args, dev, rank)
 
     def barrier():
-        if world > 1:
+        if world > 1 or forced:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -362,16 +371,33 @@ def main():
         step()
     barrier()
     # ---- headline: K steps, NO per-launch events (the profiler is a separate pass below)
-    t0 = time.perf_counter()
+    cpu0, thr0, t0 = time.process_time(), time.thread_time(), time.perf_counter()
     for _ in range(args.steps):
         out = step()
+    # host time the step's launches cost: CPU seconds of the whole process (Python thread + autograd engine thread + RCCL
+    # proxy threads) up to the point where everything is queued, i.e. before the blocking synchronize
+    cpu_queued, thr_queued, t_queued = time.process_time() - cpu0, time.thread_time() - thr0, time.perf_counter() - t0
     barrier()
     dt = time.perf_counter() - t0
+    cpu_all = time.process_time() - cpu0
     losses = {k: float(v.detach()) for k, v in out.items() if v.dim() == 0}
+    host = {'host_cpu_ms_per_step': 1e3 * cpu_queued / args.steps,
+            'host_cpu_ms_per_step_python_thread': 1e3 * thr_queued / args.steps,
+            'host_wall_ms_per_step_until_queued': 1e3 * t_queued / args.steps,
+            'host_cpu_ms_per_step_incl_final_sync': 1e3 * cpu_all / args.steps}
+    exch = {k: o.last_exchange for k, o in opts.items()}
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt, host['host_cpu_ms_per_step']], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = float(t[0].item())
+        host['host_cpu_ms_per_step_max_over_ranks'] = float(t[1].item())
+        # every rank's exchange record: all ranks must have cut the same buckets and left the same number during backward
+        early = torch.tensor([(e or {}).get('launched_during_backward', -1) for e in exch.values()], dtype=torch.int64, device=dev)
+        lo, hi = early.clone(), early.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        for i, k in enumerate(exch):
+            if exch[k] is not None:
+                exch[k] = dict(exch[k], launched_during_backward_min_over_ranks=int(lo[i]), launched_during_backward_max_over_ranks=int(hi[i]))
     # ---- the same K' steps with the Winograd GEMMs on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32) instead of the
     #      split-bf16 one: reported next to `value`, never as `value`
     alt = None
@@ -430,9 +456,15 @@ def main():
                                      'same step with those GEMMs on the fp32 pipe' if _lib.lib.fcd_conv_wino_split_set(-1) == 1 else
                                      'fp32 tensors, fp32 MFMA (v_mfma_f32_*), fp32 accumulation',
                        'world_size': dist.get_world_size() if world > 1 else 1,
-                       'backend': (dist.get_backend() if world > 1 else 'none'),
-                       'grad_exchange': 'bucketed all-reduce overlapped with backward' if world > 1 else 'none (1 rank)'},
+                       'backend': (dist.get_backend() if (world > 1 or forced) else 'none'),
+                       'grad_exchange': ('bucketed all-reduce overlapped with backward' if world > 1 else
+                                         'FORCED through a one-rank %s group (rehearsal of the collectives, --force-exchange)' % args.backend
+                                         if forced else 'none (1 rank)'),
+                       'grad_exchange_last_step': exch},
             'losses_last_step': losses,
+            'host': dict(host, cores_usable=effective_cores(),
+                         note='CPU seconds this rank spent issuing one step (all threads of the process) vs the step time: with N ranks '
+                              'per node the sum over ranks has to fit the node\'s usable cores x ms_per_step'),
         }
         if alt:
             res['fp32_mfma_only'] = alt
@@ -565,7 +597,7 @@ def main():
         if n_gpus == 1 and not args.no_cpu_baseline and args.workload == 'rsss':
             res['cpu_baseline'] = cpu_baseline(args)
         print(json.dumps(res))
-    if world > 1:
+    if world > 1 or forced:
         dist.destroy_process_group()
 
 

@@ -212,9 +212,13 @@ class Segmentor(nn.Module):
         # the augmented first-layer filters depend on the folded weights and the statistics only: built once per (weights,
         # statistics) and kept on the module, so the packed-filter cache of ops.conv2d (keyed on the tensor object) hits on
         # every later batch instead of re-folding and re-packing per call
-        key = (id(w0), w0._version, tuple(tuple(float(v) for v in np.asarray(t, dtype=np.float64).reshape(-1)) for t in stats))
+        # (the entry HOLDS w0: a folded tensor rebuilt after a train()/eval() toggle may reuse the freed one's address, so
+        # identity is tested on the live object, never on id(); the fold's own key -- storage + version of every source
+        # parameter and BatchNorm buffer -- rides along)
+        key = (self.inc.__dict__.get('_fcd_folded_key'), w0._version,
+               tuple(tuple(float(v) for v in np.asarray(t, dtype=np.float64).reshape(-1)) for t in stats))
         hit = self.__dict__.get('_fcd_raw_filters')
-        if hit is None or hit[0] != key:
+        if hit is None or hit[0] != key or hit[2] is not w0:
             augs = []
             for mean, std in ((stats[0], stats[1]), (stats[2], stats[3])):
                 m = torch.as_tensor(mean, dtype=torch.float64, device=w0.device)[:w0.shape[1]]
@@ -222,13 +226,21 @@ class Segmentor(nn.Module):
                 wd = w0.double()
                 augs.append(torch.cat([wd / s.view(1, -1, 1, 1), -(wd * (m / s).view(1, -1, 1, 1)).sum(dim=1, keepdim=True)],
                                       dim=1).float().contiguous())
-            hit = (key, augs)
+            hit = (key, augs, w0)
             self.__dict__['_fcd_raw_filters'] = hit
         for x, w_aug in ((x1_raw, hit[1][0]), (x2_raw, hit[1][1])):
             xa = torch.cat([x, valid.to(x.dtype)], dim=1)
             feats.append(ops.conv2d(xa, w_aug, b0, 1, 1, relu=True))
         f = ops.conv2d(torch.cat(feats, dim=0), w1, b1, 1, 1, relu=True)
         return self._after_inc(f, n)
+
+    def train(self, mode=True):
+        self.__dict__.pop('_fcd_raw_filters', None)      # built from the folded (frozen-weight) filters: dropped with them
+        return super().train(mode)
+
+    def _apply(self, fn, *a, **k):
+        self.__dict__.pop('_fcd_raw_filters', None)
+        return super()._apply(fn, *a, **k)
 
     def _after_inc(self, f, n):
         # f: both temporal branches in one (2N, C, h, w) batch; the reference's skip tensor is cat([branch1, branch2], 1)

@@ -514,10 +514,10 @@ SYNC_BN = {'enabled': False, 'group': None}     # see fcd_gan_pytorch_amd.set_sy
 
 
 def _sync_world():
-    import torch.distributed as dist
-    if SYNC_BN['enabled'] and dist.is_available() and dist.is_initialized():
-        w = dist.get_world_size(SYNC_BN['group'])
-        return w if w > 1 else 0
+    """Ranks whose statistics a train-mode BatchNorm sums: 0 = per-replica statistics (no exchange)."""
+    if SYNC_BN['enabled']:
+        from . import dp
+        return dp.exchanging(SYNC_BN['group'])
     return 0
 
 

@@ -185,7 +185,7 @@ def infer_scene(netS, ds, device, batch_size=10, prob_thresh=0.5, gt_map=(1, 2),
         for i, it in enumerate(items):
             grid.write_center(density, cm_h[i], it)
             grid.write_center(color, co_h[i], it)
-    if dp.world_info()[1] > 1:
+    if dp.exchanging():
         both = torch.from_numpy(np.stack([density, color])).to(dev)
         dp.sum_counts(both)
         density, color = (a.copy() for a in both.cpu().numpy())

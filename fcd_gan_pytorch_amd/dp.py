@@ -22,6 +22,7 @@ across ranks, no data-path collective except the gradient exchange of ``optim`` 
    confusion matrix: SURVEY.md 8e collective 4).
 """
 import math
+import os
 
 import torch
 import torch.distributed as dist
@@ -32,6 +33,32 @@ def world_info(group=None):
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(group), dist.get_world_size(group)
     return 0, 1
+
+
+_FORCE = {'on': os.environ.get('FCD_DP_FORCE_EXCHANGE') == '1'}
+
+
+def force_exchange(on=True):
+    """Run every data-parallel exchange even in a ONE-rank process group (default: a single rank skips them all).
+
+    A 1-GPU box cannot host two RCCL ranks (RCCL refuses two ranks on one device), so without this switch the ``nccl``
+    branches -- bucketed async ``all_reduce`` from the gradient-ready hooks, ``work.wait()``, the start-of-training
+    broadcasts, the SyncBN sums, the epoch reductions -- would run for the first time on the 8-GPU node.  With it a
+    world-size-1 ``nccl`` group exercises exactly those calls (tests/test_gpu_nccl_world1.py): the result must equal the
+    no-exchange step bit for bit, since a one-rank sum is the identity and grad_scale = 1/1.  Also FCD_DP_FORCE_EXCHANGE=1."""
+    prev = _FORCE['on']
+    _FORCE['on'] = bool(on)
+    return prev
+
+
+def exchanging(group=None):
+    """World size the exchange code should act on: > 1 under data parallelism, 1 when a one-rank group is forced through the
+    collectives (:func:`force_exchange`), 0 when there is nothing to exchange."""
+    if dist.is_available() and dist.is_initialized():
+        w = dist.get_world_size(group)
+        if w > 1 or _FORCE['on']:
+            return w
+    return 0
 
 
 class RankStridedBatches:
@@ -108,8 +135,7 @@ def sync_start(nets=(), optimizers=(), src=0, group=None):
     """Make every rank start from rank ``src``'s state: flat parameter buffers of the fcd optimizers, then every
     remaining parameter / buffer of ``nets`` (BatchNorm running statistics, nets without an optimizer such as a
     pre-trained Generator).  No-op on one rank."""
-    _, world = world_info(group)
-    if world <= 1:
+    if not exchanging(group):
         return
     owned = set()
     for opt in optimizers:
@@ -133,8 +159,7 @@ def sync_buffers(nets=(), src=0, group=None):
     writes would not reproduce it.  The demos call this before ``infer_scene`` and before every ``_save`` -- the same
     rule DistributedDataParallel applies on each forward (``broadcast_buffers``), paid once per phase instead.
     No-op on one rank."""
-    _, world = world_info(group)
-    if world <= 1:
+    if not exchanging(group):
         return
     bufs = [b for net in nets for b in net.buffers()]
     for b in bufs:
@@ -145,8 +170,7 @@ def sync_buffers(nets=(), src=0, group=None):
 
 def mean_scalars(values, weight=1.0, group=None):
     """Weighted mean over ranks of a 1-D tensor of per-rank averages (weight = samples the rank averaged over)."""
-    _, world = world_info(group)
-    if world <= 1:
+    if not exchanging(group):
         return values
     buf = torch.cat([values.detach().double() * weight, torch.tensor([float(weight)], dtype=torch.float64,
                                                                    device=values.device)])
@@ -155,7 +179,6 @@ def mean_scalars(values, weight=1.0, group=None):
 
 
 def sum_counts(counts, group=None):
-    _, world = world_info(group)
-    if world > 1:
+    if exchanging(group):
         dist.all_reduce(counts, group=group)
     return counts

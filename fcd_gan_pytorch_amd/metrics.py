@@ -69,7 +69,8 @@ class Evaluator:
     def _sync(self):
         if self._dev_counts is not None:
             c = self._dev_counts
-            if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            from . import dp
+            if dp.exchanging(self.group):
                 c = c.clone()
                 dist.all_reduce(c, group=self.group)
             self.confusion_matrix = self.confusion_matrix + c.cpu().numpy().reshape(2, 2).astype(np.float64)

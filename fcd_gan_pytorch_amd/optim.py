@@ -29,6 +29,7 @@ import torch
 import torch.distributed as dist
 
 from . import _ops as ops
+from . import dp as _dp
 
 
 class _FlatOptimizer:
@@ -140,9 +141,9 @@ class _FlatOptimizer:
 
     def begin_overlap(self, group=None):
         """Arm the bucketed exchange for the NEXT backward pass (exactly one ``backward()`` must produce this
-        net's gradients before ``allreduce_grads``).  No-op on a single rank."""
+        net's gradients before ``allreduce_grads``).  No-op on a single rank (unless ``dp.force_exchange``)."""
         self._armed = False
-        if self._world(group) <= 1:
+        if not _dp.exchanging(group):
             return False
         if self._buckets is None:
             self._build_buckets()
@@ -186,9 +187,9 @@ class _FlatOptimizer:
         inside the next ``step`` (grad_scale).  After ``begin_overlap`` the buckets that became ready during the
         backward pass are already in flight: flush the rest, then make the compute stream wait for all of them.
         Without it: one all-reduce of the whole buffer."""
-        world = self._world(group)
+        world = _dp.exchanging(group)
         self._bind_grads()
-        if world <= 1:
+        if not world:
             self._armed = False
             self.grad_scale = 1.0
             return
@@ -210,7 +211,7 @@ class _FlatOptimizer:
     def broadcast_state(self, src=0, group=None):
         """Start-of-training weight sync (SURVEY.md 8e "weights broadcast from rank 0"): parameters as ONE flat
         buffer; optimizer moments are zeros on every rank at that point and need no exchange."""
-        if self._world(group) > 1:
+        if _dp.exchanging(group):
             dist.broadcast(self.flat_p, src, group=group)
             torch._C._increment_version(self.params)
             ops.invalidate_packs(self.params)

@@ -324,10 +324,8 @@ def confusion_counts(cmap, ref_changed, prob_thresh=0.5, group=None):
     """2x2 confusion counts of the thresholded map vs. a {0,1} reference on device
     (replaces the per-sample D2H + NumPy loop of Demo_RSSS.py:345-354); returns an
     int64 tensor [tn, fp, fn, tp], all-reduced across ranks when distributed."""
-    import torch.distributed as dist
+    from . import dp
     pred = cmap > prob_thresh
     ref = ref_changed > 0.5
     counts = torch.stack([(~pred & ~ref).sum(), (pred & ~ref).sum(), (~pred & ref).sum(), (pred & ref).sum()])
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(counts, group=group)
-    return counts
+    return dp.sum_counts(counts, group)

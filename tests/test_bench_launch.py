@@ -1,8 +1,8 @@
 """bench.py's rank-set resolution (`--gpus N` is authoritative) and its self-launch of N ranks.
 
 CPU: the pure decision function against the environments that occur (bare shell, torchrun, a stale inherited
-WORLD_SIZE, a launcher that disagrees with --gpus).  GPU: `python bench.py --gpus 2 --backend gloo` WITHOUT torchrun on
-the 1-GPU box starts two ranks by itself and reports n_gpus == 2."""
+WORLD_SIZE, a launcher that disagrees with --gpus).  GPU: `python bench.py --gpus 8 --backend gloo` WITHOUT torchrun on
+the 1-GPU box starts eight ranks by itself and reports n_gpus == 8."""
 import json
 import os
 import subprocess
@@ -50,24 +50,36 @@ def test_spawn_command_is_the_drivers_launch_line(monkeypatch):
 
 
 @pytest.mark.gpu
-def test_bench_gpus2_self_launch_on_one_gpu():
+def test_bench_gpus8_self_launch_on_one_gpu():
+    """`python bench.py --gpus 8 --backend gloo` WITHOUT torchrun on the 1-GPU box: eight ranks share the device (RCCL refuses that;
+    gloo carries the collectives), the whole product path runs per rank -- hooks, 4 Segmentor buckets, async handles -- and rank
+    0 reports n_gpus == 8 with every rank's exchange record (world = 8 had never run, not even functionally)."""
     env = dict(os.environ)
-    env['WORLD_SIZE'] = '8'                                                 # stale value in the caller's environment
+    env['WORLD_SIZE'] = '4'                                                 # stale value in the caller's environment
     for k in ('RANK', 'LOCAL_RANK'):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--steps', '1',
+    env['OMP_NUM_THREADS'] = '1'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--backend', 'gloo', '--steps', '2',
                         '--warmup', '1', '--batch', '1', '--bands', '4', '--size', '176', '--no-prof', '--no-alt',
-                        '--no-cpu-baseline'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+                        '--no-cpu-baseline'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, r.stdout[-2000:]
     res = json.loads(lines[0])
-    assert res['n_gpus'] == 2 and res['config']['world_size'] == 2 and res['config']['backend'] == 'gloo'
-    assert res['config']['global_batch'] == 2 and res['value'] > 0
-    # --gpus 1 under the same stale WORLD_SIZE: one process, n_gpus 1
+    assert res['n_gpus'] == 8 and res['config']['world_size'] == 8 and res['config']['backend'] == 'gloo'
+    assert res['config']['global_batch'] == 8 and res['value'] > 0
+    ex = res['config']['grad_exchange_last_step']
+    assert ex['S']['buckets'] == 4 and ex['D']['buckets'] == 1
+    assert ex['S']['launched_during_backward_min_over_ranks'] >= 1, ex       # on EVERY rank buckets left during backward
+    assert res['host']['host_cpu_ms_per_step'] > 0 and res['host']['host_cpu_ms_per_step_max_over_ranks'] > 0
+    print('\n[bench 8 ranks, gloo, one GPU] %s' % json.dumps({'exchange': ex, 'host': res['host']}))
+    # --gpus 1 under the same stale WORLD_SIZE: one process, n_gpus 1; with --force-exchange the collectives run over a one-rank
+    # nccl (= RCCL) group
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '1', '--warmup', '1',
-                        '--batch', '1', '--bands', '4', '--size', '176', '--no-prof', '--no-alt', '--no-cpu-baseline'],
+                        '--batch', '1', '--bands', '4', '--size', '176', '--no-prof', '--no-alt', '--no-cpu-baseline',
+                        '--force-exchange'],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     res = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
-    assert res['n_gpus'] == 1 and res['config']['world_size'] == 1
+    assert res['n_gpus'] == 1 and res['config']['world_size'] == 1 and res['config']['backend'] == 'nccl'
+    assert res['config']['grad_exchange_last_step']['S']['buckets'] == 4

@@ -338,3 +338,100 @@ def test_sync_buffers_makes_inference_and_checkpoint_agree():
         assert bumped
         for got, w in zip(bufs, want):
             np.testing.assert_array_equal(got, w)
+
+
+# ------------------------------------------------- world = 8: one epoch per ragged mode through buckets + hooks
+def _sample_losses(sd, x, y, idx):
+    out = onets.generator(sd, x[idx], train=False)
+    return ((out - y[idx]) ** 2).mean()          # eval-mode BN: a plain mean over the local samples
+
+
+def _world8_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from fcd_gan_pytorch_amd import optim, dp
+        from fcd_gan_pytorch_amd.steps import _backward
+        torch.set_num_threads(1)
+        C, n, bs = 4, 21, 1
+        g = _net_and_state(C)
+        opt = optim.Adam(g.parameters(), lr=1e-3, betas=(0.9, 0.99))
+        opt.bucket_bytes = 256 << 10             # 1.8 MB of gradients -> several buckets, so the in-order issue logic runs at 8 ranks
+        if rank:
+            with torch.no_grad():
+                opt.flat_p.mul_(1.0 + 0.01 * rank)
+        dp.sync_start((g,), (opt,))
+        x, y, _ = seeded_tiles(55, n, C, 16, 16)
+        sd = dict(g.named_parameters()); sd.update(dict(g.named_buffers()))
+        out = {}
+        for mode in ('pad', 'drop', 'weighted'):
+            sampler = dp.RankStridedBatches(n, bs, seed=7, ragged=mode)          # rank / world from the process group
+            grads, early = [], []
+            for i, idx in enumerate(sampler):
+                opt.zero_grad()
+                armed = opt.begin_overlap()
+                assert armed
+                _backward(_sample_losses(sd, x, y, idx), sampler.scales[i])
+                opt.allreduce_grads()
+                grads.append((opt.flat_g * opt.grad_scale).clone().numpy())
+                early.append(opt.last_exchange['launched_during_backward'])
+                nb = opt.last_exchange['buckets']
+            out[mode] = (grads, early, nb, [list(b) for b in sampler], list(sampler.pads), list(sampler.scales))
+        mean = dp.mean_scalars(torch.tensor([float(rank)]), weight=float(rank + 1))
+        q.put((rank, out, float(mean), opt.flat_p.double().sum().item()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world8_epoch_all_ragged_modes():
+    """only world = 2 had ever run.  Eight gloo ranks walk one epoch of 21 tiles (global batch 8: two full
+    steps + 5 left over) in each ragged mode through begin_overlap / hooks / several buckets: every rank runs the same number of
+    steps (no dead-lock), every step's averaged gradient equals the single-process gradient of the samples that step is
+    meant to represent (pad: the padded global batch; drop: full batches only; weighted: exactly the 5 remaining tiles)."""
+    world = 8
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_world8_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=900) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    from fcd_gan_pytorch_amd import optim
+    C, n = 4, 21
+    g = _net_and_state(C)
+    opt = optim.Adam(g.parameters(), lr=1e-3, betas=(0.9, 0.99))
+    x, y, _ = seeded_tiles(55, n, C, 16, 16)
+    sd = dict(g.named_parameters()); sd.update(dict(g.named_buffers()))
+    assert len({r[3] for r in res}) == 1 and abs(res[0][3] - opt.flat_p.double().sum().item()) < 1e-9      # sync_start at 8 ranks
+    want_mean = sum(r * (r + 1) for r in range(world)) / float(sum(r + 1 for r in range(world)))
+    assert all(abs(r[2] - want_mean) < 1e-6 for r in res)
+
+    def full_grad(idx):
+        opt.zero_grad()
+        _sample_losses(sd, x, y, idx).backward()
+        return opt.gather_grads().clone().numpy()
+    for mode, nsteps in (('pad', 3), ('drop', 2), ('weighted', 3)):
+        per = [r[1][mode] for r in res]
+        assert all(len(p[0]) == nsteps for p in per), 'every rank must run the same number of steps (%s)' % mode
+        assert all(p[2] >= 4 for p in per)                                          # several buckets
+        for s in range(nsteps):
+            members = [i for p in per for i in p[3][s]]                              # with duplicates / fillers as dealt
+            if mode == 'weighted' and s == nsteps - 1:
+                real = [i for p in per for k, i in enumerate(p[3][s]) if p[5][s] > 0]
+                assert len(real) == 5 and len(set(real)) == 5 and sum(1 for p in per if p[5][s] == 0.0) == 3
+                want = full_grad(real)
+            else:
+                assert len(members) == world
+                want = full_grad(members)
+            for rk, p in enumerate(per):
+                np.testing.assert_allclose(p[0][s], want, rtol=2e-4, atol=2e-5 * np.abs(want).max(), err_msg='%s step %d rank %d' % (mode, s, rk))
+                assert p[1][s] >= 1, 'no bucket left during backward (%s step %d rank %d)' % (mode, s, rk)
+            for p in per[1:]:
+                np.testing.assert_array_equal(p[0][s], per[0][0][s])                 # identical reduced buffer on all 8 ranks
+        if mode == 'pad':
+            real = [i for p in per for s in range(nsteps) for i in p[3][s][:len(p[3][s]) - p[4][s]]]
+            assert sorted(real) == list(range(n))

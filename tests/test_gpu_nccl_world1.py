@@ -1,0 +1,112 @@
+"""RCCL rehearsal on the 1-GPU box: a ONE-rank ``nccl`` process group with
+``dp.force_exchange(True)`` sends the data-parallel step through every collective the 8-GPU run will issue --
+``sync_start`` / ``sync_buffers`` broadcasts, the bucketed asynchronous ``all_reduce`` calls launched from the
+gradient-ready hooks while backward is still running, ``work.wait()`` (a stream-level wait on RCCL's stream), the SyncBN
+sums between the split BatchNorm kernels, the epoch reductions -- and must reproduce the no-exchange step BIT FOR BIT
+(a one-rank sum is the identity, grad_scale = 1/1).  RCCL refuses two ranks on one device, so this is the only way the
+``nccl`` branches execute before the driver's multi-GPU run; the multi-rank logic itself is covered over gloo
+(tests/test_dp_gloo.py, tests/test_gpu_dp.py)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from seeded import seeded_state, seeded_tiles
+from oracle import nets as onets
+
+pytestmark = pytest.mark.gpu
+C, N, H = 4, 2, 176
+
+
+def _step(sync_bn):
+    import fcd_gan_pytorch_amd as p
+    dev = torch.device('cuda', 0)
+    p.set_sync_batchnorm(sync_bn)
+    netG, netS, netD = p.Module.Generator(C), p.Module.Segmentor(C, 1, True), p.Module.Discriminator_SRGAN_simple(C)
+    netG.load_state_dict(seeded_state(onets.generator_spec(C), 101))
+    netS.load_state_dict(seeded_state(onets.segmentor_spec(C, 1, True), 102))
+    netD.load_state_dict(seeded_state(onets.discriminator_spec(C), 103))
+    crit = p.Loss.CGeneratorLoss(channel=C, perception_layer=1, perception_perBand=True, allow_seeded=True)
+    crit.loss_perception.net.load_state_dict(seeded_state(onets.vgg_spec(), 4242))
+    for m in (netG, netS, netD, crit):
+        m.to(dev)
+    netS.train(); netD.train(); netG.eval()
+    oS, oD = p.optim.RMSprop(netS.parameters(), lr=5e-5), p.optim.RMSprop(netD.parameters(), lr=5e-5)
+    p.dp.sync_start((netS, netD, netG), (oS, oD))                    # ncclBroadcast of the flat buffers + BN buffers
+    store = {}
+    oS.pre_step_hooks.append(lambda o: store.__setitem__('S', (o.flat_g.clone(), o.grad_scale)))
+    oD.pre_step_hooks.append(lambda o: store.__setitem__('D', (o.flat_g.clone(), o.grad_scale)))
+    x, y, region = (t.to(dev) for t in seeded_tiles(88, N, C, H, H))
+    for _ in range(2):                                                # second step: buckets re-armed, hooks re-used
+        r = p.steps.rsss_adversarial_step(netS, netD, netG, crit, oS, oD, x, y, region)
+    p.dp.sync_buffers((netS, netD))
+    counts = p.steps.confusion_counts(r['cmap'].detach(), region)     # all-reduced int64 counts
+    means = p.dp.mean_scalars(torch.stack([r['s_loss'].detach(), r['d_loss'].detach()]), weight=float(N))
+    torch.cuda.synchronize()
+    return dict(gS=store['S'][0].cpu().numpy(), gD=store['D'][0].cpu().numpy(), scale=(store['S'][1], store['D'][1]),
+                pS=oS.flat_p.cpu().numpy(), pD=oD.flat_p.cpu().numpy(), exS=oS.last_exchange, exD=oD.last_exchange,
+                rm=netS.inc.double_conv[1].running_mean.cpu().numpy(), counts=counts.cpu().numpy(), means=means.cpu().numpy(),
+                losses=np.array([float(r['s_loss']), float(r['d_loss'])]))
+
+
+def _worker(port, q):
+    import fcd_gan_pytorch_amd as p
+    torch.cuda.set_device(0)
+    out = {}
+    out['plain'] = _step(False)                                       # no process group at all: the single-GPU product path
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        out['backend'] = dist.get_backend()
+        out['idle'] = _step(False)                                    # group exists, one rank, nothing forced: must skip the exchange
+        p.dp.force_exchange(True)
+        out['forced'] = _step(False)                                  # every collective runs, per-replica BatchNorm
+        out['forced_syncbn'] = _step(True)                            # + the SyncBN sums through ncclAllReduce
+        p.dp.force_exchange(False)
+    finally:
+        dist.destroy_process_group()
+    q.put(out)
+
+
+def test_nccl_one_rank_forced_exchange_is_bit_identical():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    pr = ctx.Process(target=_worker, args=(port, q))
+    pr.start()
+    import queue as _queue
+    import time
+    t0, out = time.time(), None
+    while out is None:
+        try:
+            out = q.get(timeout=5)
+        except _queue.Empty:
+            assert pr.exitcode in (None, 0), 'the nccl world-1 worker died (exit code %s) -- see its traceback above' % pr.exitcode
+            assert time.time() - t0 < 600, 'nccl world-1 step did not finish in 10 minutes (dead-lock in a collective?)'
+    pr.join(120)
+    assert pr.exitcode == 0
+    assert out['backend'] == 'nccl'
+    plain, idle, forced, fsbn = out['plain'], out['idle'], out['forced'], out['forced_syncbn']
+    assert idle['exS'] is None and idle['exD'] is None                # one rank, not forced: no collective was issued
+    for r in (forced, fsbn):
+        assert r['exS']['buckets'] == 4 and r['exD']['buckets'] == 1, (r['exS'], r['exD'])
+        assert r['exS']['launched_during_backward'] >= 1, r['exS']    # buckets left from the hooks, during backward
+        assert r['scale'] == (1.0, 1.0)
+    print('\n[nccl world 1] S buckets %s, %d launched during backward; D %s' % (forced['exS']['bytes'],
+                                                                             forced['exS']['launched_during_backward'], forced['exD']['bytes']))
+    for k in ('gS', 'gD', 'pS', 'pD', 'rm', 'counts', 'losses'):
+        np.testing.assert_array_equal(idle[k], plain[k], err_msg=k)
+        np.testing.assert_array_equal(forced[k], plain[k], err_msg=k)   # the exchange path changes no bit
+    np.testing.assert_allclose(forced['means'], forced['losses'], rtol=1e-6)
+    # SyncBN computes the statistics with the split kernels (partial sums -> all-reduce -> apply): same numbers up to the
+    # summation order of the fp64 partials
+    for k in ('gS', 'gD'):
+        a, b = fsbn[k].astype(np.float64), plain[k].astype(np.float64)
+        rel = np.linalg.norm(a - b) / np.linalg.norm(b)
+        print('[nccl world 1] SyncBN through ncclAllReduce vs fused per-replica kernels, %s rel-L2 %.2e' % (k, rel))
+        assert rel < 2e-3, (k, rel)
+    np.testing.assert_allclose(fsbn['rm'], plain['rm'], rtol=1e-5, atol=1e-7)
