@@ -526,7 +526,7 @@ def main():
             # rocprofv3 passes over this very command: tools/pmc_bench.sh); bench.py cannot run the profiler on itself,
             # so it reports the committed measurement of the family it belongs to.
             tpath = latest_traffic_file()
-            stamp = _lib.kernel_source_hash()
+            stamp = _lib.build_hash()            # the stamp baked into the LOADED binary, not a hash of whatever sources lie around
             if tpath and args.workload == 'rsss' and args.batch == 8 and args.bands == 13 and args.size == 256:
                 with open(tpath) as f:
                     tjson = json.load(f)
@@ -535,6 +535,7 @@ def main():
                 res['hbm_traffic_source'] = {
                     'file': os.path.relpath(tpath, ROOT), 'measured_on_kernel_source_hash': tjson.get('kernel_source_hash'),
                     'this_build_kernel_source_hash': stamp, 'valid_for_this_build': fresh,
+                    'loaded_library': _lib.LIB_PATH, 'sources_next_to_it_hash': _lib.kernel_source_hash(),
                     'note': 'bench.py cannot run rocprofv3 --pmc on itself: `traffic` is the committed PMC measurement of this very '
                             'command (tools/pmc_hbm.sh), reported ONLY while the HIP sources it was taken on are the ones built here; '
                             'otherwise traffic is null'}

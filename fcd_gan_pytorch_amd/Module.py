@@ -14,6 +14,8 @@ How it differs from a layer-by-layer module tree:
    ``groups=2`` (see include/fcdgan_hip.h: fcd_bn_act_fwd).
 CUDA/ROCm tensors only: there is no CPU fallback in the product.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -372,22 +374,29 @@ class Discriminator_SRGAN_simple(nn.Module):
         d = ops.bn_act(_conv(c[1], d), None, ops.ACT_LEAKY, slope_imm=0.2)
         return torch.sigmoid(_conv(c[3], d).view(diff.shape[0]))
 
-    def _pooled(self, f):
-        """AdaptiveAvgPool2d(1) of the whole batched feature tensor BEFORE the per-pair difference: the pool is linear, so
-        pool(f_x - f_y) = pool(f_x) - pool(f_y), and the slices / differences (and their backward: a zero-filled full-size
-        gradient, a copy and an add per slice) then act on (N, 512, 1, 1) instead of (N, 512, 16, 16)."""
-        return f.mean(dim=(2, 3), keepdim=True)
+    # How the pooled pair difference is formed (A/B switch for tools/parity_probe_d.py; the product runs 'fused'):
+    #  'fused'  -- ops.pair_gap_diff: element-wise f_x - f_y first (the reference's order, Module.py:222-223), averaged with an
+    #              fp64 accumulator in one kernel, classifier on all pairs as one batch;
+    #  'diff'   -- the same order on ATen ops in fp32: (f_x - f_y).mean();
+    #  'pooled' -- round 3: mean(f) of the whole batch first, then the difference of two ROUNDED means of nearly equal
+    #              features (loses the bits the element-wise difference keeps).
+    POOL_MODE = os.environ.get('FCD_D_POOL', 'fused')
+
+    def _classify_pairs(self, f, npairs):
+        n = f.shape[0] // (2 * npairs)
+        mode = self.POOL_MODE
+        if mode == 'fused':
+            out = self.classify(ops.pair_gap_diff(f, npairs))
+            return [out[i * n:(i + 1) * n] for i in range(npairs)]
+        if mode == 'pooled':
+            f = f.mean(dim=(2, 3), keepdim=True)
+        return [self.classify(f[(2 * i) * n:(2 * i + 1) * n] - f[(2 * i + 1) * n:(2 * i + 2) * n]) for i in range(npairs)]
 
     def forward(self, x, y):
-        n = x.shape[0]
-        f = self._pooled(self.features(torch.cat([x, y], dim=0), groups=2))
-        return self.classify(f[:n] - f[n:])
+        return self._classify_pairs(self.features(torch.cat([x, y], dim=0), groups=2), 1)[0]
 
     def forward_pairs(self, pairs):
         """Evaluate several (x, y) pairs in one batched pass; equivalent to calling
         ``forward`` on each pair in order (BN running stats see x1,y1,x2,y2,...)."""
-        n = pairs[0][0].shape[0]
         z = torch.cat([t for p in pairs for t in p], dim=0)
-        f = self._pooled(self.features(z, groups=2 * len(pairs)))
-        return [self.classify(f[(2 * i) * n:(2 * i + 1) * n] - f[(2 * i + 1) * n:(2 * i + 2) * n])
-                for i in range(len(pairs))]
+        return self._classify_pairs(self.features(z, groups=2 * len(pairs)), len(pairs))

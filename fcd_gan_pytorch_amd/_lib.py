@@ -40,19 +40,11 @@ def build(force=False, verbose=False):
 
 
 def kernel_source_hash():
-    """sha256 over the HIP sources + the C-ABI header (sorted by name): the stamp that ties a committed PMC
-    measurement (profiles/r*_hbm_traffic.json) to the kernels it was taken on -- bench.py reports the measured
-    traffic only while the stamp matches."""
-    import glob
-    import hashlib
-    h = hashlib.sha256()
-    files = sorted(glob.glob(os.path.join(CSRC, '*.hip')) + glob.glob(os.path.join(CSRC, '*.h')) +
-                   glob.glob(os.path.join(_HERE, '..', 'include', '*.h')))
-    for f in files:
-        h.update(os.path.basename(f).encode())
-        with open(f, 'rb') as fh:
-            h.update(fh.read())
-    return h.hexdigest()[:16]
+    """Stamp of the HIP sources + the C-ABI header lying next to the package (csrc/source_hash.py: the same function the
+    Makefile bakes into the binary).  ``build_hash()`` is the stamp of the LOADED binary; the two differ when the .so is
+    stale or was substituted through FCD_LIB."""
+    import runpy
+    return runpy.run_path(os.path.join(CSRC, 'source_hash.py'))['source_hash']()
 
 
 class WinoFwdExtras(Structure):
@@ -67,6 +59,7 @@ P = c_void_p  # device pointers travel as plain addresses
 
 _SIGS = {
     'fcd_version': (c_int, []),
+    'fcd_build_hash': (c_char_p, []),
     'fcd_last_error_string': (c_char_p, []),
     'fcd_conv_packed_elems': (c_int64, [c_int, c_int, c_int, c_int, c_int]),
     'fcd_conv_pack_weights': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
@@ -138,6 +131,8 @@ _SIGS = {
     'fcd_upsample2x_bwd': (c_int, [P, P, c_int, c_int, c_int, P]),
     'fcd_avgpool2_pad_fwd': (c_int, [P, P, c_int, c_int, c_int, P]),
     'fcd_avgpool2_pad_bwd': (c_int, [P, P, c_int, c_int, c_int, P]),
+    'fcd_pair_gap_diff_fwd': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    'fcd_pair_gap_diff_bwd': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     'fcd_normalize_tiles': (c_int, [P, P, P, P, P, c_int, c_int, c_int, P]),
     'fcd_masked_recon_ws_bytes': (c_size_t, [c_int]),
     'fcd_masked_recon_fwd': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
@@ -173,6 +168,11 @@ def _load():
 
 
 lib = _load()
+
+
+def build_hash():
+    """Source stamp baked into the loaded libfcdgan_hip.so at build time (``fcd_build_hash``)."""
+    return lib.fcd_build_hash().decode()
 
 
 def check(rc, what=''):

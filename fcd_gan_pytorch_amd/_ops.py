@@ -115,15 +115,17 @@ def wino2_weight(weight, mode):
 def _bn_part(d, groups, relu, device):
     """Buffer for the per-workgroup BatchNorm partial sums the F(4x4) output transform can leave behind for the BatchNorm
     that follows this convolution (fcd_conv_wino_bn_part_bytes > 0), else None."""
-    if not groups or relu or device.type != 'cuda':
-        return None
+    if not groups or relu or device.type != 'cuda' or _sync_world():      # (SyncBN sums go through the all-reduce: the local
+        return None                                                       #  partials would be computed and thrown away)
     nb = lib.fcd_conv_wino_bn_part_bytes(ctypes.byref(d), int(groups))
     return torch.empty(nb // 8, dtype=torch.float64, device=device) if nb else None
 
 
 def _tag_bn(y, d, part, groups):
     if part is not None:
-        y._fcd_bn = (part, int(lib.fcd_conv_wino_bn_split(ctypes.byref(d), int(groups))), int(groups))
+        # the sums describe y AS THE KERNEL WROTE IT: the tag carries y's storage and version, and bn_act ignores it after any
+        # in-place edit of y (add_, a fused residual, a user hook) instead of normalising with stale statistics
+        y._fcd_bn = (part, int(lib.fcd_conv_wino_bn_split(ctypes.byref(d), int(groups))), int(groups), y.data_ptr(), y._version)
     return y
 
 
@@ -536,6 +538,8 @@ class _BnAct(torch.autograd.Function):
         ws = _ws(lib.fcd_bn_act_ws_bytes(C, groups), x.device)
         world = _sync_world() if (has_bn and training) else 0
         parts = getattr(x, '_fcd_bn', None) if (has_bn and training and not world) else None
+        if parts is not None and (parts[3] != x.data_ptr() or parts[4] != x._version):
+            parts = None
         if parts is not None and parts[2] == groups and parts[1] > 0:
             # the producing convolution's output transform already summed y and y^2 per workgroup (conv2d(bn_groups=...))
             check(lib.fcd_bn_act_fwd_parts(_p(x), _p(y), N, C, H * W, groups, _p(parts[0]), parts[1], _p(gamma), _p(beta),
@@ -750,6 +754,35 @@ class _AvgPool2Pad(torch.autograd.Function):
 
 def avgpool2_pad(x):
     return _AvgPool2Pad.apply(x)
+
+
+class _PairGapDiff(torch.autograd.Function):
+    """AdaptiveAvgPool2d(1)(f_x - f_y) for the Discriminator's batched feature tensor (reference Module.py:211,222-223):
+    ``f`` = (2 * pairs * n, C, h, w), pair i = sample groups (2i, 2i + 1) -> (pairs * n, C, 1, 1)."""
+
+    @staticmethod
+    def forward(ctx, f, pairs):
+        f = _dev(f, 'pair features')
+        G, C, H, W = f.shape
+        n = G // (2 * pairs)
+        d = torch.empty((pairs * n, C, 1, 1), dtype=torch.float32, device=f.device)
+        check(lib.fcd_pair_gap_diff_fwd(_p(f), _p(d), pairs, n, C, H * W, _stream()), 'fcd_pair_gap_diff_fwd')
+        ctx.cfg = (pairs, n, C, H, W)
+        return d
+
+    @staticmethod
+    def backward(ctx, g):
+        pairs, n, C, H, W = ctx.cfg
+        g = _dev(g, 'pair feature grad')
+        df = torch.empty((2 * pairs * n, C, H, W), dtype=torch.float32, device=g.device)
+        check(lib.fcd_pair_gap_diff_bwd(_p(g), _p(df), pairs, n, C, H * W, _stream()), 'fcd_pair_gap_diff_bwd')
+        return df, None
+
+
+def pair_gap_diff(f, pairs):
+    if f.shape[0] % (2 * pairs):
+        raise ValueError('pair_gap_diff: %d samples are not %d pairs of equal groups' % (f.shape[0], pairs))
+    return _PairGapDiff.apply(f, pairs)
 
 
 @torch.no_grad()

@@ -18,6 +18,8 @@ void fcd_set_error(const char* fmt, ...) {
 
 extern "C" const char* fcd_last_error_string(void) { return g_err; }
 extern "C" int fcd_version(void) { return 100; }
+#include "build/build_hash.h"
+extern "C" const char* fcd_build_hash(void) { return FCD_BUILD_HASH; }
 
 // ---------------------------------------------------------------------------
 namespace {

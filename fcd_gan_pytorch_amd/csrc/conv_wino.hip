@@ -2524,6 +2524,10 @@ extern "C" size_t fcd_conv_wino_keepv_bytes(const fcd_conv_desc* d) {
   if (on < 0) { const char* e = getenv("FCD_WINO_KEEPV"); on = (e && e[0] == '0') ? 0 : 1; }
   if (!d || !on || !wino_split() || (d->C & 31) || !wino_plan(d, 0, &pf) || pf.m != 4 || !fcd_wino_wgrad_plan(d, &pw)) return 0;
   if (pf.T != pw.T || pf.TW != pw.TW) return 0;
+  // the forward dispatch (_ops._fwd_conv) tries the fused F(2x2) kernel first, which never writes V, and a <= 64-row GEMM takes the
+  // non-split kernel, which ignores the transposed-B layout: only layers whose forward really runs the split F(4x4) GEMM keep V
+  // (reachable with FCD_WINO_MINROWS <= 64 only)
+  if (d->K <= 64 || fcd_conv_wino2_plan(d, 0)) return 0;
   return pf.v_bytes;
 }
 

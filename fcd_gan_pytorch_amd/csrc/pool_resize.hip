@@ -397,3 +397,64 @@ extern "C" int fcd_normalize_tiles(const float* x, const float* valid, const dou
   FCD_LAUNCH_CHECK("normalize_tiles");
   return FCD_OK;
 }
+
+
+// ---- pooled pair difference: AdaptiveAvgPool2d(1)(f_x - f_y) of the Discriminator (reference Module.py:211,222-223) ----
+// f holds 2 * pairs groups of n samples: pair i = (group 2i, group 2i + 1).  d[i * n + s][c] = mean_p(f_x[s][c][p] - f_y[s][c][p]).
+// The element-wise difference is taken FIRST, in the reference's order (f_x ~ f_y on nearly unchanged pairs: the fp32 difference of
+// two close numbers is exact, the difference of two rounded means is not), and accumulated in fp64; one wave per (pair sample, channel).
+__global__ void pair_gap_diff_fwd_kernel(const float* __restrict__ f, float* __restrict__ d, int pairs, int n, int C, int HW) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  const int total = pairs * n * C;
+  if (wave >= total) return;
+  const int c = wave % C, s = (wave / C) % n, i = wave / (C * n);
+  const float* fx = f + ((size_t)((2 * i) * n + s) * C + c) * HW;
+  const float* fy = f + ((size_t)((2 * i + 1) * n + s) * C + c) * HW;
+  double acc = 0.0;
+  if ((HW & 3) == 0) {
+    for (int p = 4 * lane; p < HW; p += 256) {
+      const float4 a = *reinterpret_cast<const float4*>(fx + p), b = *reinterpret_cast<const float4*>(fy + p);
+      acc += (double)(a.x - b.x) + (double)(a.y - b.y) + (double)(a.z - b.z) + (double)(a.w - b.w);
+    }
+  } else {
+    for (int p = lane; p < HW; p += 64) acc += (double)(fx[p] - fy[p]);
+  }
+  acc = wave_sum_d(acc);
+  if (lane == 0) d[wave] = (float)(acc / (double)HW);
+}
+
+// adjoint: df_x = g / HW, df_y = -g / HW (every element of f written)
+__global__ void pair_gap_diff_bwd_kernel(const float* __restrict__ g, float* __restrict__ df, int pairs, int n, int C, int HW) {
+  const long long total = (long long)2 * pairs * n * C * HW;
+  const float inv = 1.0f / (float)HW;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long pl = e / HW;                     // (group, sample, channel) plane
+    const int c = (int)(pl % C);
+    const long long t = pl / C;
+    const int s = (int)(t % n), grp = (int)(t / n);
+    const float v = g[((size_t)(grp >> 1) * n + s) * C + c] * inv;
+    df[e] = (grp & 1) ? -v : v;
+  }
+}
+
+extern "C" int fcd_pair_gap_diff_fwd(const float* f, float* d, int pairs, int n, int C, int HW, void* stream) {
+  FCD_CHECK_ARG(f && d && pairs > 0 && n > 0 && C > 0 && HW > 0, "fcd_pair_gap_diff_fwd: bad arguments");
+  const long long waves = (long long)pairs * n * C;
+  FcdProfScope prof(FCD_K_POOL, (hipStream_t)stream, 0.0, 4.0 * (2.0 * waves * HW + waves));
+  const int block = 256;
+  hipLaunchKernelGGL(pair_gap_diff_fwd_kernel, dim3((unsigned)cdiv64(waves * 64, block)), dim3(block), 0, (hipStream_t)stream,
+                     f, d, pairs, n, C, HW);
+  FCD_LAUNCH_CHECK("pair_gap_diff_fwd");
+  return FCD_OK;
+}
+
+extern "C" int fcd_pair_gap_diff_bwd(const float* g, float* df, int pairs, int n, int C, int HW, void* stream) {
+  FCD_CHECK_ARG(g && df && pairs > 0 && n > 0 && C > 0 && HW > 0, "fcd_pair_gap_diff_bwd: bad arguments");
+  const long long total = (long long)2 * pairs * n * C * HW;
+  FcdProfScope prof(FCD_K_POOL, (hipStream_t)stream, 0.0, 4.0 * (double)total);
+  const int block = 256;
+  const long long blocks = std::min<long long>(cdiv64(total, block), 256 * 64);
+  hipLaunchKernelGGL(pair_gap_diff_bwd_kernel, dim3((unsigned)blocks), dim3(block), 0, (hipStream_t)stream, g, df, pairs, n, C, HW);
+  FCD_LAUNCH_CHECK("pair_gap_diff_bwd");
+  return FCD_OK;
+}

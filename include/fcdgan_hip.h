@@ -35,6 +35,9 @@ typedef enum fcd_status {
 enum { FCD_ACT_NONE = 0, FCD_ACT_RELU = 1, FCD_ACT_LEAKY = 2, FCD_ACT_PRELU = 3 };
 
 int fcd_version(void);
+/* sha256[:16] over the HIP sources + this header the loaded binary was built from (csrc/source_hash.py); measurements
+ * committed under profiles/ are stamped with it and reported only by the binary they were taken on */
+const char* fcd_build_hash(void);
 const char* fcd_last_error_string(void);
 
 /* ---- convolution ---------------------------------------------------------
@@ -280,6 +283,12 @@ int fcd_upsample2x_fwd(const float* x, float* y, int NC, int H, int W, void* str
 int fcd_upsample2x_bwd(const float* dy, float* dx, int NC, int H, int W, void* stream);
 int fcd_avgpool2_pad_fwd(const float* x, float* y, int NC, int H, int W, void* stream);
 int fcd_avgpool2_pad_bwd(const float* dy, float* dx, int NC, int H, int W, void* stream);
+/* Discriminator_SRGAN_simple.forward, Module.py:220-223: classifier's AdaptiveAvgPool2d(1) of net(x) - net(y) for the
+ * batched feature tensor f = (2 * pairs groups of n samples, C, HW), pair i = (group 2i, group 2i + 1):
+ *   d[i * n + s][c] = mean_p (f[(2i) n + s][c][p] - f[(2i + 1) n + s][c][p])   (difference first -- the reference's order --
+ * accumulated in fp64).  bwd: df = +/- g / HW, every element of f written. */
+int fcd_pair_gap_diff_fwd(const float* f, float* d, int pairs, int n, int C, int HW, void* stream);
+int fcd_pair_gap_diff_bwd(const float* g, float* df, int pairs, int n, int C, int HW, void* stream);
 
 /* ---- raw-tile normalisation (NORMALIZE, CommonFunc.py:199-224, as GDALDataset applies it: data_utils.py:106-116)
  * out[n][c] = float((double(x[n][c]) - mean[c]) / std[c]) where valid[n] != 0, else 0.  x, out: N*C*HW floats;

@@ -68,3 +68,15 @@ def test_product_rejects_cpu_tensors():
     g = Module.Generator(4)
     with pytest.raises(_lib.FcdError):
         g(torch.zeros(1, 4, 16, 16))
+
+
+def test_binary_carries_the_stamp_of_the_sources_it_was_built_from():
+    """the traffic stamp must identify the LOADED binary.  ``fcd_build_hash()`` is baked in at build time
+    (csrc/Makefile -> build/build_hash.h); for the in-tree build it equals the hash of the sources lying next to it, so a
+    stale .so shows up here, and bench.py compares a committed PMC measurement against the binary's stamp only."""
+    import re as _re
+    from fcd_gan_pytorch_amd import _lib
+    got = _lib.build_hash()
+    assert _re.fullmatch(r'[0-9a-f]{16}', got)
+    if not os.environ.get('FCD_LIB'):
+        assert got == _lib.kernel_source_hash(), 'libfcdgan_hip.so is stale: rebuild (make -C fcd_gan_pytorch_amd/csrc)'

@@ -12,19 +12,22 @@ from oracle import nets as onets
 pytestmark = pytest.mark.gpu
 
 
-def test_demo_usss_end_to_end(tmp_path):
+@pytest.mark.parametrize('H,W,patch,overlap', [(300, 330, 200, 10),      # ragged scene: 4 overlapped 200-px patches, padded edges
+                                                (256, 256, 256, 0)])       # BASELINE.json configs[0] to the letter: ONE 256x256x4 .tif pair = one tile
+def test_demo_usss_end_to_end(tmp_path, H, W, patch, overlap):
     from fcd_gan_pytorch_amd import demos, tiles
     rng = np.random.default_rng(11)
-    C, H, W = 4, 300, 330
+    C = 4
     t1 = rng.integers(100, 3000, (C, H, W)).astype(np.uint16)
     t2 = (t1 + rng.integers(-40, 40, (C, H, W))).clip(0, 65535).astype(np.uint16)
-    t2[:, 60:140, 200:300] = rng.integers(100, 3000, (C, 80, 100))
+    c1 = min(300, W - 6)
+    t2[:, 60:140, 200:c1] = rng.integers(100, 3000, (C, 80, c1 - 200))
     ref = np.ones((1, H, W), np.uint8)
-    ref[:, 60:140, 200:300] = 2
+    ref[:, 60:140, 200:c1] = 2
     px, py, pr = str(tmp_path / 'T1.tif'), str(tmp_path / 'T2.tif'), str(tmp_path / 'ref.tif')
     tiles.write_tiff(px, t1); tiles.write_tiff(py, t2); tiles.write_tiff(pr, ref)
     logs = []
-    out = demos.demo_usss(px, py, pr, patch_size=(200, 200), overlap_padding=(10, 10), epochs_g=2, epochs_s=1,
+    out = demos.demo_usss(px, py, pr, patch_size=(patch, patch), overlap_padding=(overlap, overlap), epochs_g=2, epochs_s=1,
                           epochs_joint=1, batch_size=2, allow_seeded=True, out_density=str(tmp_path / 'density.tif'),
                           out_color=str(tmp_path / 'color.tif'), log=logs.append)
     assert len(logs) == 4 and all(np.isfinite(v) for k in out['history'] for v in out['history'][k])
@@ -36,8 +39,9 @@ def test_demo_usss_end_to_end(tmp_path):
     # oracle: eval-mode forward per tile with the trained weights, stitched with the same geometry
     netS = out['netS']
     sd = {k: v.detach().cpu() for k, v in netS.state_dict().items()}
-    stats = demos._tile_stats(t1, t2, (200, 200))      # Dataset_meanstd over the non-overlapped tiling (Demo_USSS.py:88-95)
-    ds = tiles.PairTileDataset(t1, t2, ref, (200, 200), (10, 10), stats=stats)
+    stats = demos._tile_stats(t1, t2, (patch, patch))      # Dataset_meanstd over the non-overlapped tiling (Demo_USSS.py:88-95)
+    ds = tiles.PairTileDataset(t1, t2, ref, (patch, patch), (overlap, overlap), stats=stats)
+    assert len(ds) == (4 if patch == 200 else 1)
     want = np.zeros((1, H, W), np.float32)
     for item in range(len(ds)):
         x, y, _, _ = ds[item]

@@ -801,3 +801,67 @@ def test_conv_wino2_fused_kernel(case):
     ref = yr.detach()
     ref = torch.where(ref > 0, ref, ref * 0.25) + res.double()
     assert_close(got, ref.float(), tol=tol_f, what='prelu + residual')
+
+
+@pytest.mark.parametrize('case', [(2, 128, 64, 64, 128), (3, 256, 32, 48, 128), (2, 128, 30, 44, 256)], ids=lambda c: 'x'.join(map(str, c)))
+def test_weight_gradient_from_the_forward_v_equals_the_one_from_x(case):
+    """``fcd_conv2d_bwd_weight_bias_v`` (the weight gradient as a GEMM over the transformed input V the FORWARD pass
+    left behind, ``fcd_conv2d_fwd_wino_keepv``) against ``fcd_conv2d_bwd_weight_bias`` (which transforms x again) on the same
+    layer: identical transform values, the B operand only read in another layout -- equal within fp32 round-off, and both
+    within the Winograd weight-gradient tolerance of the fp64 gradient."""
+    import ctypes
+    ops = _ops()
+    lib = ops.lib
+    N, C, H, W, K = case
+    d = ops._desc((N, C, H, W), (K, C, 3, 3), 1, 1)
+    nb = lib.fcd_conv_wino_keepv_bytes(ctypes.byref(d))
+    if not nb:
+        pytest.skip('this layer does not keep V')
+    x, w, b = rnd(N, C, H, W, seed=71).cuda(), rnd(K, C, 3, 3, seed=72, scale=(2.0 / (C * 9)) ** 0.5).cuda(), rnd(K, seed=73).cuda()
+    dy = rnd(N, K, H, W, seed=74).cuda()
+    y = torch.empty((N, K, H, W), device='cuda')
+    vk = torch.empty(nb // 4, device='cuda')
+    ws = ops._ws(lib.fcd_conv_wino_ws_bytes(ctypes.byref(d), 0), x.device)
+    ops.check(lib.fcd_conv2d_fwd_wino_keepv(ctypes.byref(d), ops._p(x), ops._p(ops.wino_weight(w, 0, 4)), ops._p(b), ops._p(y), 0, None,
+                                            None, ops._p(ws), ws.numel(), ops._p(vk), ops._stream()), 'fwd_wino_keepv')
+    out = {}
+    for tag in ('v', 'x'):
+        dw, db = torch.zeros_like(w), torch.zeros_like(b)
+        ws = ops._ws(lib.fcd_conv2d_bwd_weight_ws_bytes(ctypes.byref(d)), x.device)
+        if tag == 'v':
+            ops.check(lib.fcd_conv2d_bwd_weight_bias_v(ctypes.byref(d), ops._p(vk), ops._p(dy), None, ops._p(dw), ops._p(db), ops._p(ws),
+                                                       ws.numel(), ops._stream()), 'bwd_weight_bias_v')
+        else:
+            ops.check(lib.fcd_conv2d_bwd_weight_bias(ctypes.byref(d), ops._p(x), ops._p(dy), None, ops._p(dw), ops._p(db), ops._p(ws),
+                                                     ws.numel(), ops._stream()), 'bwd_weight_bias')
+        out[tag] = (dw.cpu().double(), db.cpu().double())
+    scale = out['x'][0].abs().max().item()
+    assert (out['v'][0] - out['x'][0]).abs().max().item() <= 2e-6 * scale
+    assert torch.equal(out['v'][1], out['x'][1])                                  # the bias gradient is the same dY pass
+    xr, wr = x.cpu().double(), w.cpu().double().requires_grad_(True)
+    F.conv2d(xr, wr, b.cpu().double(), padding=1).backward(dy.cpu().double())
+    assert_close(out['v'][0], wr.grad, tol=6e-5, what='dw from V')
+    assert_close(out['v'][1], dy.cpu().double().sum(dim=(0, 2, 3)), tol=2e-5, what='db')
+
+
+@pytest.mark.parametrize('shape', [(2, 2, 512, 16, 16), (1, 3, 40, 7, 5), (2, 1, 64, 13, 13)], ids=lambda c: 'x'.join(map(str, c)))
+def test_pair_gap_diff(shape):
+    """AdaptiveAvgPool2d(1)(net(x) - net(y)) of the Discriminator (reference Module.py:211,222-223) on the batched feature
+    tensor: one kernel, element-wise difference first, fp64 accumulator -- against the same expression in fp64."""
+    ops = _ops()
+    pairs, n, C, H, W = shape
+    f = rnd(2 * pairs * n, C, H, W, seed=81)
+    f[n:2 * n] = f[:n] + 1e-3 * rnd(n, C, H, W, seed=82)          # nearly equal branches: the cancelling case
+    fg = f.cuda().requires_grad_(True)
+    d = ops.pair_gap_diff(fg, pairs)
+    g = rnd(pairs * n, C, 1, 1, seed=83)
+    d.backward(g.cuda())
+    fr = f.double().requires_grad_(True)
+    fr5 = fr.view(pairs, 2, n, C, H, W)
+    dr = (fr5[:, 0] - fr5[:, 1]).mean(dim=(3, 4)).reshape(pairs * n, C, 1, 1)
+    dr.backward(g.double())
+    assert d.shape == (pairs * n, C, 1, 1)
+    # exact to fp32 rounding of the RESULT (the fp32 differences are the only rounded intermediates)
+    err = (d.detach().cpu().double() - dr.detach()).abs().max().item()
+    assert err <= 1.2e-7 * dr.detach().abs().max().item() + 1.2e-7 * f.abs().max().item() * 2 ** -3, err
+    assert_close(fg.grad, fr.grad, tol=1e-6, what='df')

@@ -6,7 +6,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
-from fcd_gan_pytorch_amd._lib import kernel_source_hash      # noqa: E402  (stamp: which kernels the counters were taken on)
+from fcd_gan_pytorch_amd._lib import build_hash as kernel_source_hash      # noqa: E402  (stamp baked into the binary the counters were taken on)
 
 d = sys.argv[1]
 CAL_BYTES = float(2 << 30)
