@@ -74,9 +74,12 @@ def build_workload(args, dev, rank):
             for t in netG.buffers():
                 dist.broadcast(t, 0)
 
+        gs = fcd.graph.GraphedStep(fcd.steps.usss_g_pretrain_step, nets=(netG, crit), optimizers=(optG,), warmup=2)
+        gs.enabled = args.graph
+
         def step():
-            return fcd.steps.usss_g_pretrain_step(netG, crit, optG, x, y)
-        return step, {'G': optG}
+            return gs(netG, crit, optG, x, y)
+        return step, {'G': optG}, gs
 
     netS.train(); netD.train(); netG.eval()          # Demo_RSSS.py:146-148,240 / Demo_WSSS.py:206
     optS = fcd.optim.RMSprop(netS.parameters(), lr=5e-5)
@@ -94,13 +97,19 @@ def build_workload(args, dev, rank):
         g = torch.Generator(device=dev).manual_seed(99 + rank)
         y_nc = x_nc + 0.1 * torch.randn(x_nc.shape, device=dev, generator=g)
 
+        gs = fcd.graph.GraphedStep(fcd.steps.wsss_adversarial_step, nets=(netS, netD, netG, crit), optimizers=(optS, optD), warmup=2)
+        gs.enabled = args.graph
+
         def step():
-            return fcd.steps.wsss_adversarial_step(netS, netD, netG, crit, optS, optD, x, y, x_nc, y_nc)
-        return step, {'S': optS, 'D': optD}
+            return gs(netS, netD, netG, crit, optS, optD, x, y, x_nc, y_nc)
+        return step, {'S': optS, 'D': optD}, gs
+
+    gs = fcd.graph.GraphedStep(fcd.steps.rsss_adversarial_step, nets=(netS, netD, netG, crit), optimizers=(optS, optD), warmup=2)
+    gs.enabled = args.graph
 
     def step():
-        return fcd.steps.rsss_adversarial_step(netS, netD, netG, crit, optS, optD, x, y, region)
-    return step, {'S': optS, 'D': optD}
+        return gs(netS, netD, netG, crit, optS, optD, x, y, region)
+    return step, {'S': optS, 'D': optD}, gs
 
 
 def write_layer_tables(path, detail, psteps, args):
@@ -149,16 +158,16 @@ def write_layer_tables(path, detail, psteps, args):
         L += ['', '## wino_gemm_split kernels: the same batched GEMM on the bf16 matrix pipe, fp32 operands split exactly into three '
               'bf16 parts, six partial products accumulated in fp32', '',
               'GFLOP = fp32-equivalent GEMM FLOPs (2 x batch x M x N x Kc); the MFMAs execute 6x that in bf16; bf16 dense peak %.0f TFLOP/s' % PEAK_BF16_MFMA_TFLOPS, '',
-              '| launch | /step | avg us | ms/step | GFLOP (fp32-equiv) | TFLOP/s fp32-equiv | x of the fp32 MFMA peak | bf16 TFLOP/s executed | of bf16 peak |',
-              '|---|---|---|---|---|---|---|---|---|']
+              '| launch | /step | avg us | ms/step | GFLOP (fp32-equiv) | TFLOP/s fp32-equiv | x of the fp32 MFMA peak | bf16 TFLOP/s executed | of bf16 peak | GB (V + M + filter planes, once) | TB/s on those bytes |',
+              '|---|---|---|---|---|---|---|---|---|---|---|']
         tms = tfl = 0.0
         for tag, g in rr:
             us = 1e3 * g['ms'] / g['n']
             tf = g['flops'] / (g['ms'] * 1e-3) / 1e12 if g['ms'] > 0 else 0.0
             tms += g['ms']; tfl += g['flops']
-            L.append('| %s | %.1f | %.1f | %.3f | %.2f | %.1f | %.2f | %.0f | %.2f |' % (
+            L.append('| %s | %.1f | %.1f | %.3f | %.2f | %.1f | %.2f | %.0f | %.2f | %.2f | %.2f |' % (
                 tag, g['n'] / float(psteps), us, g['ms'] / psteps, g['flops'] / g['n'] / 1e9, tf, tf / PEAK_F32_MFMA_TFLOPS,
-                6 * tf, 6 * tf / PEAK_BF16_MFMA_TFLOPS))
+                6 * tf, 6 * tf / PEAK_BF16_MFMA_TFLOPS, g['bytes'] / g['n'] / 1e9, g['bytes'] / (g['ms'] * 1e-3) / 1e12 if g['ms'] > 0 else 0.0))
         tf = tfl / (tms * 1e-3) / 1e12
         L += ['', 'all launches: %.2f ms/step, %.1f TFLOP/s fp32-equivalent (%.2fx the fp32 MFMA peak), %.0f TFLOP/s bf16 executed = %.3f of the bf16 peak'
               % (tms / psteps, tf, tf / PEAK_F32_MFMA_TFLOPS, 6 * tf, 6 * tf / PEAK_BF16_MFMA_TFLOPS)]
@@ -322,6 +331,10 @@ def main():
     ap.add_argument('--no-alt', action='store_true', help='skip the extra pass with the Winograd GEMMs on the fp32 matrix pipe')
     ap.add_argument('--prof-steps', type=int, default=3, help='steps of the profiled pass (HIP events around every launch)')
     ap.add_argument('--layers-md', default=None, help='write per-layer tables of the profiled pass to this markdown file')
+    ap.add_argument('--no-graph', action='store_true', help='issue every step launch by launch from Python instead of replaying the '
+                    'step from a hipGraph (graph.GraphedStep)')
+    ap.add_argument('--graph-multi', action='store_true', help='replay from a hipGraph with more than one rank too (RCCL collectives '
+                    'captured in the graph); default: graphs on one rank only')
     ap.add_argument('--force-exchange', action='store_true', help='with --gpus 1: create a ONE-rank process group and run every '
                     'data-parallel collective through it (dp.force_exchange) -- the RCCL rehearsal a 1-GPU box allows')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend: 'nccl' (= RCCL over xGMI); "
@@ -360,7 +373,20 @@ def main():
     from fcd_gan_pytorch_amd import _lib, dp as fdp
     if forced:
         fdp.force_exchange(True)
-    step, opts = build_workload(args, dev, rank)
+    # hipGraph replay of the step: one rank by default (what the 1-GPU box can verify end to end, incl. a forced one-rank RCCL
+    # group); with more ranks the captured graph would hold the RCCL collectives -- opt-in until an 8-GPU node has run it
+    args.graph = (not args.no_graph) and (world == 1 or args.graph_multi)
+    step, opts, gstep = build_workload(args, dev, rank)
+    if args.graph:
+        try:
+            for _ in range(gstep.warmup + 1):        # settle + capture + first replay, before the counted warm-up steps
+                step()
+            torch.cuda.synchronize()
+        except Exception as e:                       # capture refused (e.g. an un-capturable call on this software stack):
+            if rank == 0:                            # the same kernels issued launch by launch -- still the HIP path
+                print('bench.py: hipGraph capture failed (%s: %s); stepping eagerly' % (type(e).__name__, e), file=sys.stderr)
+            gstep.enabled = False
+            args.graph = False
 
     def barrier():
         if world > 1 or forced:
@@ -404,6 +430,7 @@ def main():
     if not args.no_alt and _lib.lib.fcd_conv_wino_split_set(-1) == 1:
         _lib.lib.fcd_conv_wino_split_set(0)
         ksteps = max(1, min(args.steps, 3))
+        was_graphed, gstep.enabled = gstep.enabled, False      # (the captured graph holds the split GEMM launches: this pass is eager)
         step()
         barrier()
         t1 = time.perf_counter()
@@ -412,6 +439,7 @@ def main():
         barrier()
         dta = time.perf_counter() - t1
         _lib.lib.fcd_conv_wino_split_set(1)
+        gstep.enabled = was_graphed
         if world > 1:
             t = torch.tensor([dta], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -422,6 +450,8 @@ def main():
     prof, detail, dt_prof, psteps = {}, [], None, 0
     if not args.no_prof:
         psteps = max(1, min(args.steps, args.prof_steps))
+        was_graphed, gstep.enabled = gstep.enabled, False      # per-launch HIP events: launch by launch
+        step()                                                 # (re-pack after the fp32-pipe pass, outside the profiled region)
         _lib.prof_read(reset=True)
         _lib.lib.fcd_prof_enable(2 if (args.layers_md and rank == 0) else 1)
         barrier()
@@ -431,6 +461,7 @@ def main():
         barrier()
         dt_prof = time.perf_counter() - t1
         _lib.lib.fcd_prof_enable(0)
+        gstep.enabled = was_graphed
         prof = _lib.prof_read(reset=True)
         detail = _lib.prof_detail(reset=True)
         if args.layers_md and rank == 0:
@@ -462,6 +493,9 @@ def main():
                                          if forced else 'none (1 rank)'),
                        'grad_exchange_last_step': exch},
             'losses_last_step': losses,
+            'launch': ('hipGraph replay: the whole step (forward, backward passes, optimizer kernels, BatchNorm statistics, filter re-packing) '
+                       'captured once and replayed, %d replays / %d eager calls so far' % (gstep.replays, gstep.eager_calls)) if args.graph else
+                      'launch by launch from Python (ctypes + autograd engine)',
             'host': dict(host, cores_usable=effective_cores(),
                          note='CPU seconds this rank spent issuing one step (all threads of the process) vs the step time: with N ranks '
                               'per node the sum over ranks has to fit the node\'s usable cores x ms_per_step'),

@@ -142,6 +142,8 @@ _SIGS = {
     'fcd_ssim_level_bwd': (c_int, [P, P, P, c_int, P, P, P, P, c_int, c_int, c_int, c_float, c_float, P, c_size_t, P]),
     'fcd_adam_step': (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int, c_float, P]),
     'fcd_rmsprop_step': (c_int, [P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, P]),
+    'fcd_adam_step_h': (c_int, [P, P, P, P, c_int64, P, c_float, c_float, c_float, c_float, c_float, P]),
+    'fcd_rmsprop_step_h': (c_int, [P, P, P, c_int64, P, c_float, c_float, c_float, c_float, P]),
     'fcd_prof_enable': (None, [c_int]),
     'fcd_prof_families': (c_int, []),
     'fcd_prof_detail_read': (c_int64, [c_char_p, c_int64, c_int]),

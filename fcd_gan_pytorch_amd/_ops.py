@@ -552,6 +552,7 @@ class _BnAct(torch.autograd.Function):
             check(lib.fcd_bn_partial_stats(_p(x), _p(sums), N, C, H * W, groups, _p(ws), ws.numel(), _stream()),
                   'fcd_bn_partial_stats')
             dist.all_reduce(sums, group=SYNC_BN['group'])
+            SYNC_BN['calls'] = SYNC_BN.get('calls', 0) + 1
             count = float(N // groups) * H * W * world
             check(lib.fcd_bn_act_fwd_from_stats(_p(x), _p(y), N, C, H * W, groups, _p(sums), count, _p(gamma), _p(beta),
                                                 _p(running_mean), _p(running_var), float(momentum), float(eps),
@@ -595,6 +596,7 @@ class _BnAct(torch.autograd.Function):
                 dslope = local[:, :, 2].sum().float().view(slope.shape)
             tot = part.clone()
             dist.all_reduce(tot, group=SYNC_BN['group'])
+            SYNC_BN['calls'] = SYNC_BN.get('calls', 0) + 1
             count = float(N // groups) * H * W * world
             check(lib.fcd_bn_bwd_from_sums(_p(dz), _p(x), _p(dx), N, C, H * W, groups, _p(tot), count, _p(gamma),
                                            _p(beta), _p(save_mean), _p(save_invstd), act, _p(slope), slope_imm, _p(ws),
@@ -882,6 +884,16 @@ def ssim_level(X, Y, win, C1, C2):
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
     check(lib.fcd_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
                             grad_scale, _stream()), 'fcd_adam_step')
+
+
+def adam_step_h(p, g, m, v, hyper, beta1, beta2, eps, weight_decay, grad_scale=1.0):
+    check(lib.fcd_adam_step_h(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(hyper), beta1, beta2, eps, weight_decay, grad_scale,
+                              _stream()), 'fcd_adam_step_h')
+
+
+def rmsprop_step_h(p, g, sq, hyper, alpha, eps, weight_decay, grad_scale=1.0):
+    check(lib.fcd_rmsprop_step_h(_p(p), _p(g), _p(sq), p.numel(), _p(hyper), alpha, eps, weight_decay, grad_scale, _stream()),
+          'fcd_rmsprop_step_h')
 
 
 def rmsprop_step(p, g, sq, lr, alpha, eps, weight_decay, grad_scale=1.0):

@@ -1,0 +1,136 @@
+"""Train steps replayed from a hipGraph.
+
+One Demo_RSSS iteration is ~950 kernel launches issued from Python through ctypes and the autograd engine: measured on the
+MI355X box (bench.py ``host`` block) the host needs 80 - 85 ms to QUEUE a step whose kernels run 89 ms -- the step is one
+scheduling hiccup away from being launch-bound, and eight ranks share the node's 16 usable host cores.  The step is static
+(fixed tile shapes, no host decision depends on device data: the skip-if-empty rules of Loss.py:115-119 / :133-139 are
+evaluated on the device), so it is captured ONCE into a hipGraph -- forward, both backward passes, gradient exchange,
+optimizer kernels, BatchNorm running-statistic updates, filter re-packing -- and replayed: the host cost of a step becomes one
+graph launch plus a few scalar writes.
+
+    step = graph.GraphedStep(steps.rsss_adversarial_step, nets=(netS, netD, netG, crit), optimizers=(optS, optD))
+    out = step(netS, netD, netG, crit, optS, optD, x, y, region)       # same call as the plain function
+
+What a replay cannot carry through recorded launch arguments goes through device memory: the optimizers' learning rate /
+Adam bias corrections (``optim._FlatOptimizer.use_device_hyper``: written before every replay, so
+``adjust_learning_rate`` keeps working), and the input tiles (copied into the captured buffers).  Python-side bookkeeping the
+replay skips is redone after it: optimizer step counters, parameter version counters, packed-filter caches.
+
+Rules: tensors in the returned dict are the graph's own buffers -- valid until the next call; a call whose tensor shapes or
+keyword arguments differ from every captured signature is captured separately (``max_graphs``) or runs eagerly; the first
+``warmup`` calls run eagerly (kernel modules, allocator pools and packed frozen filters settle).  Anything the graph reads
+that lives outside it (frozen VGG / Generator filters and their packed forms) is kept alive by the wrapper and its version is
+checked before every replay: editing a frozen weight re-captures.
+"""
+import torch
+
+from . import _ops as ops
+
+
+def _sig(args, kw):
+    out = []
+    for a in args:
+        out.append((tuple(a.shape), str(a.dtype), str(a.device)) if torch.is_tensor(a) else ('obj', id(a)))
+    return tuple(out), tuple(sorted((k, v) for k, v in kw.items() if not torch.is_tensor(v)))
+
+
+class GraphedStep:
+    def __init__(self, fn, nets=(), optimizers=(), warmup=2, max_graphs=2):
+        self.fn, self.nets, self.optimizers = fn, tuple(nets), tuple(optimizers)
+        self.warmup, self.max_graphs = int(warmup), int(max_graphs)
+        self.calls = 0
+        self._graphs = {}
+        self.replays = 0
+        self.eager_calls = 0
+        self.enabled = True
+
+    # -------------------------------------------------------------------------------------------------
+    def _frozen_state(self):
+        """(tensor, version) of every parameter / buffer of the nets that no captured optimizer owns, plus everything the fcd
+        caches hang on modules and tensors (packed filters, folded conv+BN filters): kept alive for the graph's lifetime."""
+        owned = {id(p) for o in self.optimizers for p in o.params}
+        watch, keep = [], []
+        for net in self.nets:
+            for t in list(net.parameters()) + list(net.buffers()):
+                if id(t) not in owned and not getattr(t, '_fcd_graph_mutable', False):
+                    watch.append(t)
+                pk = t.__dict__.get('_fcd_pack') if hasattr(t, '__dict__') else None
+                if pk:
+                    keep.append(dict(pk))
+            for m in net.modules():
+                for k, v in m.__dict__.items():
+                    if k.startswith('_fcd_'):
+                        keep.append(v)
+        return watch, keep
+
+    def _capture(self, args, kw):
+        dev = next(a for a in args if torch.is_tensor(a)).device
+        static = [a.clone() if torch.is_tensor(a) else a for a in args]
+        counts = {}
+        orig = {}
+        for o in self.optimizers:                      # count the step() calls of each optimizer inside one fn call
+            o.use_device_hyper()
+            o.write_hyper()
+            orig[id(o)] = o._after_step
+
+            def counted(o=o):
+                counts[id(o)] = counts.get(id(o), 0) + 1
+                orig[id(o)]()
+            o._after_step = counted
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(g):
+                out = self.fn(*static, **kw)
+        finally:
+            for o in self.optimizers:
+                o._after_step = orig[id(o)]
+                o.steps -= counts.get(id(o), 0)          # capture recorded the launches, nothing ran: the replay below does the step
+        watch, keep = self._frozen_state()
+        # BatchNorm buffers of nets in train() mode are moved by captured kernels (their versions change with every replay):
+        # only tensors nothing in the graph writes are watched
+        entry = dict(graph=g, static=static, out=out, counts=counts, keep=keep,
+                     watch=[(t, t._version) for t in watch if not self._written_in_graph(t)])
+        return entry
+
+    def _written_in_graph(self, t):
+        # BatchNorm running statistics of a net that is in training mode
+        for net in self.nets:
+            if net.training:
+                for b in net.buffers():
+                    if b is t:
+                        return True
+        return False
+
+    # -------------------------------------------------------------------------------------------------
+    def __call__(self, *args, **kw):
+        self.calls += 1
+        if not self.enabled or self.calls <= self.warmup:
+            self.eager_calls += 1
+            return self.fn(*args, **kw)
+        key = _sig(args, kw)
+        entry = self._graphs.get(key)
+        if entry is not None and any(t._version != v for t, v in entry['watch']):
+            entry = None                                  # a frozen weight / buffer was edited: its packed forms in the graph are stale
+            del self._graphs[key]
+        if entry is None:
+            if len(self._graphs) >= self.max_graphs:      # e.g. the ragged last batch of an epoch: not worth a graph of its own
+                self.eager_calls += 1
+                return self.fn(*args, **kw)               # (optimizers in device-hyper mode refresh their scalars themselves)
+            entry = self._graphs[key] = self._capture(args, kw)
+        for s, a in zip(entry['static'], args):
+            if torch.is_tensor(a) and s.data_ptr() != a.data_ptr():
+                s.copy_(a, non_blocking=True)
+        for o in self.optimizers:
+            o.write_hyper()
+        entry['graph'].replay()
+        self.replays += 1
+        # what the skipped Python would have done: step counters, version counters of everything the update kernels wrote,
+        # packed / transformed filter caches of the stepped parameters
+        for o in self.optimizers:
+            n = entry['counts'].get(id(o), 0)
+            if n:
+                o.steps += n
+                torch._C._increment_version(o.params)
+                ops.invalidate_packs(o.params)
+        return entry['out']

@@ -62,6 +62,7 @@ class _FlatOptimizer:
         self._buckets = None          # [(lo, hi, n_params)] over flat_g, bucket 0 = LAST parameters
         self._armed = False
         self.last_exchange = None     # diagnostics of the most recent exchange (tests, bench)
+        self._hyper = None            # device scalars of the update kernel once a hipGraph replays this optimizer (graph.GraphedStep)
 
     def zero_grad(self, set_to_none=False):
         """One memset of the flat buffer; every ``.grad`` becomes None.  The backward kernels of the fcd ops then write
@@ -240,6 +241,30 @@ class _FlatOptimizer:
     def lr(self):
         return float(self.param_groups[0]['lr'])
 
+    # ---- hipGraph replays (graph.GraphedStep): the update kernel reads its per-step scalars from device memory
+    def hyper_values(self, step):
+        """Floats the ``_h`` kernel reads for the ``step``-th (1-based) update."""
+        return [self.lr]
+
+    def use_device_hyper(self):
+        """From now on ``step()`` launches the ``_h`` kernel (scalars from ``self._hyper``); call :meth:`write_hyper` before
+        every step / replay."""
+        if self._hyper is None:
+            self._hyper = torch.zeros(4, dtype=torch.float32, device=self.flat_p.device)
+        return self._hyper
+
+    def _refresh_hyper(self):
+        """Eager ``step()`` in device-hyper mode writes the current scalars itself; while a hipGraph is being captured the
+        host-to-device write is not capturable (and not wanted: ``GraphedStep`` writes before every replay)."""
+        if not torch.cuda.is_current_stream_capturing():
+            self.write_hyper()
+
+    def write_hyper(self, step=None):
+        vals = self.hyper_values(self.steps + 1 if step is None else step)
+        # (from pageable memory on purpose: the copy is staged before the call returns, so the next step's values cannot
+        #  overtake a copy that is still queued behind earlier replays)
+        self._hyper[:len(vals)].copy_(torch.tensor(vals, dtype=torch.float32))
+
 
 class Adam(_FlatOptimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
@@ -251,9 +276,21 @@ class Adam(_FlatOptimizer):
     @torch.no_grad()
     def step(self):
         self._before_step()
-        ops.adam_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0],
-                      self.betas[1], self.eps, self.weight_decay, self.steps + 1, self.grad_scale)
+        if self._hyper is not None:
+            self._refresh_hyper()
+            ops.adam_step_h(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self._hyper, self.betas[0], self.betas[1],
+                            self.eps, self.weight_decay, self.grad_scale)
+        else:
+            ops.adam_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0],
+                          self.betas[1], self.eps, self.weight_decay, self.steps + 1, self.grad_scale)
         self._after_step()
+
+    def hyper_values(self, step):
+        # exactly what fcd_adam_step derives on the host from (beta1, beta2, step): double precision, rounded to float
+        import math
+        import numpy as np
+        b1, b2 = float(np.float32(self.betas[0])), float(np.float32(self.betas[1]))      # the kernel entry receives them as floats
+        return [self.lr, 1.0 - math.pow(b1, step), math.sqrt(1.0 - math.pow(b2, step))]
 
 
 class RMSprop(_FlatOptimizer):
@@ -265,8 +302,13 @@ class RMSprop(_FlatOptimizer):
     @torch.no_grad()
     def step(self):
         self._before_step()
-        ops.rmsprop_step(self.flat_p, self.flat_g, self.square_avg, self.lr, self.alpha, self.eps,
-                         self.weight_decay, self.grad_scale)
+        if self._hyper is not None:
+            self._refresh_hyper()
+            ops.rmsprop_step_h(self.flat_p, self.flat_g, self.square_avg, self._hyper, self.alpha, self.eps, self.weight_decay,
+                               self.grad_scale)
+        else:
+            ops.rmsprop_step(self.flat_p, self.flat_g, self.square_avg, self.lr, self.alpha, self.eps,
+                             self.weight_decay, self.grad_scale)
         self._after_step()
 
 

@@ -364,6 +364,13 @@ int fcd_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float
                   void* stream);
 int fcd_rmsprop_step(float* p, const float* g, float* sq, int64_t n, float lr, float alpha,
                      float eps, float weight_decay, float grad_scale, void* stream);
+/* The same updates with the per-step scalars in DEVICE memory (train steps replayed from a hipGraph: a replay re-issues the
+ * recorded arguments, so the learning-rate schedule of CommonFunc.py:23-37 and Adam's bias correction reach the kernel through
+ * memory).  hyper: floats {lr, 1 - beta1^t, sqrt(1 - beta2^t)} (Adam) / {lr} (RMSprop), written by the host before each step. */
+int fcd_adam_step_h(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, float beta1,
+                    float beta2, float eps, float weight_decay, float grad_scale, void* stream);
+int fcd_rmsprop_step_h(float* p, const float* g, float* sq, int64_t n, const float* hyper, float alpha,
+                       float eps, float weight_decay, float grad_scale, void* stream);
 
 /* ---- profiling -------------------------------------------------------------
  * When enabled every launch is bracketed by HIP events on its stream; read()

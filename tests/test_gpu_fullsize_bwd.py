@@ -76,7 +76,13 @@ K_TRUTH = {'direct': dict(k_flat=2.0, k_tensor=3.0, floor_flat=2e-4, floor_tenso
 # (Winograd plan, measured: the generator's gradient through the 13 F(4x4) VGG layers of the perception term ends 4.4x
 #  (flat) / 8.1x (worst tensor) as far from the fp64 truth as stock fp32 -- 1.5e-3 / 2.5e-3 absolute; the Segmentor 1.9x /
 #  3.1x.  Direct plan: 1.0 - 1.5x flat, <= 2.5x per tensor.)
-HIP_D_LIMITS = dict(flat=2e-2, tensor=3e-2)      # D against G64_D(own map): absolute (see the module docstring, point 2)
+# D against G64_D(own map).  test_discriminator_step_gradient_error_distribution below measures, on 16 maps, how far ANY fp32
+# evaluation lands from the fp64 D gradient: either ~3e-6 (no activation decision differs) or a discrete jump of 2e-4 ... 1.05e-2
+# (one LeakyReLU / BatchNorm-ed unit of the 4 x 1024-unit classifier or of net falls on the other side), for the CPU oracle and the
+# HIP kernels alike (both max 1.05e-2).  A single draw is therefore held to 1.5 x the largest jump the CPU oracle itself shows;
+# the comparison of the two implementations is the distribution test's job.
+D_LARGEST_JUMP = 1.05e-2
+HIP_D_LIMITS = dict(flat=1.5 * D_LARGEST_JUMP, tensor=2.5 * D_LARGEST_JUMP)
 
 
 def _dbl(sd):
@@ -411,3 +417,73 @@ def test_wsss_iteration_gradients_full_size(conv_path):
     bad = check_net(tag, 'D', netD, 'rmsprop', 1e-5, store, n.capture['D'], n.D, g64['D'], conv_path, limD, truth_own=own)
     bad += check_net(tag, 'S', netS, 'rmsprop', 1e-3, store, n.capture['S'], n.S, g64['S'], conv_path, limS)
     assert not bad, bad
+
+
+def test_discriminator_step_gradient_error_distribution():
+    """the Discriminator's gradient accuracy settled as a DISTRIBUTION instead of one absolute bound.
+    On 16 density maps differing by <= 3e-5 (both HIP plans' maps, seeded 1e-5 noise draws, constant offsets) the Demo_RSSS D-step
+    gradient (13 bands 256 x 256, 2 pairs) is evaluated in fp64 (the truth for that map), on the fp32 CPU oracle and on the HIP
+    kernels.  Each fp32 evaluation is either at rounding level (~3e-6) or one activation decision away (2e-4 ... 1e-2); the rule
+    compares the two implementations where that is meaningful:
+      floor   -- the best HIP draw is as close to fp64 as the best oracle draw (<= 2x): the arithmetic itself is as accurate;
+      median, geometric mean, max over the maps <= 2x / 4x / 2x the oracle's;
+      jumps   -- HIP takes a discrete jump (error > 1e-4) on at most 4 maps more than the oracle does.
+    Numbers: profiles/r04_parity_d_probe.md (same protocol, tools/parity_probe_d.py, incl. the pooled-vs-difference A/B: the
+    order of AdaptiveAvgPool and the pair difference does not move any of the 16 errors in the third digit)."""
+    p = pkg()
+    from fcd_gan_pytorch_amd import _lib
+    C, N, H = 13, 2, 256
+    sdD = seeded_state(onets.discriminator_spec(C), 13)
+    sdS = seeded_state(onets.segmentor_spec(C, 1, True), 12)
+    xc, yc, rc = seeded_tiles(21, N, C, H, H)
+    x, y, region = xc.to(DEV), yc.to(DEV), rc.to(DEV)
+    cms = []
+    prev = _lib.lib.fcd_conv_wino_set(-1)
+    try:
+        for plan in (0, 4):
+            _lib.lib.fcd_conv_wino_set(plan)
+            S = p.Module.Segmentor(C, 1, True); S.load_state_dict(sdS); S.to(DEV).train()
+            with torch.no_grad():
+                cms.append(S(x, y))
+    finally:
+        _lib.lib.fcd_conv_wino_set(prev)
+    i = 0
+    while len(cms) < 16:
+        g = torch.Generator(device=DEV).manual_seed(100 + i)
+        if i % 4 == 3:
+            cms.append(cms[0] + (i // 4 + 1) * 1e-5 * (-1) ** (i // 4))
+        else:
+            cms.append(cms[0] + 1e-5 * torch.randn(cms[0].shape, device=DEV, generator=g))
+        i += 1
+    eh, eo = [], []
+    for cm in cms:
+        keep64 = 1 - cm.detach().cpu().double()
+        xd, yd, rd = xc.double(), yc.double(), rc.double()
+        t = _d_step_fp64(sdD, (xd * keep64, yd * keep64), (xd * keep64, (yd * (1 - rd) + xd * rd) * keep64))
+        oD = onets.clone_state(sdD)
+        keep32 = 1 - cm.detach().cpu()
+        c = onets.discriminator(oD, xc * keep32, yc * keep32, train=True)
+        nc = onets.discriminator(oD, xc * keep32, (yc * (1 - rc) + xc * rc) * keep32, train=True)
+        (1 + nc.mean() - c.mean()).backward()
+        D = p.Module.Discriminator_SRGAN_simple(C); D.load_state_dict(sdD); D.to(DEV).train()
+        keep = 1 - cm.detach()
+        c_out, nc_out = D.forward_pairs([(x * keep, y * keep), (x * keep, (y * (1 - region) + x * region) * keep)])
+        (1 + nc_out.mean() - c_out.mean()).backward()
+        ks = [k for k in t if not is_pre_bn_bias(k)]
+        gh = dict(D.named_parameters())
+        ft = _flat64(t, ks)
+        eh.append(((torch.cat([gh[k].grad.detach().cpu().double().reshape(-1) for k in ks]) - ft).norm() / ft.norm()).item())
+        eo.append(((torch.cat([oD[k].grad.detach().double().reshape(-1) for k in ks]) - ft).norm() / ft.norm()).item())
+    eh, eo = np.array(eh), np.array(eo)
+    rep = dict(hip=eh.tolist(), oracle32=eo.tolist(), hip_median=float(np.median(eh)), oracle32_median=float(np.median(eo)),
+               hip_max=float(eh.max()), oracle32_max=float(eo.max()), hip_min=float(eh.min()), oracle32_min=float(eo.min()),
+               hip_geomean=float(np.exp(np.log(eh).mean())), oracle32_geomean=float(np.exp(np.log(eo).mean())),
+               hip_jumps=int((eh > 1e-4).sum()), oracle32_jumps=int((eo > 1e-4).sum()))
+    _REPORT['d_step_error_distribution_16_maps'] = rep
+    _dump_report()
+    print('\n[D distribution] %s' % json.dumps({k: v for k, v in rep.items() if not isinstance(v, list)}))
+    assert rep['hip_min'] <= 2 * rep['oracle32_min'] + 1e-6, rep
+    assert rep['hip_median'] <= 2 * rep['oracle32_median'] + 1e-5, rep
+    assert rep['hip_geomean'] <= 4 * rep['oracle32_geomean'], rep
+    assert rep['hip_max'] <= 2 * rep['oracle32_max'], rep
+    assert rep['hip_jumps'] <= rep['oracle32_jumps'] + 4, rep

@@ -22,7 +22,7 @@ pytestmark = pytest.mark.gpu
 C, N, H = 4, 2, 176
 
 
-def _step(sync_bn):
+def _step(sync_bn, graphed=False):
     import fcd_gan_pytorch_amd as p
     dev = torch.device('cuda', 0)
     p.set_sync_batchnorm(sync_bn)
@@ -41,8 +41,15 @@ def _step(sync_bn):
     oS.pre_step_hooks.append(lambda o: store.__setitem__('S', (o.flat_g.clone(), o.grad_scale)))
     oD.pre_step_hooks.append(lambda o: store.__setitem__('D', (o.flat_g.clone(), o.grad_scale)))
     x, y, region = (t.to(dev) for t in seeded_tiles(88, N, C, H, H))
-    for _ in range(2):                                                # second step: buckets re-armed, hooks re-used
-        r = p.steps.rsss_adversarial_step(netS, netD, netG, crit, oS, oD, x, y, region)
+    fn = p.steps.rsss_adversarial_step
+    if graphed:      # one eager step, then the step -- collectives included -- captured into a hipGraph and replayed twice
+        fn = p.graph.GraphedStep(fn, nets=(netS, netD, netG, crit), optimizers=(oS, oD), warmup=1)
+    for _ in range(3):                                                # later steps: buckets re-armed, hooks re-used
+        r = fn(netS, netD, netG, crit, oS, oD, x, y, region)
+    if graphed:
+        assert fn.replays == 2 and fn.eager_calls == 1
+        oS.gather_grads(); oD.gather_grads()
+        store['S'], store['D'] = (oS.flat_g.clone(), 1.0), (oD.flat_g.clone(), 1.0)      # (pre-step hooks do not run in a replay)
     p.dp.sync_buffers((netS, netD))
     counts = p.steps.confusion_counts(r['cmap'].detach(), region)     # all-reduced int64 counts
     means = p.dp.mean_scalars(torch.stack([r['s_loss'].detach(), r['d_loss'].detach()]), weight=float(N))
@@ -50,7 +57,7 @@ def _step(sync_bn):
     return dict(gS=store['S'][0].cpu().numpy(), gD=store['D'][0].cpu().numpy(), scale=(store['S'][1], store['D'][1]),
                 pS=oS.flat_p.cpu().numpy(), pD=oD.flat_p.cpu().numpy(), exS=oS.last_exchange, exD=oD.last_exchange,
                 rm=netS.inc.double_conv[1].running_mean.cpu().numpy(), counts=counts.cpu().numpy(), means=means.cpu().numpy(),
-                losses=np.array([float(r['s_loss']), float(r['d_loss'])]))
+                losses=np.array([float(r['s_loss']), float(r['d_loss'])]), syncbn_allreduces=p._ops.SYNC_BN.get('calls', 0))
 
 
 def _worker(port, q):
@@ -66,6 +73,7 @@ def _worker(port, q):
         p.dp.force_exchange(True)
         out['forced'] = _step(False)                                  # every collective runs, per-replica BatchNorm
         out['forced_syncbn'] = _step(True)                            # + the SyncBN sums through ncclAllReduce
+        out['forced_graph'] = _step(False, graphed=True)              # the same collectives recorded in a hipGraph and replayed
         p.dp.force_exchange(False)
     finally:
         dist.destroy_process_group()
@@ -102,6 +110,8 @@ def test_nccl_one_rank_forced_exchange_is_bit_identical():
         np.testing.assert_array_equal(idle[k], plain[k], err_msg=k)
         np.testing.assert_array_equal(forced[k], plain[k], err_msg=k)   # the exchange path changes no bit
     np.testing.assert_allclose(forced['means'], forced['losses'], rtol=1e-6)
+    for k in ('gS', 'gD', 'pS', 'pD', 'rm', 'counts', 'losses'):        # RCCL collectives captured in the step's hipGraph
+        np.testing.assert_array_equal(out['forced_graph'][k], plain[k], err_msg='graph ' + k)
     # SyncBN computes the statistics with the split kernels (partial sums -> all-reduce -> apply): same numbers up to the
     # summation order of the fp64 partials
     for k in ('gS', 'gD'):
@@ -110,3 +120,4 @@ def test_nccl_one_rank_forced_exchange_is_bit_identical():
         print('[nccl world 1] SyncBN through ncclAllReduce vs fused per-replica kernels, %s rel-L2 %.2e' % (k, rel))
         assert rel < 2e-3, (k, rel)
     np.testing.assert_allclose(fsbn['rm'], plain['rm'], rtol=1e-5, atol=1e-7)
+    assert fsbn['syncbn_allreduces'] > forced['syncbn_allreduces'] == 0      # the SyncBN sums really went through the process group
