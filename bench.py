@@ -331,10 +331,8 @@ def main():
     ap.add_argument('--no-alt', action='store_true', help='skip the extra pass with the Winograd GEMMs on the fp32 matrix pipe')
     ap.add_argument('--prof-steps', type=int, default=3, help='steps of the profiled pass (HIP events around every launch)')
     ap.add_argument('--layers-md', default=None, help='write per-layer tables of the profiled pass to this markdown file')
-    ap.add_argument('--no-graph', action='store_true', help='issue every step launch by launch from Python instead of replaying the '
-                    'step from a hipGraph (graph.GraphedStep)')
-    ap.add_argument('--graph-multi', action='store_true', help='replay from a hipGraph with more than one rank too (RCCL collectives '
-                    'captured in the graph); default: graphs on one rank only')
+    ap.add_argument('--graph', action='store_true', help='replay the step from a hipGraph (graph.GraphedStep) instead of issuing it launch '
+                    'by launch; one rank only (collectives are never captured).  Measured: no faster on this box -- the step is kernel-bound')
     ap.add_argument('--force-exchange', action='store_true', help='with --gpus 1: create a ONE-rank process group and run every '
                     'data-parallel collective through it (dp.force_exchange) -- the RCCL rehearsal a 1-GPU box allows')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend: 'nccl' (= RCCL over xGMI); "
@@ -373,9 +371,9 @@ def main():
     from fcd_gan_pytorch_amd import _lib, dp as fdp
     if forced:
         fdp.force_exchange(True)
-    # hipGraph replay of the step: one rank by default (what the 1-GPU box can verify end to end, incl. a forced one-rank RCCL
-    # group); with more ranks the captured graph would hold the RCCL collectives -- opt-in until an 8-GPU node has run it
-    args.graph = (not args.no_graph) and (world == 1 or args.graph_multi)
+    # hipGraph replay of the step: opt-in, one rank only (graph.py: same-box A/B shows no gain on a kernel-bound step, and a process
+    # group's watchdog thread aborts a capture that holds collectives)
+    args.graph = args.graph and world == 1 and not forced
     step, opts, gstep = build_workload(args, dev, rank)
     if args.graph:
         try:

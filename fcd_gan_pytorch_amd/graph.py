@@ -16,6 +16,21 @@ Adam bias corrections (``optim._FlatOptimizer.use_device_hyper``: written before
 ``adjust_learning_rate`` keeps working), and the input tiles (copied into the captured buffers).  Python-side bookkeeping the
 replay skips is redone after it: optimizer step counters, parameter version counters, packed-filter caches.
 
+Streams: every call -- eager warm-up, capture, replay -- is issued on ONE side stream the wrapper owns, ordered against the
+caller's stream on entry and exit.  Autograd ties each parameter's gradient-accumulation node to the stream it was created on;
+capturing on another stream than the one the warm-up steps ran on would make the engine synchronise the capturing stream with
+a non-capturing one (an invalid capture).  Returned tensors are detached: nothing keeps the previous step's autograd graph (and
+its accumulation nodes) alive into the capture.
+
+Data parallelism: NOT captured.  Measured on the MI355X box (ROCm 7.0 / PyTorch 2.10, one-rank ``nccl`` group with
+``dp.force_exchange``): with the bucketed all-reduces recorded in the graph the replays are bit-identical, but in 3 of 5 runs the
+process group's WATCHDOG THREAD -- which polls the events of earlier, eagerly issued collectives -- hit
+``hipErrorStreamCaptureUnsupported`` while the stream was capturing and aborted the process.  A wrapper whose process group is
+exchanging therefore never captures: it calls the step launch by launch (``self.refused_dp``).  Nothing is lost: at one rank the
+replayed step is not faster either (same box, 90.8 / 91.3 ms replayed vs 90.4 / 90.6 ms launch by launch at the headline
+workload; the step is kernel-bound, its ~950 launches cost the host 10 - 12 ms, and ``hipGraphLaunch`` spends as long enqueuing
+the nodes) -- the wrapper is for hosts that ARE launch-bound (fewer cores per rank, smaller tiles).
+
 Rules: tensors in the returned dict are the graph's own buffers -- valid until the next call; a call whose tensor shapes or
 keyword arguments differ from every captured signature is captured separately (``max_graphs``) or runs eagerly; the first
 ``warmup`` calls run eagerly (kernel modules, allocator pools and packed frozen filters settle).  Anything the graph reads
@@ -25,6 +40,7 @@ checked before every replay: editing a frozen weight re-captures.
 import torch
 
 from . import _ops as ops
+from . import dp as _dp
 
 
 def _sig(args, kw):
@@ -43,6 +59,8 @@ class GraphedStep:
         self.replays = 0
         self.eager_calls = 0
         self.enabled = True
+        self.refused_dp = False
+        self._side = None
 
     # -------------------------------------------------------------------------------------------------
     def _frozen_state(self):
@@ -67,25 +85,29 @@ class GraphedStep:
         dev = next(a for a in args if torch.is_tensor(a)).device
         static = [a.clone() if torch.is_tensor(a) else a for a in args]
         counts = {}
-        orig = {}
         for o in self.optimizers:                      # count the step() calls of each optimizer inside one fn call
             o.use_device_hyper()
             o.write_hyper()
-            orig[id(o)] = o._after_step
+            # every packed / transformed form of a TRAINED filter must be produced by a kernel recorded in the graph: a pack that
+            # happens to be current now (the net ran after its last update, e.g. the Discriminator inside the Segmentor step) would
+            # be read as a constant by every replay
+            ops.invalidate_packs(o.params)
 
             def counted(o=o):
+                # capture records the update launch, nothing runs: no step / version bookkeeping here (the replay does it); only
+                # the packed-filter caches must go, so that a later forward inside the same step re-packs the UPDATED weights
                 counts[id(o)] = counts.get(id(o), 0) + 1
-                orig[id(o)]()
+                o.grad_scale = 1.0
+                ops.invalidate_packs(o.params)
             o._after_step = counted
         torch.cuda.synchronize(dev)
         g = torch.cuda.CUDAGraph()
         try:
-            with torch.cuda.graph(g):
-                out = self.fn(*static, **kw)
+            with torch.cuda.graph(g, stream=self._side):
+                out = self._detached(self.fn(*static, **kw))
         finally:
             for o in self.optimizers:
-                o._after_step = orig[id(o)]
-                o.steps -= counts.get(id(o), 0)          # capture recorded the launches, nothing ran: the replay below does the step
+                del o._after_step                        # back to the class's method
         watch, keep = self._frozen_state()
         # BatchNorm buffers of nets in train() mode are moved by captured kernels (their versions change with every replay):
         # only tensors nothing in the graph writes are watched
@@ -103,11 +125,43 @@ class GraphedStep:
         return False
 
     # -------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _detached(out):
+        if isinstance(out, dict):
+            return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()}
+        if isinstance(out, (tuple, list)):
+            return type(out)(v.detach() if torch.is_tensor(v) else v for v in out)
+        return out.detach() if torch.is_tensor(out) else out
+
+    def _eager(self, main, args, kw):
+        self.eager_calls += 1
+        out = self._detached(self.fn(*args, **kw))
+        for v in (out.values() if isinstance(out, dict) else (out if isinstance(out, (tuple, list)) else (out,))):
+            if torch.is_tensor(v) and v.is_cuda:
+                v.record_stream(main)                    # allocated on the side stream, read by the caller on its own
+        return out
+
     def __call__(self, *args, **kw):
         self.calls += 1
-        if not self.enabled or self.calls <= self.warmup:
+        if self.enabled and _dp.exchanging(kw.get('group')):
+            self.enabled, self.refused_dp = False, True       # collectives must not be captured on this stack (module docstring)
+        if not self.enabled:
             self.eager_calls += 1
             return self.fn(*args, **kw)
+        dev = next(a for a in args if torch.is_tensor(a) and a.is_cuda).device
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=dev)
+        main = torch.cuda.current_stream(dev)
+        self._side.wait_stream(main)
+        try:
+            with torch.cuda.stream(self._side):
+                return self._call(main, args, kw)
+        finally:
+            main.wait_stream(self._side)
+
+    def _call(self, main, args, kw):
+        if self.calls <= self.warmup:
+            return self._eager(main, args, kw)
         key = _sig(args, kw)
         entry = self._graphs.get(key)
         if entry is not None and any(t._version != v for t, v in entry['watch']):
@@ -115,8 +169,7 @@ class GraphedStep:
             del self._graphs[key]
         if entry is None:
             if len(self._graphs) >= self.max_graphs:      # e.g. the ragged last batch of an epoch: not worth a graph of its own
-                self.eager_calls += 1
-                return self.fn(*args, **kw)               # (optimizers in device-hyper mode refresh their scalars themselves)
+                return self._eager(main, args, kw)        # (optimizers in device-hyper mode refresh their scalars themselves)
             entry = self._graphs[key] = self._capture(args, kw)
         for s, a in zip(entry['static'], args):
             if torch.is_tensor(a) and s.data_ptr() != a.data_ptr():

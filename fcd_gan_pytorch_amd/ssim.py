@@ -28,10 +28,26 @@ def _fspecial_gauss_1d(size, sigma):
     return (g / g.sum()).view(1, 1, size)
 
 
+_DEV_CONST = {}
+
+
+def _dev_const(values, device):
+    """A small constant vector on the device, uploaded ONCE per (values, device): the window taps and the level weights are the
+    same 11 + 5 numbers in every call, and a host-to-device copy per call is both two launches per step and the one thing in the
+    loss that a hipGraph capture of the train step cannot record (graph.GraphedStep)."""
+    key = (tuple(float(v) for v in values), str(device))
+    t = _DEV_CONST.get(key)
+    if t is None:
+        t = _DEV_CONST[key] = torch.tensor(key[0], dtype=torch.float32, device=device)
+    return t
+
+
 def _taps_from(win, device):
     """Accept the reference's (C,1,1,k) / (1,1,k) window tensors; return the k taps."""
     w = win.reshape(-1, win.shape[-1])[0]
-    return w.to(device=device, dtype=torch.float32).contiguous()
+    if w.is_cuda:
+        return w.to(device=device, dtype=torch.float32).contiguous()
+    return _dev_const(w.tolist(), device)
 
 
 def _check_pair(X, Y):
@@ -81,8 +97,7 @@ def ms_ssim(X, Y, data_range=255, size_average=True, win_size=11, win_sigma=1.5,
     smaller_side = min(X.shape[-2:])
     assert smaller_side > (win_size - 1) * (2 ** 4), \
         "Image size should be larger than %d due to the 4 downsamplings in ms-ssim" % ((win_size - 1) * (2 ** 4))
-    w = torch.tensor(list(weights) if weights is not None else list(_DEFAULT_WEIGHTS),
-                     dtype=X.dtype, device=X.device)
+    w = _dev_const(list(weights) if weights is not None else list(_DEFAULT_WEIGHTS), X.device).to(X.dtype)
     taps = _taps_from(win if win is not None else _fspecial_gauss_1d(win_size, win_sigma), X.device)
     C1, C2 = _consts(data_range, K)
     levels = w.shape[0]
@@ -94,7 +109,13 @@ def ms_ssim(X, Y, data_range=255, size_average=True, win_size=11, win_sigma=1.5,
             X = ops.avgpool2_pad(X)
             Y = ops.avgpool2_pad(Y)
     terms.append(torch.relu(s_c))
-    val = torch.prod(torch.stack(terms, dim=0) ** w.view(-1, 1, 1), dim=0)
+    # prod_l term_l ** w_l (reference ssim.py:219-222: torch.prod over the stacked levels).  Written as a chain of products:
+    # torch.prod's backward counts the zeros of its input with ``.item()`` -- a host synchronisation in the middle of every
+    # backward pass that runs through MS-SSIM (the USSS steps), and not capturable in a hipGraph.  The chain's gradient w.r.t. a
+    # level is the product of the other levels, which is what prod_backward computes on its zero-safe path.
+    val = terms[0] ** w[0]
+    for lvl in range(1, levels):
+        val = val * terms[lvl] ** w[lvl]
     return val.mean() if size_average else val.mean(1)
 
 

@@ -233,13 +233,13 @@ def wsss_adversarial_step(netS, netD, netG, crit, optS, optD, x, y, x_nc, y_nc, 
 
 
 # ------------------------------------------------------------------------ USSS
-def usss_g_pretrain_step(netG, crit, optG, x, y, perception_weight=0.4, ssim_weight=0, group=None, loss_scale=1.0):
+def usss_g_pretrain_step(netG, crit, optG, x, y, perception_weight=0.4, ssim_weight=0, group=None, loss_scale=1.0, literal=False):
     """Demo_USSS.py:142-159 (cmap = 0)."""
     optG.zero_grad()
     y_fake = netG(x)
     cmap = torch.zeros((x.shape[0], 1, x.shape[2], x.shape[3]), device=x.device)
     generator_loss, l1_loss, perception_loss, ssim_loss = crit(y, y_fake, cmap)
-    loss = generator_loss + perception_weight * perception_loss + ssim_weight * ssim_loss
+    loss = generator_loss + perception_weight * perception_loss + _weighted(ssim_weight, ssim_loss, literal)
     optG.begin_overlap(group)
     _backward(loss, loss_scale)
     optG.allreduce_grads(group)
@@ -258,7 +258,7 @@ def usss_s_pretrain_step(netS, netG, crit, optS, x, y, perception_weight=0.4, l1
             y_fake = netG(x)
     cmap = netS(x, y)
     generator_loss, l1_loss, perception_loss, ssim_loss = crit(y, y_fake, cmap)
-    net_loss = generator_loss + l1_weight * l1_loss + perception_weight * perception_loss + ssim_weight * ssim_loss
+    net_loss = generator_loss + l1_weight * l1_loss + perception_weight * perception_loss + _weighted(ssim_weight, ssim_loss, literal)
     optS.zero_grad()
     optS.begin_overlap(group)
     _backward(net_loss, loss_scale)
@@ -278,8 +278,8 @@ def usss_joint_step(netS, netG, crit, optS, optG, x, y, perception_weight=0.4, l
     y_fake = netG(x)
     cmap = netS(x, y)
     generator_loss, l1_loss, perception_loss, ssim_loss = crit(y, y_fake, cmap)
-    loss = generator_loss + perception_weight * perception_loss + ssim_weight * ssim_loss
-    net_loss = generator_loss + l1_weight * l1_loss + perception_weight * perception_loss + ssim_weight * ssim_loss
+    loss = generator_loss + perception_weight * perception_loss + _weighted(ssim_weight, ssim_loss, literal)
+    net_loss = generator_loss + l1_weight * l1_loss + perception_weight * perception_loss + _weighted(ssim_weight, ssim_loss, literal)
     if literal:
         _backward(loss, loss_scale, retain_graph=True)
         optS.zero_grad()

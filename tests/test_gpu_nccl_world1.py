@@ -47,9 +47,7 @@ def _step(sync_bn, graphed=False):
     for _ in range(3):                                                # later steps: buckets re-armed, hooks re-used
         r = fn(netS, netD, netG, crit, oS, oD, x, y, region)
     if graphed:
-        assert fn.replays == 2 and fn.eager_calls == 1
-        oS.gather_grads(); oD.gather_grads()
-        store['S'], store['D'] = (oS.flat_g.clone(), 1.0), (oD.flat_g.clone(), 1.0)      # (pre-step hooks do not run in a replay)
+        assert fn.replays == 0 and fn.eager_calls == 3                # refused to capture collectives: launch by launch
     p.dp.sync_buffers((netS, netD))
     counts = p.steps.confusion_counts(r['cmap'].detach(), region)     # all-reduced int64 counts
     means = p.dp.mean_scalars(torch.stack([r['s_loss'].detach(), r['d_loss'].detach()]), weight=float(N))
@@ -60,31 +58,53 @@ def _step(sync_bn, graphed=False):
                 losses=np.array([float(r['s_loss']), float(r['d_loss'])]), syncbn_allreduces=p._ops.SYNC_BN.get('calls', 0))
 
 
-def _worker(port, q):
+def _digest(r):
+    import hashlib
+    return {k: hashlib.sha256(np.ascontiguousarray(r[k]).tobytes()).hexdigest() for k in ('gS', 'gD', 'pS', 'pD', 'rm', 'counts', 'losses')}
+
+
+def _small(r, plain):
+    """What travels back to the test process: digests for the bit-equality checks, small records, and the distances to the
+    plain run (the flat gradient / parameter buffers themselves are 2 x 163 MB per variant)."""
+    def rel(k):
+        a, b = r[k].astype(np.float64), plain[k].astype(np.float64)
+        return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+    return dict(digest=_digest(r), scale=r['scale'], exS=r['exS'], exD=r['exD'], means=r['means'], losses=r['losses'],
+                syncbn_allreduces=r['syncbn_allreduces'], rel={k: rel(k) for k in ('gS', 'gD')}, rm=r['rm'])
+
+
+def _worker(port, q, variants):
     import fcd_gan_pytorch_amd as p
     torch.cuda.set_device(0)
     out = {}
-    out['plain'] = _step(False)                                       # no process group at all: the single-GPU product path
+    plain = _step(False)                                              # no process group at all: the single-GPU product path
+    out['plain'] = _small(plain, plain)
     os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
     try:
         out['backend'] = dist.get_backend()
-        out['idle'] = _step(False)                                    # group exists, one rank, nothing forced: must skip the exchange
+        if 'idle' in variants:
+            out['idle'] = _small(_step(False), plain)                 # group exists, one rank, nothing forced: must skip the exchange
         p.dp.force_exchange(True)
-        out['forced'] = _step(False)                                  # every collective runs, per-replica BatchNorm
-        out['forced_syncbn'] = _step(True)                            # + the SyncBN sums through ncclAllReduce
-        out['forced_graph'] = _step(False, graphed=True)              # the same collectives recorded in a hipGraph and replayed
+        if 'forced' in variants:
+            out['forced'] = _small(_step(False), plain)               # every collective runs, per-replica BatchNorm
+        if 'forced_syncbn' in variants:
+            out['forced_syncbn'] = _small(_step(True), plain)         # + the SyncBN sums through ncclAllReduce
+        if 'forced_graph' in variants:
+            # a GraphedStep under an active exchange must NOT capture (see graph.py: the process group's watchdog thread polls
+            # its events while the stream is capturing and aborts the process on this software stack): it steps launch by launch
+            out['forced_graph'] = _small(_step(False, graphed=True), plain)
         p.dp.force_exchange(False)
     finally:
         dist.destroy_process_group()
     q.put(out)
 
 
-def test_nccl_one_rank_forced_exchange_is_bit_identical():
+def _run_worker(variants):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
-    pr = ctx.Process(target=_worker, args=(port, q))
+    pr = ctx.Process(target=_worker, args=(port, q, variants))
     pr.start()
     import queue as _queue
     import time
@@ -98,6 +118,11 @@ def test_nccl_one_rank_forced_exchange_is_bit_identical():
     pr.join(120)
     assert pr.exitcode == 0
     assert out['backend'] == 'nccl'
+    return out
+
+
+def test_nccl_one_rank_forced_exchange_is_bit_identical():
+    out = _run_worker(('idle', 'forced', 'forced_syncbn', 'forced_graph'))
     plain, idle, forced, fsbn = out['plain'], out['idle'], out['forced'], out['forced_syncbn']
     assert idle['exS'] is None and idle['exD'] is None                # one rank, not forced: no collective was issued
     for r in (forced, fsbn):
@@ -106,18 +131,14 @@ def test_nccl_one_rank_forced_exchange_is_bit_identical():
         assert r['scale'] == (1.0, 1.0)
     print('\n[nccl world 1] S buckets %s, %d launched during backward; D %s' % (forced['exS']['bytes'],
                                                                              forced['exS']['launched_during_backward'], forced['exD']['bytes']))
-    for k in ('gS', 'gD', 'pS', 'pD', 'rm', 'counts', 'losses'):
-        np.testing.assert_array_equal(idle[k], plain[k], err_msg=k)
-        np.testing.assert_array_equal(forced[k], plain[k], err_msg=k)   # the exchange path changes no bit
+    assert idle['digest'] == plain['digest']
+    assert forced['digest'] == plain['digest'], forced['rel']          # the exchange path changes no bit
+    assert out['forced_graph']['digest'] == plain['digest']
     np.testing.assert_allclose(forced['means'], forced['losses'], rtol=1e-6)
-    for k in ('gS', 'gD', 'pS', 'pD', 'rm', 'counts', 'losses'):        # RCCL collectives captured in the step's hipGraph
-        np.testing.assert_array_equal(out['forced_graph'][k], plain[k], err_msg='graph ' + k)
     # SyncBN computes the statistics with the split kernels (partial sums -> all-reduce -> apply): same numbers up to the
     # summation order of the fp64 partials
     for k in ('gS', 'gD'):
-        a, b = fsbn[k].astype(np.float64), plain[k].astype(np.float64)
-        rel = np.linalg.norm(a - b) / np.linalg.norm(b)
-        print('[nccl world 1] SyncBN through ncclAllReduce vs fused per-replica kernels, %s rel-L2 %.2e' % (k, rel))
-        assert rel < 2e-3, (k, rel)
+        print('[nccl world 1] SyncBN through ncclAllReduce vs fused per-replica kernels, %s rel-L2 %.2e' % (k, fsbn['rel'][k]))
+        assert fsbn['rel'][k] < 2e-3, (k, fsbn['rel'][k])
     np.testing.assert_allclose(fsbn['rm'], plain['rm'], rtol=1e-5, atol=1e-7)
     assert fsbn['syncbn_allreduces'] > forced['syncbn_allreduces'] == 0      # the SyncBN sums really went through the process group
