@@ -73,6 +73,11 @@ def ms_ssim(X, Y, data_range=1.0, size_average=True, win_size=11, win_sigma=1.5,
 
 # --------------------------------------------------------------- perception
 TAP_ORDER = (29, 22, 15, 8, 3)     # Loss.py:30
+# Test-infrastructure switch: run the per-band VGG passes of Loss.py:50-60 as ONE batch of C x N band images instead of C
+# sequential passes of N.  Every band is an independent sample, and sum_b mse(fx_b, fy_b) / C over equally sized tensors is the mse
+# over their concatenation, so the value and gradients are the same function; only the fp64 TRUTH runs of the full-size tests
+# switch it on (torch's double-precision CPU convolution parallelises over the batch only: 2 of 16 cores busy otherwise).
+BATCH_BANDS = False
 
 
 def perception(vgg_sd, target, generated, cmask, feature_layer=1, per_band=False, prefix=''):
@@ -85,6 +90,15 @@ def perception(vgg_sd, target, generated, cmask, feature_layer=1, per_band=False
         m = 1 - cmask.repeat((1, 3, 1, 1))
         fx = nets.vgg_features(vgg_sd, target[:, 0:3] * m, taps, prefix)
         fy = nets.vgg_features(vgg_sd, generated[:, 0:3] * m, taps, prefix)
+        for i in sorted(taps):
+            total = total + F.mse_loss(fx[i], fy[i]) / nl
+    elif BATCH_BANDS:
+        n, C, H, W = target.shape
+        keep = 1 - cmask
+        xb = (target * keep).reshape(n * C, 1, H, W).repeat((1, 3, 1, 1))
+        yb = (generated * keep).reshape(n * C, 1, H, W).repeat((1, 3, 1, 1))
+        fx = nets.vgg_features(vgg_sd, xb, taps, prefix)
+        fy = nets.vgg_features(vgg_sd, yb, taps, prefix)
         for i in sorted(taps):
             total = total + F.mse_loss(fx[i], fy[i]) / nl
     else:

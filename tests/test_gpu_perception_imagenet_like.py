@@ -42,8 +42,9 @@ def _rel(a, b):
 
 
 def _oracle(vgg, t, g, cmask, dtype):
-    prev = torch.get_default_dtype()
+    prev, prev_bb = torch.get_default_dtype(), olosses.BATCH_BANDS
     torch.set_default_dtype(dtype)
+    olosses.BATCH_BANDS = dtype == torch.float64      # the fp64 truth: bands as one batch (same function, ~3x less wall time)
     try:
         sd = {k: v.to(dtype) for k, v in vgg.items()}
         gr, cr = g.to(dtype).clone().requires_grad_(True), cmask.to(dtype).clone().requires_grad_(True)
@@ -56,6 +57,7 @@ def _oracle(vgg, t, g, cmask, dtype):
         return dict(loss=loss.detach(), dg=gr.grad, dc=cr.grad, feat=torch.cat(f, 0))
     finally:
         torch.set_default_dtype(prev)
+        olosses.BATCH_BANDS = prev_bb
 
 
 def test_perception_chain_on_imagenet_like_statistics(conv_path):
