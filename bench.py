@@ -573,10 +573,14 @@ def main():
                             'otherwise traffic is null'}
                 alg = {'wino_gemm': wgemm['bytes'] / max(wgemm['launches'], 1),
                        'wino_gemm_split': wsplit['bytes'] / max(wsplit['launches'], 1),
+                       'conv_wino2': (w2f['bytes'] + w2d['bytes']) / max(w2f['launches'] + w2d['launches'], 1),
+                       'conv_wgrad': (wg['bytes'] - wgw_['bytes']) / max(wg['launches'] - wgw_['launches'], 1),
                        'conv_igemm': (fwd['bytes'] + dg['bytes']) / max(fwd['launches'] + dg['launches'], 1)}
                 for e in cands:
                     key = ('wino_gemm_split' if e['kernel'].startswith('wino_gemm_split') else
                            'wino_gemm' if e['kernel'].startswith('wino_gemm') else
+                           'conv_wino2' if e['kernel'].startswith('conv_wino2') else
+                           'conv_wgrad' if e['kernel'].startswith('weight gradient') else
                            'conv_igemm' if e['kernel'].startswith('conv_igemm') else None)
                     if key:
                         e['algorithmic_bytes_per_launch'] = alg[key]

@@ -42,6 +42,20 @@ int fcd_wino_mode_now();   // conv_wino.hip: 0 = direct kernels only (tests' A/B
 #ifndef W2_DEEP
 #define W2_DEEP 1
 #endif
+// W2_TIME: attribution build (tools/w2_segments.py): every wave stamps s_memtime at the segment borders of its
+// stage loop and writes the per-segment cycle sums {prologue, issue (filter DMA + patch loads), operands + transforms + MFMA issue,
+// LDS commit of the next patch (waits for its global loads), barrier, epilogue, total} to a debug buffer.  Results stay correct;
+// the stamps cost ~10 % (each waits for the wave's outstanding LDS reads).  Never defined in the product build.
+#ifndef W2_TIME
+#define W2_TIME 0
+#endif
+#if W2_TIME
+#define W2_T(var) const unsigned long long var = __builtin_readcyclecounter();
+#define W2_TACC(slot, t1, t0) tacc[slot] += (t1) - (t0);
+#else
+#define W2_T(var)
+#define W2_TACC(slot, t1, t0)
+#endif
 namespace {
 constexpr int W2_ROWS = 64;                 // GEMM rows per workgroup (all of them)
 constexpr int W2_LP = 12;                   // floats per lane row in the filter slab: the ROW-transformed filter G g (4 x 3),
@@ -80,6 +94,7 @@ struct Wino2Args {
   float slope_imm;
   int relu, act_slope;
   int N, C, H, W, K, Hp, Wp, nchunks, tiles_p, tiles_q, xcd_remap;
+  unsigned long long* tbuf;   // W2_TIME builds: [workgroup][wave][8] cycle sums
 };
 
 // Row-transformed filters G g (4 x 3 per (row, channel)), G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]: 12 floats instead of the 16
@@ -140,6 +155,10 @@ __global__ __launch_bounds__(64 * NW) void conv_wino2_kernel(Wino2Args a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = wave & 3, hrow = wave >> 2;
   const int ln = lane & 15, kc = lane >> 4;
+#if W2_TIME
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  W2_T(t_begin)
 
   unsigned v;
   {
@@ -248,11 +267,13 @@ __global__ __launch_bounds__(64 * NW) void conv_wino2_kernel(Wino2Args a) {
     const int cch = (CH);                                                                             \
     const bool have_next = cch + 1 < a.nchunks;                                                       \
     const int xb = (W2_EXP & 64) ? 0 : (cch & 1);                                                     \
+    W2_T(ts0)                                                                                         \
     if (have_next && !(W2_EXP & 1)) {                                                                \
       W2_DMA(cch + 1, UNXT)                                                                           \
       if (!DEEP) W2_LOAD_X(cch + 1, XNEXT)                                                            \
     }                                                                                                \
     if (DEEP && cch + 2 < a.nchunks) W2_LOAD_X(cch + 2, XFAR)                                         \
+    W2_T(ts1)                                                                                         \
     const float* xl = sx + xb * XS_SZ;                                                               \
     _Pragma("unroll") for (int ks = 0; ks < W2_KS; ++ks) {                                           \
     float av[16];                                                                                    \
@@ -305,8 +326,12 @@ __global__ __launch_bounds__(64 * NW) void conv_wino2_kernel(Wino2Args a) {
       }                                                                                              \
     }                                                                                                \
     }                                                                                                \
+    W2_T(ts2)                                                                                         \
     if (have_next && !(W2_EXP & 1)) W2_STORE_X(((W2_EXP & 64) ? 0 : (xb ^ 1)), cch + 1, XNEXT)        \
+    W2_T(ts3)                                                                                         \
     if (!(W2_EXP & 2)) __syncthreads();                                                                                 \
+    W2_T(ts4)                                                                                         \
+    W2_TACC(1, ts1, ts0) W2_TACC(2, ts2, ts1) W2_TACC(3, ts3, ts2) W2_TACC(4, ts4, ts3)               \
   }
 
   W2_DMA(0, su0)
@@ -314,6 +339,8 @@ __global__ __launch_bounds__(64 * NW) void conv_wino2_kernel(Wino2Args a) {
   if (DEEP && 1 < a.nchunks) W2_LOAD_X(1, xr2)
   W2_STORE_X(0, 0, xr)
   __syncthreads();
+  W2_T(t_loop)
+  W2_TACC(0, t_loop, t_begin)
   // (loop peeled rather than "if (ch + 1 < n) STEP" inside the body: that form was MIScompiled by this toolchain --
   // the second step's contributions vanished -- tools/debug/dbg_wino2*.py)
   {
@@ -338,6 +365,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wino2_kernel(Wino2Args a) {
 #undef W2_DMA
 
   // ---- output transform + epilogue.  Lane: tile column ln, rows 16 g + 4 kc + reg; A^T = [[1,1,1,0],[0,1,-1,-1]]
+  W2_T(t_epi)
   const int P = a.H, Q = a.W;          // stride 1 / pad 1: output extent == input extent
 #pragma unroll
   for (int gr = 0; gr < 2 * PG; ++gr) {
@@ -397,7 +425,21 @@ __global__ __launch_bounds__(64 * NW) void conv_wino2_kernel(Wino2Args a) {
       }
     }
   }
+#if W2_TIME
+  {
+    const unsigned long long t_end = __builtin_readcyclecounter();
+    tacc[5] = t_end - t_epi; tacc[6] = t_end - t_begin; tacc[7] = t_begin;
+    if (a.tbuf && lane == 0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a.tbuf[((size_t)blockIdx.x * NW + wave) * 8 + i] = tacc[i];
+    }
+  }
+#endif
 }
+
+#if W2_TIME
+unsigned long long* g_w2_tbuf = nullptr;
+#endif
 
 int w2_env() {
   static int v = -1;
@@ -459,8 +501,15 @@ static int w2_waves() {     // FCD_WINO2_WAVES = 8 (one 8 x 32 workgroup per CU)
   return v;
 }
 
+#if W2_TIME
+extern "C" void fcd_wino2_time_buf(void* p) { g_w2_tbuf = (unsigned long long*)p; }
+#endif
+
 template <int SRC, int EPI>
 static void w2_launch(Wino2Args& a, int red, hipStream_t st) {
+#if W2_TIME
+  a.tbuf = g_w2_tbuf;
+#endif
   a.tiles_q = cdiv(a.W, W2_TW);
   a.xcd_remap = w2_xcd();
   static int ks = -1;

@@ -44,6 +44,10 @@ FAM = {
     'wino_gemm_split': (['wino_gemm_split'], F_DMA, W_B128, 'bf16 planes of U and fp32 V by global_load_lds 16 B/lane; C tile by dword stores'),
     'wino_input_transform': (['wino_input_kernel', 'wino_input_roll_kernel', 'wino_wg_input_kernel', 'wino_wg_dy_kernel'], F_B128, W_B32, 'float4 row reads; V rows as 128 B dword-store segments'),
     'wino_output_transform': (['wino_output_kernel', 'wino_output_blk_kernel'], F_B32, W_B128, 'coalesced dword reads of M; float4 row stores'),
+    'conv_wino2': (['conv_wino2_kernel'], F_B32, W_B32, 'fused F(2x2) kernel: dword patch loads (8 x 32 pixel blocks + halo), filter slabs by LDS-DMA (L2-resident), '
+                   'dword / 8-B output stores'),
+    'conv_wgrad': (['conv_wgrad_kernel', 'conv_wgrad_roll_kernel', 'conv_wgrad_thin_kernel', 'nchw_to_nhwc', 'wgrad_reduce'], F_DMA, W_B32,
+                   'direct weight-gradient kernels incl. their re-layout and split-K reduce passes'),
     'conv_igemm': (['conv_igemm_kernel', 'conv_igemm_glds_kernel', 'conv3x3_fwd_thin', 'conv3x3_dgrad_thin'], F_B32, W_B32, 'dword patch loads (+ small L2-resident filter slabs by LDS-DMA); dword stores'),
 }
 out = {'source': 'tools/pmc_hbm.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over tools/hbm_calib.bin '
