@@ -50,7 +50,9 @@ int fcd_wino_mode_now();   // conv_wino.hip: 0 = direct kernels only (tests' A/B
 #define W2_TIME 0
 #endif
 #if W2_TIME
-#define W2_T(var) const unsigned long long var = __builtin_readcyclecounter();
+// (scheduling barriers on both sides: the stamp is a scalar instruction with no dependences, and without them the compiler
+//  floats it 25 MFMAs up into the block it is meant to close)
+#define W2_T(var) __builtin_amdgcn_sched_barrier(0); const unsigned long long var = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0);
 #define W2_TACC(slot, t1, t0) tacc[slot] += (t1) - (t0);
 #else
 #define W2_T(var)
@@ -191,31 +193,44 @@ __global__ __launch_bounds__(64 * NW) void conv_wino2_kernel(Wino2Args a) {
 
   // DEEP [r3]: plain sources keep TWO chunks of patch loads in flight (the chunk two stages ahead is requested while the next
   // one is still on its way): a stage lasts ~3.6 us, an HBM round trip under load is not much shorter.  Costs X_PER_T registers.
-  constexpr bool DEEP = (SRC == 0) && (W2_DEEP != 0);
-  float xr[X_PER_T], xr2[DEEP ? X_PER_T : 1], mr[X_PER_T];
-  unsigned mcode[X_PER_T], x_want[X_PER_T], x_boff[X_PER_T];
-  // per staged element: byte offset in the source chunk + ONE packed word {LDS offset of the .x copy : 16, channel : 4,
-  // .x copy exists : 1, .y copy exists : 1} -- staging registers are what pushes this kernel against the 256-VGPR limit
-  unsigned x_pk[X_PER_T];
+  // [r4] The pooled-gradient source (SRC == 2) stages UNIQUE pooled elements: the 10 x 34 patch of a channel is the 2 x 2
+  // expansion of 6 x 18 pooled gradients, and the element-per-patch-position staging loaded each of them (and its argmax code)
+  // four times -- 12 loads + 30 staging registers per thread and stage, requested in the stage that consumes them (the s_memtime
+  // attribution, profiles/r04_w2_segments.md: 18 % of a wave's life issuing them, 17 % waiting for them at the LDS commit).  Now a
+  // thread loads L_PER_T = 2 pooled gradients + codes and routes each into its window's four patch positions at commit time;
+  // that fits two chunks in flight (DEEP) like the plain source.
+  constexpr int PPH = W2_PH / 2 + 1, PPW = W2_PW / 2 + 1;           // pooled rows / columns under the patch (6 x 18)
+  constexpr int P_ELEMS = W2_CB * PPH * PPW;
+  constexpr int L_PER_T = (SRC == 2) ? (P_ELEMS + NT - 1) / NT : X_PER_T;
+  constexpr int L_ELEMS = (SRC == 2) ? P_ELEMS : X_ELEMS;
+  constexpr bool DEEP = (SRC == 0 || SRC == 2) && (W2_DEEP != 0);
+  float xr[L_PER_T], xr2[DEEP ? L_PER_T : 1], mr[SRC == 1 ? L_PER_T : 1];
+  unsigned xr_c[SRC == 2 ? L_PER_T : 1], xr2_c[SRC == 2 ? L_PER_T : 1], x_boff[L_PER_T];
+  // per staged element: byte offset in the source chunk + ONE packed word.  Patch-position staging: {LDS offset of the .x copy
+  // : 16, channel : 4, .x copy exists : 1, .y copy exists : 1}; pooled staging: {LDS offset of patch position (2a, 2b) : 16,
+  // channel : 4, pooled row a : 3, pooled column b : 5} -- staging registers are what pushes this kernel against the 256-VGPR limit
+  unsigned x_pk[L_PER_T];
   const int ih0 = p0 - 1, iw0 = q0 - 1;
 #pragma unroll
-  for (int i = 0; i < X_PER_T; ++i) {
+  for (int i = 0; i < L_PER_T; ++i) {
     const int idx = tid + i * NT;
-    const int cc = idx / (W2_PH * W2_PW), rem = idx % (W2_PH * W2_PW);
-    const int ph = rem / W2_PW, pw = rem % W2_PW;
-    const int ih = ih0 + ph, iw = iw0 + pw;
-    bool ok = idx < X_ELEMS && ih >= 0 && iw >= 0 && ih < a.H && iw < a.W;
-    int goff = (cc * a.H + ih) * a.W + iw;
-    const unsigned lo = (unsigned)(cc * W2_PL + ph * W2_RP + 2 * pw);       // .y copy lives at lo - 2 * W2_RP + 1
-    x_want[i] = 0;
     if (SRC == 2) {
-      const int hp = ih >> 1, wq = iw >> 1;
-      if (hp >= a.Hp || wq >= a.Wp) ok = false;
-      goff = (cc * a.Hp + hp) * a.Wp + wq;
-      x_want[i] = (unsigned)((((ih & 1) << 1) | (iw & 1)) | 4);
+      const int cc = idx / (PPH * PPW), rem = idx % (PPH * PPW);
+      const int pa = rem / PPW, pb = rem % PPW;
+      const int hp = (ih0 >> 1) + pa, wq = (iw0 >> 1) + pb;         // ih0, iw0 are odd (or -1): patch rows 2 pa - 1, 2 pa belong to hp
+      const bool ok = idx < P_ELEMS && hp >= 0 && wq >= 0 && hp < a.Hp && wq < a.Wp;
+      const unsigned lo = (unsigned)((cc < W2_CB ? cc : 0) * W2_PL + (2 * pa) * W2_RP + 2 * (2 * pb));
+      x_pk[i] = lo | ((ok ? (unsigned)cc : 15u) << 16) | ((unsigned)pa << 20) | ((unsigned)pb << 23);
+      x_boff[i] = ok ? (unsigned)((cc * a.Hp + hp) * a.Wp + wq) * 4u : 0u;
+    } else {
+      const int cc = idx / (W2_PH * W2_PW), rem = idx % (W2_PH * W2_PW);
+      const int ph = rem / W2_PW, pw = rem % W2_PW;
+      const int ih = ih0 + ph, iw = iw0 + pw;
+      const bool ok = idx < X_ELEMS && ih >= 0 && iw >= 0 && ih < a.H && iw < a.W;
+      const unsigned lo = (unsigned)(cc * W2_PL + ph * W2_RP + 2 * pw);       // .y copy lives at lo - 2 * W2_RP + 1
+      x_pk[i] = lo | ((ok ? (unsigned)cc : 15u) << 16) | ((ph < W2_TH ? 1u : 0u) << 20) | ((ph >= 2 ? 1u : 0u) << 21);
+      x_boff[i] = ok ? (unsigned)((cc * a.H + ih) * a.W + iw) * 4u : 0u;
     }
-    x_pk[i] = lo | ((ok ? (unsigned)cc : 15u) << 16) | ((ph < W2_TH ? 1u : 0u) << 20) | ((ph >= 2 ? 1u : 0u) << 21);
-    x_boff[i] = ok ? (unsigned)goff * 4u : 0u;
   }
   const int in_plane = (SRC == 2) ? a.Hp * a.Wp : a.H * a.W;
   const float* xin = a.x + (size_t)n * a.C * in_plane;
@@ -239,26 +254,42 @@ __global__ __launch_bounds__(64 * NW) void conv_wino2_kernel(Wino2Args a) {
     const char* xsrc = (const char*)(xin + (size_t)(CH) * chunk_elems);                              \
     const char* msrc = (const char*)(min_ + (size_t)(CH) * chunk_elems);                             \
     const unsigned char* csrc = cin_ + (size_t)(CH) * chunk_elems;                                   \
-    _Pragma("unroll") for (int i = 0; i < X_PER_T; ++i) {                                            \
+    _Pragma("unroll") for (int i = 0; i < L_PER_T; ++i) {                                            \
       unsigned off = x_boff[i];                                                                      \
       if (tail) off = ((int)((x_pk[i] >> 16) & 15u) < cleft) ? off : 0u;                             \
       XR[i] = *(const float*)(xsrc + off);                                                           \
       if (SRC == 1) mr[i] = *(const float*)(msrc + off);                                             \
-      if (SRC == 2) mcode[i] = csrc[off >> 2];                                                       \
+      if (SRC == 2) XR##_c[i] = csrc[off >> 2];                                                      \
     }                                                                                                \
   }
 #define W2_STORE_X(BUF, CH, XR)                                                                      \
   {                                                                                                  \
     const int cleft = a.C - (CH) * W2_CB;                                                            \
-    _Pragma("unroll") for (int i = 0; i < X_PER_T; ++i) {                                            \
-      if (tid + i * NT < X_ELEMS) {                                                                  \
+    _Pragma("unroll") for (int i = 0; i < L_PER_T; ++i) {                                            \
+      if (tid + i * NT < L_ELEMS) {                                                                  \
         bool keep = ((x_pk[i] >> 16) & 15u) < (unsigned)min(cleft, 15);                              \
-        if (SRC == 2) keep = keep && mcode[i] == x_want[i];                                          \
         if (SRC == 1) keep = keep && mr[i] > 0.f;                                                    \
         const float xv = keep ? XR[i] : 0.f;                                                         \
         const int lo_ = (int)(x_pk[i] & 0xFFFFu);                                                    \
-        if (x_pk[i] & (1u << 20)) sx[(BUF) * XS_SZ + lo_] = xv;                                      \
-        if (x_pk[i] & (1u << 21)) sx[(BUF) * XS_SZ + lo_ - 2 * W2_RP + 1] = xv;                      \
+        if (SRC == 2) {                                                                              \
+          /* pooled gradient xv of window (pa, pb): patch rows 2 pa - 1 + dy, columns 2 pb - 1 + dx; the argmax code names */ \
+          /* the one position that receives it, the other three get zeros (every patch position is written: no stale data) */ \
+          const int pa_ = (int)((x_pk[i] >> 20) & 7u), pb_ = (int)((x_pk[i] >> 23) & 31u);           \
+          const unsigned code_ = XR##_c[i];                                                          \
+          _Pragma("unroll") for (int dy = 0; dy < 2; ++dy)                                           \
+            _Pragma("unroll") for (int dx = 0; dx < 2; ++dx) {                                       \
+              const int ph_ = 2 * pa_ - 1 + dy, pw_ = 2 * pb_ - 1 + dx;                              \
+              if (ph_ >= 0 && ph_ < W2_PH && pw_ >= 0 && pw_ < W2_PW) {                              \
+                const float v_ = (code_ == (unsigned)((dy << 1) | dx | 4)) ? xv : 0.f;               \
+                const int at_ = lo_ + (dy - 1) * W2_RP + 2 * (dx - 1);                               \
+                if (ph_ < W2_TH) sx[(BUF) * XS_SZ + at_] = v_;                                       \
+                if (ph_ >= 2) sx[(BUF) * XS_SZ + at_ - 2 * W2_RP + 1] = v_;                          \
+              }                                                                                      \
+            }                                                                                        \
+        } else {                                                                                     \
+          if (x_pk[i] & (1u << 20)) sx[(BUF) * XS_SZ + lo_] = xv;                                    \
+          if (x_pk[i] & (1u << 21)) sx[(BUF) * XS_SZ + lo_ - 2 * W2_RP + 1] = xv;                    \
+        }                                                                                            \
       }                                                                                              \
     }                                                                                                \
   }
@@ -329,7 +360,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wino2_kernel(Wino2Args a) {
     W2_T(ts2)                                                                                         \
     if (have_next && !(W2_EXP & 1)) W2_STORE_X(((W2_EXP & 64) ? 0 : (xb ^ 1)), cch + 1, XNEXT)        \
     W2_T(ts3)                                                                                         \
-    if (!(W2_EXP & 2)) __syncthreads();                                                                                 \
+    if (!(W2_EXP & 2)) __syncthreads();     /* (a hand-written `s_waitcnt vmcnt(X_PER_T)` + s_barrier that keeps the DEEP loads in flight makes LLVM's waitcnt pass put a vmcnt(0) right behind the next stage's loads: measured on the ISA, not kept) */ \
     W2_T(ts4)                                                                                         \
     W2_TACC(1, ts1, ts0) W2_TACC(2, ts2, ts1) W2_TACC(3, ts3, ts2) W2_TACC(4, ts4, ts3)               \
   }
