@@ -307,6 +307,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wino2_kernel(Wino2Args a) {
     W2_T(ts1)                                                                                         \
     const float* xl = sx + xb * XS_SZ;                                                               \
     _Pragma("unroll") for (int ks = 0; ks < W2_KS; ++ks) {                                           \
+    if (W2_KS == 3 && ks > 0 && cch * W2_CB + ks * 4 >= a.C) continue;   /* 12-channel stages: the last one may hold 4 or 8 */ \
     float av[16];                                                                                    \
     {                                                                                                \
       const float* up = (UCUR) + ks * W2_SLAB + aoff;                                                \
@@ -499,7 +500,7 @@ extern "C" int fcd_conv_wino2_plan(const fcd_conv_desc* d, int mode) {
 
 extern "C" int64_t fcd_conv_wino2_filter_elems(int K, int C, int mode) {
   const int red = mode == 0 ? C : K;
-  return (int64_t)round_up(cdiv(red, 4), 2) * W2_SLAB;     // whole 8-channel stages: the tail chunk is zero-filled by the packer
+  return (int64_t)round_up(cdiv(red, 4), 6) * W2_SLAB;     // whole 8- or 12-channel stages: the tail chunks are zero-filled by the packer
 }
 
 extern "C" int fcd_conv_wino2_pack(const float* w, float* U, int K, int C, int mode, void* stream) {
@@ -546,12 +547,16 @@ static void w2_launch(Wino2Args& a, int red, hipStream_t st) {
   static int ks = -1;
   if (ks < 0) {
     const char* e = getenv("FCD_WINO2_KS");
-    ks = (e && atoi(e) == 1) ? 1 : 2;
+    ks = (e && atoi(e) == 1) ? 1 : ((e && atoi(e) == 3) ? 3 : 2);
   }
   if (w2_waves() == 1) {          // one wave per SIMD: 4 waves x 4 tile rows, 512-register budget (accumulators in AGPRs)
     a.tiles_p = cdiv(a.H, 8);
     a.nchunks = cdiv(red, 8);
     hipLaunchKernelGGL((conv_wino2_kernel<SRC, EPI, 4, 2, 2>), dim3((unsigned)(a.N * a.tiles_p * a.tiles_q)), dim3(256), 0, st, a);
+  } else if (w2_waves() == 8 && ks == 3) {      // 12-channel stages: 145 KB of LDS, 6 instead of 8 barriers per 64 channels
+    a.tiles_p = cdiv(a.H, 8);
+    a.nchunks = cdiv(red, 12);
+    hipLaunchKernelGGL((conv_wino2_kernel<SRC, EPI, 8, 3, 1>), dim3((unsigned)(a.N * a.tiles_p * a.tiles_q)), dim3(512), 0, st, a);
   } else if (w2_waves() == 8 && ks == 2) {
     a.tiles_p = cdiv(a.H, 8);
     a.nchunks = cdiv(red, 8);

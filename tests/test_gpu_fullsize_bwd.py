@@ -72,7 +72,11 @@ LIMITS = {
 # see the table there; K = 2 on the direct plan, and on the Winograd plan K = 2 for everything but the tensors listed
 # with their measured ratios in that file (F(4x4) transforms carry ~1e-5 rounding per layer vs ~1e-6 direct).
 K_TRUTH = {'direct': dict(k_flat=2.0, k_tensor=3.0, floor_flat=2e-4, floor_tensor=5e-4),
-           'winograd': dict(k_flat=6.0, k_tensor=10.0, floor_flat=2e-4, floor_tensor=5e-4)}
+           'winograd': dict(k_flat=6.0, k_tensor=10.0, floor_flat=2e-4, floor_tensor=5e-4),
+           # per net where the measured ratio leaves room (~1.5x the measurement, so that a regression in the blocked-M /
+           # transposed-B GEMM / BatchNorm-statistics kernels cannot hide in the Generator step's slack): Segmentor on the Winograd
+           # plan measured 1.9 - 2.0 flat, 3.1 worst tensor
+           ('winograd', 'S'): dict(k_flat=3.0, k_tensor=5.0, floor_flat=2e-4, floor_tensor=5e-4)}
 # (Winograd plan, measured: the generator's gradient through the 13 F(4x4) VGG layers of the perception term ends 4.4x
 #  (flat) / 8.1x (worst tensor) as far from the fp64 truth as stock fp32 -- 1.5e-3 / 2.5e-3 absolute; the Segmentor 1.9x /
 #  3.1x.  Direct plan: 1.0 - 1.5x flat, <= 2.5x per tensor.)
@@ -205,7 +209,7 @@ def check_net(tag, which, net, opt_kind, lr, store, oracle_grads, oracle_sd, tru
     rep = {}
     # (a) gradients against the fp64 truth, next to the fp32 oracle's own distance to it
     # truth_own = (G64(forward state of the HIP path), G64(forward state of the fp32 oracle)): see the module docstring
-    kt = K_TRUTH[plan]
+    kt = K_TRUTH.get((plan, which), K_TRUTH[plan])
     g64_full = torch.cat([truth[k].reshape(-1) for k, _, _, _ in slices])
     n64 = cat(g64_full).double().norm().item()
     if truth_own is not None:

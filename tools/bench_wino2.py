@@ -61,7 +61,7 @@ def main():
             t1 = timeit(lambda: check(lib.fcd_conv2d_bwd_data(ctypes.byref(d), ops._p(dy), ops._p(y), ops._p(wp), ops._p(dx), s)))
             err = (d2 - dx).abs().max().item() / max(dx.abs().max().item(), 1e-30)
             line += ' gated dgrad: fused %.3f ms (%.0f TF alg) direct %.3f ms (%.0f TF)  rel diff %.1e' % (t2, fl / t2 / 1e9, t1, fl / t1 / 1e9, err)
-        if lib.fcd_conv_wino2_plan(ctypes.byref(d), 1) and HW % 2 == 0:
+        if lib.fcd_conv_wino2_plan(ctypes.byref(d), 1) and lib.fcd_conv_wino2_plan(ctypes.byref(d), 0) and HW % 2 == 0:
             # the pooled data gradient (VGG conv1_2: gradient arrives on the max-pooled map + argmax codes)
             py = torch.empty(N, K, HW // 2, HW // 2, device='cuda')
             code = torch.empty(N, K, HW // 2, HW // 2, dtype=torch.uint8, device='cuda')

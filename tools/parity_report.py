@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """profiles/rNN_parity_fullsize.md from the reports the GPU parity tests leave in gpurun_out/
-(parity_fullsize_bwd.json, parity_trajectory_<plan>.json) + the text blocks passed on the command line."""
+(parity_fullsize_bwd.json, parity_trajectory_<plan>.json, parity_perception_imagenet_like_<plan>.json) + an optional markdown
+file appended as it is (the pooled-vs-difference probe, tools/parity_probe_d.py --md).
+usage: parity_report.py [gpurun_out] [extra.md] > profiles/r04_parity_fullsize.md"""
 import json
 import os
 import sys
@@ -8,7 +10,8 @@ import sys
 src = sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out'
 extra = sys.argv[2] if len(sys.argv) > 2 else None
 r = json.load(open(os.path.join(src, 'parity_fullsize_bwd.json')))
-L = ['# Full-size backward parity against an fp64 truth (round 3)', '',
+dist = r.pop('d_step_error_distribution_16_maps', None)
+L = ['# Full-size backward parity against an fp64 truth (round 4)', '',
      '`tests/test_gpu_fullsize_bwd.py` on MI355X: one whole train iteration of each demo on the HIP path; next to it the CPU oracle step',
      '(`oracle/steps.py`, stock fp32 PyTorch, literal reference order) and THE SAME oracle step in double precision.  Every gradient is compared',
      'exactly as its optimizer sees it (pre-step hook).  `HIP` / `oracle32` = relative L2 distance to the fp64 gradient.', '',
@@ -23,10 +26,10 @@ for tag in sorted(r):
             tag, w, v['flat_rel_l2_vs_fp64'], v['flat_rel_l2_oracle32_vs_fp64'], v['flat_rel_l2_vs_fp64'] / v['flat_rel_l2_oracle32_vs_fp64'],
             v['worst_tensor_over_rule'], v['worst_tensor'], v['worst_tensor_rel_l2_vs_fp64'], v['worst_tensor_oracle32_vs_fp64'],
             v['worst_error_ratio_above_floor'], v['worst_error_ratio_tensor'], v['worst_update_rel_l2'], v['bn_running_rel_err']))
-L += ['', 'K (flat / per tensor): direct plan 2 / 3, Winograd plan 6 / 10; floors 2e-4 / 5e-4 of the gradient norm (`K_TRUTH`).  The Winograd plan is',
-      'further from the truth than stock fp32 where a gradient runs through many F(4x4,3x3) layers (the Generator step: 13 VGG layers of the',
-      'perception term) -- the transforms round ~10x coarser than a direct fp32 convolution (1.4e-5 vs 1e-6 of a layer output).', '',
-      '## Discriminator: against the fp64 D-step evaluated on the map each path produced, absolute bound', '',
+L += ['', 'K (flat / per tensor, `K_TRUTH`): direct plan 2 / 3; Winograd plan: Segmentor 3 / 5, Generator step 6 / 10; floors 2e-4 / 5e-4 of the gradient norm.',
+      'The Winograd plan is further from the truth than stock fp32 where a gradient runs through many F(4x4,3x3) layers (the Generator step: 13 VGG layers',
+      'of the perception term) -- the transforms round ~10x coarser than a direct fp32 convolution (1.4e-5 vs 1e-6 of a layer output).', '',
+      '## Discriminator: one draw, against the fp64 D-step evaluated on the map each path produced', '',
       '| case | HIP vs G64_D(cmap_HIP) flat | oracle32 vs G64_D(cmap_oracle32) flat | worst tensor HIP / oracle32 | end to end: HIP | end to end: oracle32 | map deviation HIP vs fp64 | moves G64_D by | amplification |',
       '|---|---|---|---|---|---|---|---|---|']
 for tag in sorted(r):
@@ -38,9 +41,47 @@ for tag in sorted(r):
             tag, v['flat_rel_l2_vs_fp64'], v['flat_rel_l2_oracle32_vs_fp64'], v['worst_tensor'], v['worst_tensor_rel_l2_vs_fp64'],
             v['worst_tensor_oracle32_vs_fp64'], v['e2e_flat_rel_l2_vs_fp64'], v['e2e_flat_rel_l2_oracle32_vs_fp64'],
             a.get('map_dev', float('nan')), a.get('grad_rel_change', float('nan')), a.get('amplification', float('nan'))))
-L += ['', 'Bound: 2e-2 flat, 3e-2 per tensor (`HIP_D_LIMITS`).  Why not a ratio: see the probe below.', '']
+L += ['', 'A single draw is held to 1.5x (flat) / 2.5x (per tensor) the largest single-decision jump the fp32 CPU oracle itself shows in the distribution below',
+      '(`HIP_D_LIMITS` = 1.6e-2 / 2.6e-2, was an unexplained 2e-2 / 3e-2); comparing the two implementations is the distribution test\'s job.', '']
+if dist:
+    L += ['## Discriminator-step gradient: error DISTRIBUTION over 16 density maps (`test_discriminator_step_gradient_error_distribution`)', '',
+          'Demo_RSSS D step, 13 bands 256x256, 2 pairs; maps differ by <= 3e-5 (both HIP plans\' maps, 1e-5 noise draws, constant offsets); relative L2',
+          'distance of the whole D gradient to the fp64 gradient evaluated on the same map.  Each fp32 evaluation is either at rounding level (~3e-6) or one',
+          'activation decision away (2e-4 ... 1e-2) -- for stock fp32 PyTorch and the HIP kernels alike.', '',
+          '| | fp32 CPU oracle | HIP | rule |', '|---|---|---|---|',
+          '| best draw (floor) | %.2e | %.2e | HIP <= 2x + 1e-6 |' % (dist['oracle32_min'], dist['hip_min']),
+          '| median | %.2e | %.2e | HIP <= 2x + 1e-5 |' % (dist['oracle32_median'], dist['hip_median']),
+          '| geometric mean | %.2e | %.2e | HIP <= 4x |' % (dist['oracle32_geomean'], dist['hip_geomean']),
+          '| max | %.2e | %.2e | HIP <= 2x |' % (dist['oracle32_max'], dist['hip_max']),
+          '| maps with a discrete jump (error > 1e-4) | %d / 16 | %d / 16 | HIP <= oracle + 4 |' % (dist['oracle32_jumps'], dist['hip_jumps']), '',
+          'per map (HIP / oracle32): ' + ', '.join('%.1e / %.1e' % (h, o) for h, o in zip(dist['hip'], dist['oracle32'])), '']
 if extra and os.path.exists(extra):
-    L += open(extra).read().splitlines() + ['']
+    L += ['## Pooled-vs-difference A/B of the Discriminator\'s pooled pair difference (VERDICT r3 item 2)', '',
+          'Same protocol with the three ways of forming AdaptiveAvgPool2d(1)(net(x) - net(y)): `pooled` = round 3 (mean of the batch first, difference of two',
+          'rounded means), `diff` = the reference\'s order on ATen fp32 ops, `fused` = `ops.pair_gap_diff` (reference order, fp64 accumulator, one kernel; the',
+          'product).  The order does not move any of the 16 errors in the third digit: the distance to fp64 is decided by activation decisions inside `net`',
+          'and the classifier, not by the pooling arithmetic.  `fused` is kept because it is the reference\'s order and removes the slice / mean / subtract glue.', '']
+    L += [l for l in open(extra).read().splitlines() if not l.startswith('# ')] + ['']
+first = True
+for plan in ('direct', 'winograd'):
+    f = os.path.join(src, 'parity_perception_imagenet_like_%s.json' % plan)
+    if not os.path.exists(f):
+        continue
+    q = json.load(open(f))
+    if first:
+        first = False
+        g = q['activation_growth']
+        L += ['## ImageNet-like VGG statistics (`tests/test_gpu_perception_imagenet_like.py`)', '',
+              'PerceptionLoss at 13 bands x 256 x 256 (26 band images through conv1_1 ... conv5_3) on a seeded VGG16 with Student-t (4 dof) filters, biased biases',
+              'and gains calibrated in fp64 so that the post-ReLU activation rms grows %.1f -> %.0f (peaks %.0f -> %.0f) from conv1_1 to conv5_3; loss value %.1f.'
+              % (g[0]['rms'], g[-1]['rms'], g[0]['peak'], g[-1]['peak'], q['loss_fp64']),
+              'Relative L2 distance to the fp64 CPU oracle, next to the fp32 CPU oracle\'s own:', '',
+              '| plan | quantity | HIP vs fp64 | fp32 oracle vs fp64 | ratio |', '|---|---|---|---|---|']
+    for k, nm in (('feat', 'relu5_3 features (tap 29)'), ('loss', 'loss value'), ('dgen', 'gradient w.r.t. the generated image'),
+                  ('dcmask', 'gradient w.r.t. the change mask')):
+        L.append('| %s | %s | %.2e | %.2e | %.2f |' % (plan, nm, q[k]['hip_vs_fp64'], q[k]['oracle32_vs_fp64'], q[k]['ratio']))
+if not first:
+    L += ['', 'Same single-digit factors as on He-initialised filters: heavy tails and 10^3 activation peaks do not make the F(4x4) transforms fall apart.', '']
 for plan in ('direct', 'winograd'):
     f = os.path.join(src, 'parity_trajectory_%s.json' % plan)
     if not os.path.exists(f):
@@ -48,7 +89,8 @@ for plan in ('direct', 'winograd'):
     rows = json.load(open(f))
     if plan == 'direct':
         L += ['## Six-iteration Demo_RSSS trajectory (reference fixture, LR schedule in the loop): density-map drift from the fp64 trajectory', '',
-              'rule per iteration: drift(HIP, fp64) <= 3 x drift(reference fp32 fixture, fp64) + floor (1e-4 max / 2e-5 mean)', '',
+              'rule per iteration: drift(HIP, fp64) <= 3 x drift(reference fp32 fixture, fp64) + floor (1e-4 max / 2e-5 mean); the fp64 trajectory is the fixture',
+              '`tests/golden/traj64.npz` (CPU oracle in double precision, `gen_traj64.py`)', '',
               '| plan | iteration | HIP vs fp64 (max / mean) | reference fp32 vs fp64 | HIP vs reference fp32 |', '|---|---|---|---|---|']
     for w in rows:
         L.append('| %s | %d | %.1e / %.1e | %.1e / %.1e | %.1e / %.1e |' % ((plan, w['it']) + tuple(w['hip_vs_fp64']) + tuple(w['ref32_vs_fp64']) + tuple(w['hip_vs_ref32'])))
