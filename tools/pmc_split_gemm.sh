@@ -23,6 +23,14 @@ for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
             # one row per (kernel, grid): the three layers launch different grids
             k = '%s grid=%s' % (m.group(1), r.get('Grid_Size', r.get('Grid_Size_X', '?')))
             ctr[k][r['Counter_Name']].append(float(r['Counter_Value']))
+# launch durations of the same run (kernel trace): with GRBM_GUI_ACTIVE they give the shader clock the kernel really ran at
+for f in glob.glob(d + '/**/*kernel_trace.csv', recursive=True):
+    for r in csv.DictReader(open(f)):
+        m = re.search(r'(wino_gemm\w*kernel(?:<[^>]*>)?)', r['Kernel_Name'])
+        if m:
+            k = '%s grid=%s' % (m.group(1), r.get('Grid_Size', r.get('Grid_Size_X', '?')))
+            if k in ctr:
+                ctr[k]['DURATION_NS'].append(float(r['End_Timestamp']) - float(r['Start_Timestamp']))
 for k, cs in sorted(ctr.items()):
     print('FCD_WINO_SPLIT=%s  %s  dispatches %d' % (split, k, max(len(v) for v in cs.values())))
     for c, v in sorted(cs.items()):

@@ -19,6 +19,11 @@ for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
         k = m.group(1) if m else ''
         if k:
             ctr[k][r['Counter_Name']].append(float(r['Counter_Value']))
+for f in glob.glob(d + '/**/*kernel_trace.csv', recursive=True):
+    for r in csv.DictReader(open(f)):
+        m = re.search(r'(conv_wino2_kernel<[^>]*>|conv_igemm_glds_kernel<[^>]*>)', r['Kernel_Name'])
+        if m and m.group(1) in ctr:
+            ctr[m.group(1)]['DURATION_NS'].append(float(r['End_Timestamp']) - float(r['Start_Timestamp']))
 for k, cs in ctr.items():
     print(k, ' dispatches', max(len(v) for v in cs.values()))
     for c, v in sorted(cs.items()):
