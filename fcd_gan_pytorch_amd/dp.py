@@ -8,7 +8,13 @@ across ranks, no data-path collective except the gradient exchange of ``optim`` 
    ``batch_size`` and a shorter last one (the reference has no ``drop_last``).
  * ``ragged='weighted'`` (opt-in): no padded duplicates at all -- the last global batch is dealt out as it is, ranks hold
    ceil / floor(L / world) samples and scale their loss by ``n_local * world / L`` (``scales[i]``, ``steps._backward``), so the
-   averaged gradient is exactly the gradient of the mean over the L samples (the reference's shorter last batch).
+   averaged gradient is exactly the gradient of the mean over the L samples (the reference's shorter last batch) -- exactly for
+   everything but train-mode BatchNorm: with per-replica statistics a rank normalises over its own n_local samples (possibly 1),
+   not over the L of the reference's batch (SyncBN removes that difference).  A rank left without a sample runs one flagged filler
+   tile at loss scale 0: it takes part in every collective, contributes zero gradient as long as the filler's loss is finite (a
+   non-finite loss times 0 is NaN and would reach every rank through the all-reduce -- the same tile would have produced it as a
+   regular sample of another step), and its train-mode BatchNorm layers do see the duplicate once more in their running
+   statistics (as the padded duplicates of ``ragged='pad'`` do).
  * Ragged last batch under DP: every loss is a batch mean, so mean-of-local-gradients equals the global-batch
    gradient only if all ranks hold the same number of samples.  Rule (``ragged='pad'``, default): the last global
    batch is cut into equal local batches of ``ceil(L / world)`` samples; the (< world) missing samples are taken from
