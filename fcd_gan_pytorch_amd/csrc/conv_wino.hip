@@ -1708,6 +1708,15 @@ __device__ __forceinline__ void wino_out_one(const WinoOutArgs& a, const float (
     // the maximum count as tied and the FIRST one takes the gradient, as MaxPool2d does on exact ties
     // (Loss.py:25 -> torchvision vgg16.features[4,9,16,23]); the pooled VALUE is always the maximum.
     const int Pp = a.P >> 1, Qp = a.Q >> 1;
+    // [r4] ... plus a floor from the transform domain: where the products M cancel (flat image regions: zero padding, nodata
+    // areas -- every output of the region is the same small number) the rounding of A^T M A scales with max |M| of the tile, not
+    // with the outputs, and the relative rule alone would break such exact ties at random instead of first-wins
+    float mabs = 0.f;
+#pragma unroll
+    for (int i = 0; i < A; ++i)
+#pragma unroll
+      for (int j = 0; j < A; ++j) mabs = fmaxf(mabs, fabsf(mv[i][j]));
+    const float tie_floor = (MM == 4 ? 4e-6f : 5e-7f) * mabs;
 #pragma unroll
     for (int wi = 0; wi < MM / 2; ++wi)
 #pragma unroll
@@ -1717,7 +1726,7 @@ __device__ __forceinline__ void wino_out_one(const WinoOutArgs& a, const float (
         const float c0 = o[2 * wi][2 * wj], c1 = o[2 * wi][2 * wj + 1], c2 = o[2 * wi + 1][2 * wj],
                     c3 = o[2 * wi + 1][2 * wj + 1];
         const float m = fmaxf(fmaxf(c0, c1), fmaxf(c2, c3));
-        const float tie = (MM == 4 ? 3e-5f : 2e-6f) * fmaxf(fmaxf(fabsf(c0), fabsf(c1)), fmaxf(fabsf(c2), fabsf(c3)));
+        const float tie = (MM == 4 ? 3e-5f : 2e-6f) * fmaxf(fmaxf(fabsf(c0), fabsf(c1)), fmaxf(fabsf(c2), fabsf(c3))) + tie_floor;
         const float mx = m - tie;
         int arg = 3;
         if (c2 >= mx) arg = 2;

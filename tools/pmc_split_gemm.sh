@@ -28,8 +28,16 @@ for f in glob.glob(d + '/**/*kernel_trace.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         m = re.search(r'(wino_gemm\w*kernel(?:<[^>]*>)?)', r['Kernel_Name'])
         if m:
-            k = '%s grid=%s' % (m.group(1), r.get('Grid_Size', r.get('Grid_Size_X', '?')))
-            if k in ctr:
+            # the trace names the grid per dimension (Grid_Size_X/Y/Z or Grid_Size), the counter file as one number
+            if 'Grid_Size' in r:
+                gs = r['Grid_Size']
+            else:
+                gs = str(int(r.get('Grid_Size_X', 1)) * int(r.get('Grid_Size_Y', 1)) * int(r.get('Grid_Size_Z', 1)))
+            k = '%s grid=%s' % (m.group(1), gs)
+            if k not in ctr:          # fall back to the kernel name when there is exactly one grid of it
+                cand = [q for q in ctr if q.startswith(m.group(1) + ' grid=')]
+                k = cand[0] if len(cand) == 1 else None
+            if k:
                 ctr[k]['DURATION_NS'].append(float(r['End_Timestamp']) - float(r['Start_Timestamp']))
 for k, cs in sorted(ctr.items()):
     print('FCD_WINO_SPLIT=%s  %s  dispatches %d' % (split, k, max(len(v) for v in cs.values())))
