@@ -15,7 +15,7 @@ agg = collections.defaultdict(lambda: [0, 0.0])
 for r in csv.DictReader(open(d + '/pmc_counter_collection.csv')):
     if r['Counter_Name'] != ctr:
         continue
-    k = r['Kernel_Name'].split('(')[0][:90]
+    k = r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0][:90]
     agg[k][0] += 1
     agg[k][1] += float(r['Counter_Value'])
 json.dump({k: {'dispatches': v[0], ctr + '_KiB_total': v[1]} for k, v in agg.items()}, open(d + '/agg.json', 'w'), indent=1)

@@ -16,7 +16,7 @@ for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         if r['Counter_Name'] != ctr:
             continue
-        k = r['Kernel_Name'].split('(')[0][:100]
+        k = r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0][:100]
         agg[k][0] += 1
         agg[k][1] += float(r['Counter_Value'])
 json.dump({k: {'dispatches': v[0], ctr: v[1]} for k, v in agg.items()}, open(d + '/agg.json', 'w'), indent=1)
