@@ -60,7 +60,8 @@ if extra and os.path.exists(extra):
           'Same protocol with the three ways of forming AdaptiveAvgPool2d(1)(net(x) - net(y)): `pooled` = round 3 (mean of the batch first, difference of two',
           'rounded means), `diff` = the reference\'s order on ATen fp32 ops, `fused` = `ops.pair_gap_diff` (reference order, fp64 accumulator, one kernel; the',
           'product).  The order does not move any of the 16 errors in the third digit: the distance to fp64 is decided by activation decisions inside `net`',
-          'and the classifier, not by the pooling arithmetic.  `fused` is kept because it is the reference\'s order and removes the slice / mean / subtract glue.', '']
+          'and the classifier, not by the pooling arithmetic.  `fused` is kept because it is the reference\'s order and removes the slice / mean / subtract glue.',
+          '(Probe taken before the F(4x4) interpolation points changed; the distribution table above is from the final build.)', '']
     L += [l for l in open(extra).read().splitlines() if not l.startswith('# ')] + ['']
 first = True
 for plan in ('direct', 'winograd'):

@@ -55,9 +55,10 @@ def main():
             ctypes.byref(d), ops._p(x), ops._p(U0), ops._p(b), ops._p(y), 1, None, 0.0, None, None, None, s))),
     ]
     L = ['# Fused F(2x2,3x3) kernel: where a wave\'s cycles go (s_memtime stamps, tools/w2_segments.py)', '',
-         'Attribution build (-DW2_TIME=1; the stamps wait for the wave\'s outstanding LDS reads: launch times are ~10 %% above the product build).',
+         'Attribution build (-DW2_TIME=1; the stamps wait for the wave\'s outstanding LDS reads: launch times are a few % above the product build).',
          'VGG conv1_2 geometry: N = %d band images, 64 -> 64 channels, 256 x 256; %d workgroups of 8 waves on 256 CUs (one resident workgroup per CU), '
-         '8 stages of 8 channels per workgroup.  s_memtime runs at 100 MHz: "us" below are wall-clock.' % (N, wgs), '']
+         '8 stages of 8 channels per workgroup.  One counter tick is calibrated against the launch time (workgroups run back to back on a CU); it comes out at the '
+         'shader clock (~0.44 ns).' % (N, wgs), '']
     for tag, fn in runs:
         raw.fcd_wino2_time_buf(ctypes.c_void_p(0))
         fn(); fn()
@@ -70,7 +71,9 @@ def main():
         ms = e0.elapsed_time(e1)
         t = tbuf.cpu().numpy().reshape(wgs, 8, 8).astype(np.float64)
         tot = t[:, :, 6]
-        tick_us = 0.01                                                     # s_memtime counts the 100 MHz reference clock on gfx950
+        # the counter runs at the shader clock here (not at a fixed reference): calibrate one tick against the launch time --
+        # a CU runs its wgs / 256 workgroups back to back, so launch time ~= mean wave life x workgroups per CU
+        tick_us = 1e3 * ms / (tot.mean() * wgs / 256.0)
         seg = t[:, :, :6]
         other = tot - seg.sum(axis=2)
         print('\n%s: launch %.3f ms, mean wave life %.2f us, timer tick %.4f us' % (tag, ms, tot.mean() * tick_us, tick_us))
