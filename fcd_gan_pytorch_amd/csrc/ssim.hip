@@ -15,6 +15,8 @@
 
 struct SsimGeom {
   int H, W, OH, OW, ws, tiles_x, tiles_y;
+  int wsh, wsw;   // taps applied along H / W: ws, or 1 (identity) when that dimension is shorter than the window -- gaussian_filter
+                  // skips the smoothing along such a dimension (reference ssim.py:44-50)
   float C1, C2;
 };
 
@@ -28,14 +30,17 @@ __global__ __launch_bounds__(256) void ssim_stats_kernel(const float* __restrict
                                                          long long map_stride) {
   __shared__ float sx[ST_PH * ST_PW], sy[ST_PH * ST_PW];
   __shared__ float vb[5][ST_TY * ST_PW];
-  __shared__ float wv[ST_WMAX];
+  __shared__ float wvh[ST_WMAX], wvw[ST_WMAX];
   __shared__ double red[16];
   const int tid = threadIdx.x;
   const int nc = blockIdx.z;
   const int oy0 = blockIdx.y * ST_TY, ox0 = blockIdx.x * ST_TX;
-  const int ws = g.ws;
-  const int ph = ST_TY + ws - 1, pw = ST_TX + ws - 1;
-  if (tid < ws) wv[tid] = win[tid];
+  const int wsh = g.wsh, wsw = g.wsw;
+  const int ph = ST_TY + wsh - 1, pw = ST_TX + wsw - 1;
+  if (tid < g.ws) {
+    wvh[tid] = wsh == g.ws ? win[tid] : 1.f;      // (a skipped dimension uses the single tap 1)
+    wvw[tid] = wsw == g.ws ? win[tid] : 1.f;
+  }
   const float* xp = X + (size_t)nc * g.H * g.W;
   const float* yp = Y + (size_t)nc * g.H * g.W;
   for (int i = tid; i < ph * pw; i += 256) {
@@ -54,8 +59,8 @@ __global__ __launch_bounds__(256) void ssim_stats_kernel(const float* __restrict
   for (int i = tid; i < ST_TY * pw; i += 256) {
     const int r = i / pw, c = i % pw;
     float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
-    for (int k = 0; k < ws; ++k) {
-      const float w = wv[k];
+    for (int k = 0; k < wsh; ++k) {
+      const float w = wvh[k];
       const float a = sx[(r + k) * ST_PW + c], b = sy[(r + k) * ST_PW + c];
       m1 = fmaf(w, a, m1);
       m2 = fmaf(w, b, m2);
@@ -85,7 +90,7 @@ __global__ __launch_bounds__(256) void ssim_stats_kernel(const float* __restrict
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
       float acc = 0.f;
-      for (int k = 0; k < ws; ++k) acc = fmaf(wv[k], vb[j][r * ST_PW + c + k], acc);
+      for (int k = 0; k < wsw; ++k) acc = fmaf(wvw[k], vb[j][r * ST_PW + c + k], acc);
       q[j] = acc;
     }
     const float mu1 = q[0], mu2 = q[1];
@@ -144,15 +149,18 @@ __global__ __launch_bounds__(256) void ssim_bwd_apply_kernel(const float* __rest
                                                              float* __restrict__ dX, float* __restrict__ dY) {
   __shared__ float m[4][ST_PH * ST_PW];
   __shared__ float vb[4][ST_TY * ST_PW];
-  __shared__ float wv[ST_WMAX];
+  __shared__ float wvh[ST_WMAX], wvw[ST_WMAX];
   const int tid = threadIdx.x, nc = blockIdx.z;
   const int iy0 = blockIdx.y * ST_TY, ix0 = blockIdx.x * ST_TX;
-  const int ws = g.ws, halo = ws - 1;
-  const int ph = ST_TY + halo, pw = ST_TX + halo;
-  if (tid < ws) wv[tid] = win[ws - 1 - tid];   // transposed taps
+  const int wsh = g.wsh, wsw = g.wsw, halo_h = wsh - 1, halo_w = wsw - 1;
+  const int ph = ST_TY + halo_h, pw = ST_TX + halo_w;
+  if (tid < g.ws) {                               // transposed taps
+    wvh[tid] = wsh == g.ws ? win[g.ws - 1 - tid] : 1.f;
+    wvw[tid] = wsw == g.ws ? win[g.ws - 1 - tid] : 1.f;
+  }
   for (int i = tid; i < ph * pw; i += 256) {
     const int r = i / pw, c = i % pw;
-    const int oy = iy0 - halo + r, ox = ix0 - halo + c;
+    const int oy = iy0 - halo_h + r, ox = ix0 - halo_w + c;
     const bool ok = oy >= 0 && oy < g.OH && ox >= 0 && ox < g.OW;
     const size_t o = ok ? ((size_t)nc * g.OH + oy) * g.OW + ox : 0;
 #pragma unroll
@@ -164,7 +172,7 @@ __global__ __launch_bounds__(256) void ssim_bwd_apply_kernel(const float* __rest
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float acc = 0.f;
-      for (int k = 0; k < ws; ++k) acc = fmaf(wv[k], m[j][(r + k) * ST_PW + c], acc);
+      for (int k = 0; k < wsh; ++k) acc = fmaf(wvh[k], m[j][(r + k) * ST_PW + c], acc);
       vb[j][r * ST_PW + c] = acc;
     }
   }
@@ -177,7 +185,7 @@ __global__ __launch_bounds__(256) void ssim_bwd_apply_kernel(const float* __rest
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float acc = 0.f;
-      for (int k = 0; k < ws; ++k) acc = fmaf(wv[k], vb[j][r * ST_PW + c + k], acc);
+      for (int k = 0; k < wsw; ++k) acc = fmaf(wvw[k], vb[j][r * ST_PW + c + k], acc);
       t[j] = acc;
     }
     const size_t o = ((size_t)nc * g.H + iy) * g.W + ix;
@@ -189,9 +197,11 @@ __global__ __launch_bounds__(256) void ssim_bwd_apply_kernel(const float* __rest
 
 static int make_geom(int H, int W, int win_size, float C1, float C2, SsimGeom* g) {
   if (win_size < 1 || win_size > ST_WMAX || (win_size & 1) == 0) return -1;
-  if (H < win_size || W < win_size) return -1;
+  if (H < 1 || W < 1) return -1;
   g->H = H; g->W = W; g->ws = win_size;
-  g->OH = H - win_size + 1; g->OW = W - win_size + 1;
+  g->wsh = H >= win_size ? win_size : 1;      // gaussian_filter (ssim.py:44-50): no smoothing along a dimension shorter than the window
+  g->wsw = W >= win_size ? win_size : 1;
+  g->OH = H - g->wsh + 1; g->OW = W - g->wsw + 1;
   g->tiles_x = cdiv(g->OW, ST_TX); g->tiles_y = cdiv(g->OH, ST_TY);
   g->C1 = C1; g->C2 = C2;
   return 0;
@@ -209,7 +219,7 @@ extern "C" int fcd_ssim_level_fwd(const float* X, const float* Y, const float* w
   FCD_CHECK_ARG(X && Y && win && out && NC > 0, "fcd_ssim_level_fwd: bad arguments");
   SsimGeom g;
   FCD_CHECK_ARG(make_geom(H, W, win_size, C1, C2, &g) == 0,
-                "fcd_ssim_level_fwd: window %d unsupported for %dx%d (odd, <= 11, <= min(H,W))", win_size, H, W);
+                "fcd_ssim_level_fwd: window %d unsupported for %dx%d (odd, <= 11)", win_size, H, W);
   const size_t need = (size_t)NC * g.tiles_x * g.tiles_y * 2 * sizeof(double);
   if (!ws || ws_bytes < need) {
     fcd_set_error("fcd_ssim_level_fwd: workspace too small");

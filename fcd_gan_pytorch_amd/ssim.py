@@ -9,11 +9,13 @@ kernel.  Only the O(levels*N*C) tail (relu, powers, product, mean) uses torch op
 Deliberate differences from the vendored pytorch-msssim (none is on a demo's path; each RAISES instead of
 silently computing something else):
  * 5-D (N,C,T,H,W) inputs (``conv3d`` branch, ssim.py:120-137,171-186) -> ValueError: 4-d tensors only;
- * ``gaussian_filter``'s "skip a spatial dimension shorter than the window, with a warning" (ssim.py:44-50): the
-   kernel needs H, W >= window size and reports smaller inputs as an error (MS-SSIM's own assert, ssim.py:194-197,
-   already requires min(H, W) > 160 for the default window);
  * windows longer than 11 taps -> error.
+``gaussian_filter``'s "skip a spatial dimension shorter than the window, with a warning" (ssim.py:44-50) is reproduced [r4]: the
+kernel applies the single tap 1 along such a dimension (``ssim`` only -- MS-SSIM's own assert, ssim.py:194-197, requires
+min(H, W) > 160 for the default window).
 """
+import warnings
+
 import torch
 
 from . import _ops as ops
@@ -76,6 +78,9 @@ def ssim(X, Y, data_range=255, size_average=True, win_size=11, win_sigma=1.5, wi
     if not (win_size % 2 == 1):
         raise ValueError("Window size should be odd.")
     taps = _taps_from(win if win is not None else _fspecial_gauss_1d(win_size, win_sigma), X.device)
+    for i, sdim in enumerate(X.shape[2:]):            # the reference's warning, from gaussian_filter (ssim.py:46-50)
+        if sdim < win_size:
+            warnings.warn(f"Skipping Gaussian Smoothing at dimension 2+{i} for input: {X.shape} and win size: {win_size}")
     C1, C2 = _consts(data_range, K)
     per_channel, _ = ops.ssim_level(X, Y, taps, C1, C2)
     if nonnegative_ssim:

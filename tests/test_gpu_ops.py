@@ -339,9 +339,11 @@ def test_adam_rmsprop_match_torch():
         assert_close(pg, pr, tol=1e-6, what=kind)
 
 
-@pytest.mark.parametrize('shape', [(2, 3, 40, 52), (1, 4, 176, 176), (1, 2, 200, 184), (2, 1, 11, 11), (1, 1, 13, 31)])
+@pytest.mark.parametrize('shape', [(2, 3, 40, 52), (1, 4, 176, 176), (1, 2, 200, 184), (2, 1, 11, 11), (1, 1, 13, 31),
+                                   (2, 3, 8, 40), (1, 2, 37, 6), (1, 1, 5, 7)])      # [r4] a dimension shorter than the 11-tap window
 def test_ssim_level_and_msssim(shape):
-    """fused SSIM level vs the oracle's op-by-op restatement of ssim.py:55-92."""
+    """fused SSIM level vs the oracle's op-by-op restatement of ssim.py:55-92 (incl. gaussian_filter's rule of skipping the
+    smoothing along a dimension shorter than the window, ssim.py:44-50)."""
     ops = _ops()
     from oracle import losses as ol
     from fcd_gan_pytorch_amd import ssim as pssim
@@ -360,6 +362,13 @@ def test_ssim_level_and_msssim(shape):
     assert_close(cs, cs_ref, tol=2e-5, what='cs')
     assert_close(xg.grad, xr.grad, tol=1e-4, what='dX')
     assert_close(yg.grad, yr.grad, tol=1e-4, what='dY')
+    if min(H, W) < 11:       # the public entry point warns like the reference does and returns the same number
+        import warnings as _w
+        with _w.catch_warnings(record=True) as rec:
+            _w.simplefilter('always')
+            v = pssim.ssim(x.cuda(), y.cuda(), data_range=1.0)
+        assert any('Skipping Gaussian Smoothing' in str(r.message) for r in rec)
+        assert abs(v.item() - s_ref.mean().item()) < 2e-5
     if min(H, W) > 160:
         xr.grad = None; yr.grad = None; xg.grad = None; yg.grad = None
         v_ref = ol.ms_ssim(xr, yr, data_range=1.0)
