@@ -900,7 +900,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void wino_gem
 // step 1 in their shadows (4 VALU per MFMA), then the 24 MFMAs of step 1.
 #define WS_STEP(SA, SB, SAN, SBN)                                                                \
   {                                                                                              \
-    if (!(FCD_SEXP & 8)) if (fb < nb) WS_DMA(SAN, SBN)                                           \
+    if (!(FCD_SEXP & 8) && !(FCD_YEXP & 16)) if (fb < nb) WS_DMA(SAN, SBN)                       \
     f32x4 xr[2][2][2];                                                                           \
     u32x4 ah[2][2], am[2][2], al[2][2], bh[2][2], bm[2][2], bl[2][2];                            \
     _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                \
@@ -923,6 +923,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void wino_gem
       }                                                                                          \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) WS_SPLIT(xr[0][i][0], xr[0][i][1], bh[0][i], bm[0][i], bl[0][i]) \
     WS_SIX(ah[0], am[0], al[0], bh[0], bm[0], bl[0])                                             \
+    if ((FCD_YEXP & 16) && !(FCD_SEXP & 8)) if (fb < nb) WS_DMA(SAN, SBN)                        \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) WS_SPLIT(xr[1][i][0], xr[1][i][1], bh[1][i], bm[1][i], bl[1][i]) \
     WS_SIX(ah[1], am[1], al[1], bh[1], bm[1], bl[1])                                             \
     if (!(FCD_SEXP & 16)) {                                                                      \
@@ -1243,9 +1244,18 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split256_kernel(WinoGemmArgs
           __builtin_bit_cast(bf16x8, AV[i]), __builtin_bit_cast(bf16x8, BV[j]), acc[2 * (IH) + i][j], 0, 0, 0);
 #define Y_SIX(IH, AH, AM, AL, BH, BM_, BL)                                                       \
   Y_MFMA(IH, AL, BH) Y_MFMA(IH, AH, BL) Y_MFMA(IH, AM, BM_) Y_MFMA(IH, AM, BH) Y_MFMA(IH, AH, BM_) Y_MFMA(IH, AH, BH)
+// Where in a stage the LDS-DMA of the NEXT stage is issued (FCD_YEXP, results identical): [r4] after the SECOND of the four MFMA groups
+// (bit 4, the default) instead of at the top of the stage -- measured on conv3_x / conv4_x / conv3_1: 1.58 -> 1.485, 1.297 -> 1.257,
+// 0.727 -> 0.699 ms (the requests no longer sit in front of the stage's own LDS operand reads, and half a stage is still enough for
+// them to land); after the first group (bit 2) 1.53 / 1.285 / 0.706, after the third (bit 8) 1.51 / 1.264 / 0.709.  Bit 1 = s_setprio 2
+// over the MFMA part of a stage: no effect.  Bit 16 = the same move in the 128-tile kernel: no gain (9.73 - 9.86 vs 9.69 - 9.72 ms over the
+// 12 layer shapes of tools/bench_wino_gemm.py).
+#ifndef FCD_YEXP
+#define FCD_YEXP 4
+#endif
 #define Y_STEP(SA, SB, SAN, SBN)                                                                 \
   {                                                                                              \
-    if (!(FCD_SEXP & 8)) if (fb < nb) Y_DMA(SAN, SBN)                                            \
+    if (!(FCD_SEXP & 8) && !(FCD_YEXP & 14)) if (fb < nb) Y_DMA(SAN, SBN)                         \
     f32x4 xa[2][2];                                                                              \
     u32x4 pah[2], pam[2], pal[2], qah[2], qam[2], qal[2];                                        \
     u32x4 bh0[2], bm0[2], bl0[2], bh1[2], bm1[2], bl1[2];                                        \
@@ -1259,12 +1269,16 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split256_kernel(WinoGemmArgs
       xa[j][0] = (FCD_SEXP & 32) ? f32x4{(float)lane, 1.f, 2.f, 2.f} : *(const f32x4*)((SB) + boff[j] + ((2 ^ swb) * 4)); \
       xa[j][1] = (FCD_SEXP & 32) ? f32x4{(float)j, 3.f, (float)lane, 2.f} : *(const f32x4*)((SB) + boff[j] + ((3 ^ swb) * 4)); \
     }                                                                                            \
+    if (FCD_YEXP & 1) __builtin_amdgcn_s_setprio(2);                                             \
     Y_SIX(0, pah, pam, pal, bh0, bm0, bl0)                                                       \
+    if ((FCD_YEXP & 2) && !(FCD_SEXP & 8)) if (fb < nb) Y_DMA(SAN, SBN)                          \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) WS_SPLIT(xa[j][0], xa[j][1], bh1[j], bm1[j], bl1[j]) \
     Y_LOADA(SA, 0, 1, qah, qam, qal)                                                             \
     Y_SIX(1, qah, qam, qal, bh0, bm0, bl0)                                                       \
+    if ((FCD_YEXP & 4) && !(FCD_SEXP & 8)) if (fb < nb) Y_DMA(SAN, SBN)                          \
     Y_LOADA(SA, 1, 0, pah, pam, pal)                                                             \
     Y_SIX(0, pah, pam, pal, bh1, bm1, bl1)                                                       \
+    if ((FCD_YEXP & 8) && !(FCD_SEXP & 8)) if (fb < nb) Y_DMA(SAN, SBN)                          \
     Y_LOADA(SA, 1, 1, qah, qam, qal)                                                             \
     Y_SIX(1, qah, qam, qal, bh1, bm1, bl1)                                                       \
     __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);     /* B raw step 0, A (0, 0) */         \
@@ -1292,6 +1306,7 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split256_kernel(WinoGemmArgs
     }                                                                                            \
     __builtin_amdgcn_sched_group_barrier(0x008, 36, 0);                                          \
     __builtin_amdgcn_sched_barrier(0);                                                           \
+    if (FCD_YEXP & 1) __builtin_amdgcn_s_setprio(0);                                             \
     __syncthreads();                                                                             \
   }
 
