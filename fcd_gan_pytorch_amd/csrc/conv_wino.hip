@@ -744,6 +744,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void wino_gem
 // the v_mfma_f32_32x32x2_f32 chain performs.  A (the transformed filters) is split once per weight version by the pack
 // kernel (three bf16 planes); B (the transformed activations V, fp32 in HBM and in LDS) is split in registers right
 // before the MFMAs.  Lane (row, half) owns reduction elements half*16 .. half*16+15 of the 32-chunk, 8 per MFMA step.
+// Where in a stage the LDS-DMA of the NEXT stage is issued (FCD_YEXP, results identical): [r4] after the SECOND of the four MFMA groups
+// (bit 4, the default) instead of at the top of the stage -- measured on conv3_x / conv4_x / conv3_1: 1.58 -> 1.485, 1.297 -> 1.257,
+// 0.727 -> 0.699 ms (the requests no longer sit in front of the stage's own LDS operand reads, and half a stage is still enough for
+// them to land); after the first group (bit 2) 1.53 / 1.285 / 0.706, after the third (bit 8) 1.51 / 1.264 / 0.709.  Bit 1 = s_setprio 2
+// over the MFMA part of a stage: no effect.  Bit 16 = the same move in the 128-tile kernel: no gain (9.73 - 9.86 vs 9.69 - 9.72 ms over the
+// 12 layer shapes of tools/bench_wino_gemm.py).
+#ifndef FCD_YEXP
+#define FCD_YEXP 4
+#endif
 #ifndef FCD_SEXP
 #define FCD_SEXP 0   // diagnostic builds only (wrong results): 1 no operand split, 2 one MFMA of the six, 4 no barrier, 8 no DMA,
                      // 64 no A-operand DMA (128-tile kernel), 128 no C stores (128-tile kernel)
@@ -1244,15 +1253,6 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split256_kernel(WinoGemmArgs
           __builtin_bit_cast(bf16x8, AV[i]), __builtin_bit_cast(bf16x8, BV[j]), acc[2 * (IH) + i][j], 0, 0, 0);
 #define Y_SIX(IH, AH, AM, AL, BH, BM_, BL)                                                       \
   Y_MFMA(IH, AL, BH) Y_MFMA(IH, AH, BL) Y_MFMA(IH, AM, BM_) Y_MFMA(IH, AM, BH) Y_MFMA(IH, AH, BM_) Y_MFMA(IH, AH, BH)
-// Where in a stage the LDS-DMA of the NEXT stage is issued (FCD_YEXP, results identical): [r4] after the SECOND of the four MFMA groups
-// (bit 4, the default) instead of at the top of the stage -- measured on conv3_x / conv4_x / conv3_1: 1.58 -> 1.485, 1.297 -> 1.257,
-// 0.727 -> 0.699 ms (the requests no longer sit in front of the stage's own LDS operand reads, and half a stage is still enough for
-// them to land); after the first group (bit 2) 1.53 / 1.285 / 0.706, after the third (bit 8) 1.51 / 1.264 / 0.709.  Bit 1 = s_setprio 2
-// over the MFMA part of a stage: no effect.  Bit 16 = the same move in the 128-tile kernel: no gain (9.73 - 9.86 vs 9.69 - 9.72 ms over the
-// 12 layer shapes of tools/bench_wino_gemm.py).
-#ifndef FCD_YEXP
-#define FCD_YEXP 4
-#endif
 #define Y_STEP(SA, SB, SAN, SBN)                                                                 \
   {                                                                                              \
     if (!(FCD_SEXP & 8) && !(FCD_YEXP & 14)) if (fb < nb) Y_DMA(SAN, SBN)                         \
