@@ -42,6 +42,9 @@ int fcd_wino_mode_now();   // conv_wino.hip: 0 = direct kernels only (tests' A/B
 #ifndef W2_DEEP
 #define W2_DEEP 1
 #endif
+#ifndef W2_LATE
+#define W2_LATE 0     // 1: the next stage's filter LDS-DMA is issued after the first 4-channel group of the stage instead of at its top
+#endif
 // W2_TIME: attribution build (tools/w2_segments.py): every wave stamps s_memtime at the segment borders of its
 // stage loop and writes the per-segment cycle sums {prologue, issue (filter DMA + patch loads), operands + transforms + MFMA issue,
 // LDS commit of the next patch (waits for its global loads), barrier, epilogue, total} to a debug buffer.  Results stay correct;
@@ -300,13 +303,14 @@ __global__ __launch_bounds__(64 * NW) void conv_wino2_kernel(Wino2Args a) {
     const int xb = (W2_EXP & 64) ? 0 : (cch & 1);                                                     \
     W2_T(ts0)                                                                                         \
     if (have_next && !(W2_EXP & 1)) {                                                                \
-      W2_DMA(cch + 1, UNXT)                                                                           \
+      if (!W2_LATE) W2_DMA(cch + 1, UNXT)                                                             \
       if (!DEEP) W2_LOAD_X(cch + 1, XNEXT)                                                            \
     }                                                                                                \
     if (DEEP && cch + 2 < a.nchunks) W2_LOAD_X(cch + 2, XFAR)                                         \
     W2_T(ts1)                                                                                         \
     const float* xl = sx + xb * XS_SZ;                                                               \
     _Pragma("unroll") for (int ks = 0; ks < W2_KS; ++ks) {                                           \
+    if (W2_LATE && ks == 1 && have_next && !(W2_EXP & 1)) W2_DMA(cch + 1, UNXT)                      \
     if (W2_KS == 3 && ks > 0 && cch * W2_CB + ks * 4 >= a.C) continue;   /* 12-channel stages: the last one may hold 4 or 8 */ \
     float av[16];                                                                                    \
     {                                                                                                \
