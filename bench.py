@@ -554,6 +554,12 @@ def main():
             cands.sort(key=lambda e: -(e['share_of_step_time'] or 0.0))
             res['roofline'] = cands[0]
             res['roofline']['other_mfma_kernels'] = cands[1:]
+            if res['roofline']['kernel'].startswith('wino_gemm_split'):
+                # context, never the peak the fraction is priced against: what the vendor library's best bf16 GEMM reaches on this chip
+                res['roofline']['vendor_bf16_gemm'] = {
+                    'frac_of_peak': 0.548, 'tflops': 1370.1, 'what': 'hipBLASLt bf16 16384^3 through torch.matmul on one MI355X '
+                    '(tools/bench_vendor_gemm.py, profiles/r04_vendor_gemm.md); the vendor fp32 GEMM on the conv3_x / conv4_x shapes of this '
+                    'step takes 1.5 - 1.6x the split GEMM\'s time'}
             # HBM bytes per launch of the direct-conv family from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate
             # rocprofv3 passes over this very command: tools/pmc_bench.sh); bench.py cannot run the profiler on itself,
             # so it reports the committed measurement of the family it belongs to.

@@ -150,22 +150,25 @@ class PerceptionLoss(nn.Module):
             i += 1
         return taps
 
-    def forward(self, target_image, generate_image, cmask):
+    def forward(self, target_image, generate_image, cmask, stacked=None):
+        """``stacked``: ``masked_pair(target_image, generate_image, cmask)`` when the caller has it already (the criteria
+        feed the same masked pair to MS-SSIM)."""
         n = target_image.shape[0]
         nl = len(self.feature_layer_list)
         if not self.perception_perBand:
             assert target_image.shape[1] >= 3
-            keep = 1 - cmask
-            z = torch.cat([target_image[:, 0:3] * keep, generate_image[:, 0:3] * keep], dim=0)
+            if target_image.shape[1] == 3:
+                z = stacked if stacked is not None else masked_pair(target_image, generate_image, cmask)
+            else:
+                keep = 1 - cmask
+                z = torch.cat([target_image[:, 0:3] * keep, generate_image[:, 0:3] * keep], dim=0)
             nb = n
         else:
             # every band becomes its own 3-channel image (band replicated), all bands of
             # both images in one batch: rows [0, n*C) target, [n*C, 2*n*C) generated
             C, H, W = target_image.shape[1:]
-            keep = 1 - cmask
-            tb = (target_image * keep).reshape(n * C, 1, H, W)
-            gb = (generate_image * keep).reshape(n * C, 1, H, W)
-            z = torch.cat([tb, gb], dim=0)          # (2*n*C, 1, H, W): see _first_filter_1ch
+            z = stacked if stacked is not None else masked_pair(target_image, generate_image, cmask)
+            z = z.reshape(2 * n * C, 1, H, W)           # see _first_filter_1ch
             nb = n * C
         feats = self._features(z, single_band=self.perception_perBand)
         total = 0
@@ -174,6 +177,16 @@ class PerceptionLoss(nn.Module):
             # sum over bands of per-band MSE / C  ==  MSE over the band-batched tensor
             total = total + mse_halves(f, nb) / nl
         return total
+
+
+def masked_pair(target_image, generate_image, cmask):
+    """``torch.cat([target_image * (1 - cmask), generate_image * (1 - cmask)], dim=0)`` -- the reference's
+    ``mask_t = target * (1 - cmask).repeat(...)`` / ``mask_g`` (Loss.py:78-79,111-112) as one batch, from one HIP kernel
+    (``ops.masked_stack``; FCD_FUSED_GLUE=0: the ATen sequence)."""
+    if os.environ.get('FCD_FUSED_GLUE', '1') == '0' or not target_image.is_cuda:
+        keep = 1 - cmask
+        return torch.cat([target_image * keep, generate_image * keep], dim=0)
+    return ops.masked_stack([target_image, generate_image], cmask)
 
 
 class _MseHalves(torch.autograd.Function):
@@ -240,10 +253,11 @@ class CNetLoss(nn.Module):
         num, wsum = ops.masked_sums(target_image, generate_image, cmap, 0, True)
         generator_loss = _per_sample_ratio(num, wsum, 1.0 / C, skip_zero=False)
         l1_loss = torch.mean(abs(cmap))
-        perception_loss = self.loss_perception(target_image, generate_image,
-                                               cmask if generator_mask_switch else cmap)
-        keep = 1 - cmap
-        ssim_loss = 1 - self.ssim(target_image * keep, generate_image * keep)
+        n = target_image.shape[0]
+        z = masked_pair(target_image, generate_image, cmap)
+        perception_loss = self.loss_perception(target_image, generate_image, cmask if generator_mask_switch else cmap,
+                                               stacked=None if generator_mask_switch else z)
+        ssim_loss = 1 - self.ssim(z[:n], z[n:])
         return generator_loss, l1_loss, perception_loss, ssim_loss
 
 
@@ -262,9 +276,10 @@ class CGeneratorLoss(nn.Module):
         C = target_image.shape[1]
         num, wsum = ops.masked_sums(target_image, generate_image, cmap, 1, True)
         generator_loss = _per_sample_ratio(num, wsum, 1.0 / C, skip_zero=True)
-        keep = 1 - cmap
-        ssim_loss = 1 - self.ssim(target_image * keep, generate_image * keep)
-        perception_loss = self.loss_perception(target_image, generate_image, cmap)
+        n = target_image.shape[0]
+        z = masked_pair(target_image, generate_image, cmap)
+        ssim_loss = 1 - self.ssim(z[:n], z[n:])
+        perception_loss = self.loss_perception(target_image, generate_image, cmap, stacked=z)
         return generator_loss, ssim_loss, perception_loss
 
 

@@ -398,5 +398,11 @@ class Discriminator_SRGAN_simple(nn.Module):
     def forward_pairs(self, pairs):
         """Evaluate several (x, y) pairs in one batched pass; equivalent to calling
         ``forward`` on each pair in order (BN running stats see x1,y1,x2,y2,...)."""
-        z = torch.cat([t for p in pairs for t in p], dim=0)
-        return self._classify_pairs(self.features(z, groups=2 * len(pairs)), len(pairs))
+        return self.forward_stacked(torch.cat([t for p in pairs for t in p], dim=0), len(pairs))
+
+    def forward_stacked(self, z, npairs):
+        """``forward_pairs`` on the already batched tensor ``z`` = cat([x1, y1, x2, y2, ...], dim=0) (what
+        ``ops.masked_stack`` writes): a list of ``npairs`` outputs."""
+        if z.shape[0] % (2 * npairs):
+            raise ValueError('forward_stacked: %d samples are not %d (x, y) pairs' % (z.shape[0], npairs))
+        return self._classify_pairs(self.features(z, groups=2 * npairs), npairs)

@@ -133,6 +133,8 @@ _SIGS = {
     'fcd_avgpool2_pad_bwd': (c_int, [P, P, c_int, c_int, c_int, P]),
     'fcd_pair_gap_diff_fwd': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     'fcd_pair_gap_diff_bwd': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    'fcd_masked_stack_fwd': (c_int, [P, P, P, P, c_int, P, P, c_int, c_int, c_int, P]),
+    'fcd_masked_stack_bwd': (c_int, [P, P, P, P, P, c_int, P, P, P, P, P, P, c_int, c_int, c_int, P]),
     'fcd_normalize_tiles': (c_int, [P, P, P, P, P, c_int, c_int, c_int, P]),
     'fcd_masked_recon_ws_bytes': (c_size_t, [c_int]),
     'fcd_masked_recon_fwd': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),

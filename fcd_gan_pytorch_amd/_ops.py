@@ -787,6 +787,55 @@ def pair_gap_diff(f, pairs):
     return _PairGapDiff.apply(f, pairs)
 
 
+class _MaskedStack(torch.autograd.Function):
+    """``torch.cat([t * (1 - cmask) for t in tensors], dim=0)`` as one node: the reference multiplies every image that enters the
+    Discriminator, the perception VGG or SSIM by ``(1 - cmask).repeat(1, C, 1, 1)`` (Demo_RSSS.py:290-300, Demo_WSSS.py:264-277,
+    Loss.py:78-79,111-112); through ATen that is an rsub, a broadcast multiply per tensor and a cat -- and in the backward pass two
+    multiplies and a channel reduction per tensor, the adds joining them and a negation."""
+
+    @staticmethod
+    def forward(ctx, cmask, *tensors):
+        k = len(tensors)
+        ts = [_dev(t, 'masked_stack source') for t in tensors]
+        cm = _dev(cmask, 'masked_stack mask')
+        N, C, H, W = ts[0].shape
+        z = torch.empty((k * N, C, H, W), dtype=torch.float32, device=ts[0].device)
+        ptr = [_p(t) for t in ts] + [None] * (4 - k)
+        check(lib.fcd_masked_stack_fwd(ptr[0], ptr[1], ptr[2], ptr[3], k, _p(cm), _p(z), N, C, H * W, _stream()), 'fcd_masked_stack_fwd')
+        ctx.save_for_backward(cm, *ts)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        cm, ts = ctx.saved_tensors[0], ctx.saved_tensors[1:]
+        k = len(ts)
+        N, C, H, W = ts[0].shape
+        dz = _dev(dz, 'masked_stack grad')
+        need = ctx.needs_input_grad
+        dcm = torch.empty_like(cm) if need[0] else None
+        # the same tensor may stand in two slots (x of both Discriminator pairs): autograd adds the per-slot gradients
+        ds = [torch.empty_like(ts[i]) if need[1 + i] else None for i in range(k)]
+        if dcm is not None or any(d is not None for d in ds):
+            ptr = [_p(t) for t in ts] + [None] * (4 - k)
+            dp = [(_p(d) if d is not None else None) for d in ds] + [None] * (4 - k)
+            check(lib.fcd_masked_stack_bwd(_p(dz), ptr[0], ptr[1], ptr[2], ptr[3], k, _p(cm), _p(dcm) if dcm is not None else None,
+                                           dp[0], dp[1], dp[2], dp[3], N, C, H * W, _stream()), 'fcd_masked_stack_bwd')
+        return (dcm,) + tuple(ds)
+
+
+def masked_stack(tensors, cmask):
+    """``torch.cat([t * (1 - cmask) for t in tensors], dim=0)``; ``tensors``: 1 - 4 tensors (N, C, H, W), ``cmask`` (N, 1, H, W)."""
+    tensors = list(tensors)
+    if not 1 <= len(tensors) <= 4:
+        raise ValueError('masked_stack: 1 - 4 tensors, got %d' % len(tensors))
+    shp = tuple(tensors[0].shape)
+    if len(shp) != 4 or any(tuple(t.shape) != shp for t in tensors):
+        raise ValueError('masked_stack: tensors of one (N, C, H, W) shape')
+    if tuple(cmask.shape) != (shp[0], 1, shp[2], shp[3]):
+        raise ValueError('masked_stack: mask %s for tensors %s' % (tuple(cmask.shape), shp))
+    return _MaskedStack.apply(cmask, *tensors)
+
+
 @torch.no_grad()
 def normalize_tiles(x, mean, std, valid=None, out=None):
     """Per-band ``(x - mean) / std`` of raw (N,C,H,W) tiles on the device, zero outside ``valid`` (N,1,H,W);

@@ -458,3 +458,125 @@ extern "C" int fcd_pair_gap_diff_bwd(const float* g, float* df, int pairs, int n
   FCD_LAUNCH_CHECK("pair_gap_diff_bwd");
   return FCD_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// masked stack [r4]: z[i * N + n][c][p] = src_i[n][c][p] * (1 - cmask[n][p]),  i < k <= 4 -- the reference's
+// `x * (1 - cmask).repeat(1, C, 1, 1)` of every tensor that goes into the Discriminator / the perception VGG / SSIM
+// (Demo_RSSS.py:290-300, Demo_WSSS.py:264-277, Loss.py:78-79,111-112), written straight into the batch the consumer reads:
+// one pass instead of rsub + k broadcast multiplies + cat, and in the backward pass one kernel instead of 2 k multiplies,
+// k channel reductions, the adds joining them and a negation.  Forward values are bit-identical to the ATen sequence
+// (one rounding in 1 - cmask, one in the product); the mask gradient is accumulated in fp64.
+template <int VEC>
+__global__ void masked_stack_fwd_kernel(const float* __restrict__ s0, const float* __restrict__ s1, const float* __restrict__ s2,
+                                        const float* __restrict__ s3, int k, const float* __restrict__ cmask, float* __restrict__ z,
+                                        int N, int C, int HW) {
+  const long long per = (long long)N * C * (HW / VEC), total = per * k;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int i = (int)(e / per);
+    const long long r = e % per;
+    const int pv = (int)(r % (HW / VEC));
+    const long long nc = r / (HW / VEC);
+    const int n = (int)(nc / C);
+    const float* src = i == 0 ? s0 : (i == 1 ? s1 : (i == 2 ? s2 : s3));
+    if (VEC == 4) {
+      const float4 m = *reinterpret_cast<const float4*>(cmask + (size_t)n * HW + 4 * pv);
+      const float4 v = *reinterpret_cast<const float4*>(src + (size_t)nc * HW + 4 * pv);
+      float4 o;
+      o.x = v.x * (1.0f - m.x); o.y = v.y * (1.0f - m.y); o.z = v.z * (1.0f - m.z); o.w = v.w * (1.0f - m.w);
+      *reinterpret_cast<float4*>(z + ((size_t)i * N * C + nc) * HW + 4 * pv) = o;
+    } else {
+      z[((size_t)i * N * C + nc) * HW + pv] = src[(size_t)nc * HW + pv] * (1.0f - cmask[(size_t)n * HW + pv]);
+    }
+  }
+}
+
+// one thread per (sample, VEC pixels): walks the k tensors' C channels; dcmask = -sum_i sum_c dz_i * src_i (fp64), d_i = dz_i * (1 - cmask)
+template <int VEC>
+__global__ void masked_stack_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ s0, const float* __restrict__ s1,
+                                        const float* __restrict__ s2, const float* __restrict__ s3, int k,
+                                        const float* __restrict__ cmask, float* __restrict__ dcmask, float* __restrict__ d0,
+                                        float* __restrict__ d1, float* __restrict__ d2, float* __restrict__ d3, int N, int C, int HW) {
+  const int per = HW / VEC;
+  const long long total = (long long)N * per;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(e / per), pv = (int)(e % per);
+    float keep[VEC];
+    double acc[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { keep[j] = 1.0f - cmask[(size_t)n * HW + VEC * pv + j]; acc[j] = 0.0; }
+    for (int i = 0; i < k; ++i) {
+      const float* src = i == 0 ? s0 : (i == 1 ? s1 : (i == 2 ? s2 : s3));
+      float* dst = i == 0 ? d0 : (i == 1 ? d1 : (i == 2 ? d2 : d3));
+      for (int c = 0; c < C; ++c) {
+        const size_t so = ((size_t)n * C + c) * HW + (size_t)VEC * pv;
+        const size_t zo = (((size_t)i * N + n) * C + c) * HW + (size_t)VEC * pv;
+        float g[VEC], v[VEC];
+        if (VEC == 4) {
+          const float4 g4 = *reinterpret_cast<const float4*>(dz + zo);
+          g[0] = g4.x; g[1] = g4.y; g[2] = g4.z; g[3] = g4.w;
+          if (dcmask) {
+            const float4 v4 = *reinterpret_cast<const float4*>(src + so);
+            v[0] = v4.x; v[1] = v4.y; v[2] = v4.z; v[3] = v4.w;
+          }
+        } else {
+          g[0] = dz[zo];
+          if (dcmask) v[0] = src[so];
+        }
+        if (dcmask) {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) acc[j] += (double)g[j] * (double)v[j];
+        }
+        if (dst) {
+          if (VEC == 4) {
+            float4 o; o.x = g[0] * keep[0]; o.y = g[1] * keep[1]; o.z = g[2] * keep[2]; o.w = g[3] * keep[3];
+            *reinterpret_cast<float4*>(dst + so) = o;
+          } else {
+            dst[so] = g[0] * keep[0];
+          }
+        }
+      }
+    }
+    if (dcmask) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) dcmask[(size_t)n * HW + VEC * pv + j] = (float)(-acc[j]);
+    }
+  }
+}
+
+extern "C" int fcd_masked_stack_fwd(const float* s0, const float* s1, const float* s2, const float* s3, int k, const float* cmask,
+                                    float* z, int N, int C, int HW, void* stream) {
+  FCD_CHECK_ARG(s0 && cmask && z && k >= 1 && k <= 4 && N > 0 && C > 0 && HW > 0, "fcd_masked_stack_fwd: bad arguments");
+  FCD_CHECK_ARG((k < 2 || s1) && (k < 3 || s2) && (k < 4 || s3), "fcd_masked_stack_fwd: fewer sources than k");
+  const double elems = (double)k * N * C * HW;
+  FcdProfScope prof(FCD_K_POOL, (hipStream_t)stream, 0.0, 4.0 * 2.0 * elems);
+  const int block = 256;
+  if ((HW & 3) == 0) {
+    const long long blocks = std::min<long long>(cdiv64((long long)(elems / 4), block), 256 * 32);
+    hipLaunchKernelGGL(masked_stack_fwd_kernel<4>, dim3((unsigned)blocks), dim3(block), 0, (hipStream_t)stream, s0, s1, s2, s3, k, cmask, z, N, C, HW);
+  } else {
+    const long long blocks = std::min<long long>(cdiv64((long long)elems, block), 256 * 32);
+    hipLaunchKernelGGL(masked_stack_fwd_kernel<1>, dim3((unsigned)blocks), dim3(block), 0, (hipStream_t)stream, s0, s1, s2, s3, k, cmask, z, N, C, HW);
+  }
+  FCD_LAUNCH_CHECK("masked_stack_fwd");
+  return FCD_OK;
+}
+
+extern "C" int fcd_masked_stack_bwd(const float* dz, const float* s0, const float* s1, const float* s2, const float* s3, int k,
+                                    const float* cmask, float* dcmask, float* d0, float* d1, float* d2, float* d3,
+                                    int N, int C, int HW, void* stream) {
+  FCD_CHECK_ARG(dz && cmask && k >= 1 && k <= 4 && N > 0 && C > 0 && HW > 0, "fcd_masked_stack_bwd: bad arguments");
+  FCD_CHECK_ARG(!dcmask || (s0 && (k < 2 || s1) && (k < 3 || s2) && (k < 4 || s3)), "fcd_masked_stack_bwd: the mask gradient needs every source");
+  FCD_CHECK_ARG(dcmask || d0 || d1 || d2 || d3, "fcd_masked_stack_bwd: nothing to compute");
+  const double elems = (double)k * N * C * HW;
+  FcdProfScope prof(FCD_K_POOL, (hipStream_t)stream, 0.0, 4.0 * 2.0 * elems);
+  const int block = 128;
+  if ((HW & 3) == 0) {
+    hipLaunchKernelGGL(masked_stack_bwd_kernel<4>, dim3((unsigned)cdiv64((long long)N * (HW / 4), block)), dim3(block), 0, (hipStream_t)stream,
+                       dz, s0, s1, s2, s3, k, cmask, dcmask, d0, d1, d2, d3, N, C, HW);
+  } else {
+    hipLaunchKernelGGL(masked_stack_bwd_kernel<1>, dim3((unsigned)cdiv64((long long)N * HW, block)), dim3(block), 0, (hipStream_t)stream,
+                       dz, s0, s1, s2, s3, k, cmask, dcmask, d0, d1, d2, d3, N, C, HW);
+  }
+  FCD_LAUNCH_CHECK("masked_stack_bwd");
+  return FCD_OK;
+}

@@ -54,6 +54,19 @@ def _bcast_keep(cmask, C):
     return 1 - cmask            # (N,1,H,W) broadcasts over the C bands (reference uses .repeat)
 
 
+def _masked_batch(tensors, cmask):
+    """``torch.cat([t * (1 - cmask) for t in tensors], dim=0)``: every image the reference multiplies by
+    ``(1 - cmask).repeat(1, C, 1, 1)`` before a Discriminator call (Demo_RSSS.py:290-300, Demo_WSSS.py:264-279), laid out as the
+    batch ``Discriminator_SRGAN_simple.forward_stacked`` reads.  One HIP kernel forward, one backward (``ops.masked_stack``);
+    FCD_FUSED_GLUE=0 runs the ATen sequence (rsub, a broadcast multiply per tensor, cat) for A/B."""
+    import os
+    if os.environ.get('FCD_FUSED_GLUE', '1') == '0':
+        keep = _bcast_keep(cmask, tensors[0].shape[1])
+        return torch.cat([t * keep for t in tensors], dim=0)
+    from . import _ops
+    return _ops.masked_stack(tensors, cmask)
+
+
 _SIDE = {}
 
 
@@ -131,9 +144,7 @@ def rsss_adversarial_step(netS, netD, netG, crit, optS, optD, x, y, region, perc
         if side is not None:
             side.wait_stream(main)              # cmap, y_unc are ready
         with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
-            keep_d = _bcast_keep(cmask.detach(), x.shape[1])
-            xm_d = x * keep_d
-            c_out, nc_out = netD.forward_pairs([(xm_d, y * keep_d), (xm_d, y_unc * keep_d)])
+            c_out, nc_out = netD.forward_stacked(_masked_batch([x, y, x, y_unc], cmask.detach()), 2)
             optD.zero_grad()
             d_loss = 1 + nc_out.mean() - c_out.mean()
             optD.begin_overlap(group)
@@ -152,14 +163,13 @@ def rsss_adversarial_step(netS, netD, netG, crit, optS, optD, x, y, region, perc
         y_fake = netG(x)
         generator_loss, ssim_loss, perception_loss = crit(y, y_fake, cmap)
     else:
-        keep = _bcast_keep(cmask, x.shape[1])
         with torch.no_grad():
             y_fake = netG(x)
         generator_loss, ssim_loss, perception_loss = crit(y, y_fake, cmap)
         if side is not None:
             main.wait_stream(side)              # D's updated weights and running statistics
         with _frozen(netD):
-            c_out = netD(x * keep, y * keep)
+            c_out = netD.forward_stacked(_masked_batch([x, y], cmask), 1)[0]
     g_loss = generator_loss + perception_weight * perception_loss + _weighted(ssim_weight, ssim_loss, literal)
     l1_loss = region_loss(cmap, region, 'l1')
     s_d_loss = c_out.mean()
@@ -194,8 +204,7 @@ def wsss_adversarial_step(netS, netD, netG, crit, optS, optD, x, y, x_nc, y_nc, 
         _backward(d_loss, loss_scale, retain_graph=True)
     else:
         ncmap = netS(x_nc, y_nc)
-        keep_d = _bcast_keep(cmask.detach(), x.shape[1])
-        c_out, nc_out = netD.forward_pairs([(x * keep_d, y * keep_d), (x_nc * keep_d, y_nc * keep_d)])
+        c_out, nc_out = netD.forward_stacked(_masked_batch([x, y, x_nc, y_nc], cmask.detach()), 2)
         optD.zero_grad()
         d_loss = 1 + nc_out.mean() - c_out.mean()
         optD.begin_overlap(group)
@@ -208,9 +217,8 @@ def wsss_adversarial_step(netS, netD, netG, crit, optS, optD, x, y, x_nc, y_nc, 
         if g_weight != 0:
             y_fake = netG(x)
     else:
-        keep = _bcast_keep(cmask, x.shape[1])
         with _frozen(netD):
-            c_out = netD(x * keep, y * keep)
+            c_out = netD.forward_stacked(_masked_batch([x, y], cmask), 1)[0]
         if g_weight != 0:
             with torch.no_grad():
                 y_fake = netG(x)

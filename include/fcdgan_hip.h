@@ -289,6 +289,16 @@ int fcd_avgpool2_pad_bwd(const float* dy, float* dx, int NC, int H, int W, void*
  * accumulated in fp64).  bwd: df = +/- g / HW, every element of f written. */
 int fcd_pair_gap_diff_fwd(const float* f, float* d, int pairs, int n, int C, int HW, void* stream);
 int fcd_pair_gap_diff_bwd(const float* g, float* df, int pairs, int n, int C, int HW, void* stream);
+/* `x * (1 - cmask).repeat(1, C, 1, 1)` of every tensor entering the Discriminator / perception VGG / SSIM (Demo_RSSS.py:290-300,
+ * Demo_WSSS.py:264-277, Loss.py:78-79,111-112), written as ONE batch: z[i * N + n][c][p] = src_i[n][c][p] * (1 - cmask[n][p]),
+ * i < k <= 4 sources of N*C*HW floats (unused source pointers NULL), cmask N*HW floats, z k*N*C*HW floats.  Forward values are
+ * bit-identical to the ATen sequence.  bwd: dcmask[n][p] = -sum_i sum_c dz_i * src_i (fp64 accumulator; NULL: not wanted),
+ * d_i = dz_i * (1 - cmask) for every non-NULL d_i. */
+int fcd_masked_stack_fwd(const float* s0, const float* s1, const float* s2, const float* s3, int k, const float* cmask, float* z,
+                         int N, int C, int HW, void* stream);
+int fcd_masked_stack_bwd(const float* dz, const float* s0, const float* s1, const float* s2, const float* s3, int k,
+                         const float* cmask, float* dcmask, float* d0, float* d1, float* d2, float* d3, int N, int C, int HW,
+                         void* stream);
 
 /* ---- raw-tile normalisation (NORMALIZE, CommonFunc.py:199-224, as GDALDataset applies it: data_utils.py:106-116)
  * out[n][c] = float((double(x[n][c]) - mean[c]) / std[c]) where valid[n] != 0, else 0.  x, out: N*C*HW floats;

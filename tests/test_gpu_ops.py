@@ -874,3 +874,50 @@ def test_pair_gap_diff(shape):
     err = (d.detach().cpu().double() - dr.detach()).abs().max().item()
     assert err <= 1.2e-7 * dr.detach().abs().max().item() + 1.2e-7 * f.abs().max().item() * 2 ** -3, err
     assert_close(fg.grad, fr.grad, tol=1e-6, what='df')
+
+
+@pytest.mark.parametrize('case', [(4, 2, 13, 32, 32), (2, 3, 3, 7, 5), (1, 1, 5, 16, 8), (3, 2, 4, 9, 9)], ids=lambda c: 'x'.join(map(str, c)))
+def test_masked_stack(case):
+    """cat([t * (1 - cmask) for t in tensors]) -- the reference's `x * (1 - cmask).repeat(1, C, 1, 1)` in front of the
+    Discriminator / perception VGG / SSIM (Demo_RSSS.py:290-300, Loss.py:78-79,111-112) -- as one kernel: forward bit-equal to
+    the ATen sequence, backward (source gradients where wanted, mask gradient with an fp64 accumulator) against fp64 autograd.
+    The same tensor may stand in two slots (x of both Discriminator pairs)."""
+    ops = _ops()
+    k, N, C, H, W = case
+    ts = [rnd(N, C, H, W, seed=90 + i) for i in range(k)]
+    if k >= 3:
+        ts[2] = ts[0]                                   # duplicate slot
+    cm = torch.sigmoid(rnd(N, 1, H, W, seed=99))
+    want_src = [i % 2 == 1 for i in range(k)]           # odd slots want a gradient
+    tg = []
+    for i, t in enumerate(ts):
+        if k >= 3 and i == 2:
+            tg.append(tg[0])
+        else:
+            tg.append(t.cuda().requires_grad_(want_src[i]))
+    cg = cm.cuda().requires_grad_(True)
+    z = ops.masked_stack(tg, cg)
+    ref = torch.cat([t.cuda() * (1 - cm.cuda()) for t in ts], dim=0)
+    assert z.shape == (k * N, C, H, W)
+    assert torch.equal(z.detach(), ref)
+    g = rnd(k * N, C, H, W, seed=77)
+    z.backward(g.cuda())
+    td = [t.double().requires_grad_(True) for t in ts]
+    cd = cm.double().requires_grad_(True)
+    zr = torch.cat([t * (1 - cd) for t in td], dim=0)
+    zr.backward(g.double())
+    assert_close(cg.grad, cd.grad, tol=2e-6, what='dcmask')
+    for i in range(k):
+        if k >= 3 and i in (0, 2):
+            continue
+        if want_src[i]:
+            assert_close(tg[i].grad, td[i].grad, tol=1e-6, what='dsrc%d' % i)
+        else:
+            assert tg[i].grad is None
+    # no mask gradient wanted: only the source gradients are written
+    t1 = ts[0].cuda().requires_grad_(True)
+    z2 = ops.masked_stack([t1], cm.cuda())
+    z2.backward(g[:N].cuda())
+    assert_close(t1.grad, (g[:N].double() * (1 - cm.double())), tol=1e-6, what='dsrc only')
+    with pytest.raises(ValueError):
+        ops.masked_stack([ts[0].cuda(), ts[0].cuda()[:, :1]], cm.cuda())
