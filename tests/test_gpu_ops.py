@@ -277,7 +277,8 @@ def test_conv1x1_head(case):
     assert not ops.conv1x1_head_supported(xg, rnd(2, C, 1, 1).cuda())                              # two output channels
 
 
-@pytest.mark.parametrize('shape', [(2, 3, 8, 8), (1, 5, 11, 13), (2, 4, 27, 55), (1, 2, 2, 2), (1, 2, 3, 3)])
+@pytest.mark.parametrize('shape', [(2, 3, 8, 8), (1, 5, 11, 13), (2, 4, 27, 55), (1, 2, 2, 2), (1, 2, 3, 3), (1, 3, 5, 4), (2, 2, 9, 12),
+                                   (1, 2, 32, 64)])
 def test_maxpool_upsample_avgpool(shape):
     ops = _ops()
     x = rnd(*shape, seed=41)
@@ -294,6 +295,24 @@ def test_maxpool_upsample_avgpool(shape):
         y.backward(g.cuda())
         assert_close(y, yr, tol=1e-6, what=name + ' y')
         assert_close(xg.grad, xr.grad, tol=2e-6, what=name + ' dx')
+
+
+@pytest.mark.parametrize('shape', [(3, 2, 4), (2, 7, 12), (4, 16, 16), (1, 33, 64)], ids=lambda c: 'x'.join(map(str, c)))
+def test_upsample_bwd_four_column_kernel_is_bit_identical(shape):
+    """The adjoint of the x2 bilinear upsampling: the four-columns-per-thread kernel (W % 4 == 0, 16-B aligned buffers) against the
+    one-pixel kernel the same entry point falls back to for a misaligned gradient buffer -- same weights, same summation order."""
+    import ctypes
+    from fcd_gan_pytorch_amd._lib import lib, check
+    ops = _ops()
+    NC, H, W = shape
+    g = rnd(NC, 2 * H, 2 * W, seed=43).cuda()
+    gm = torch.empty(g.numel() + 1, device='cuda')[1:]          # 4-B aligned only
+    gm.copy_(g.reshape(-1))
+    a, b = torch.empty(NC, H, W, device='cuda'), torch.empty(NC, H, W, device='cuda')
+    check(lib.fcd_upsample2x_bwd(ops._p(g), ops._p(a), NC, H, W, ops._stream()))
+    check(lib.fcd_upsample2x_bwd(ctypes.c_void_p(gm.data_ptr()), ops._p(b), NC, H, W, ops._stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize('kind', [0, 1])
