@@ -315,6 +315,15 @@ def latest_traffic_file():
     return files[-1] if files else None
 
 
+def _flush_c_stdio():
+    import ctypes
+    try:
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -639,9 +648,16 @@ def main():
                                          'kernel_families numbers come from a second pass of %d step(s) with them on' % psteps}
         if n_gpus == 1 and not args.no_cpu_baseline and args.workload == 'rsss':
             res['cpu_baseline'] = cpu_baseline(args)
-        print(json.dumps(res))
+    # the JSON line is the LAST thing on stdout: RCCL / Gloo write their banners through C stdio, which -- redirected to a file or a
+    # pipe -- is block-buffered and would otherwise come out at exit, behind the line.  Every rank flushes, then rank 0 prints.
+    _flush_c_stdio()
+    if world > 1 or forced:
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps(res), flush=True)
     if world > 1 or forced:
         dist.destroy_process_group()
+        _flush_c_stdio()
 
 
 if __name__ == '__main__':

@@ -223,6 +223,15 @@ def mse_halves(f, nb):
     return _MseHalves.apply(f, nb)
 
 
+def _masked_ratio(a, b, m, kind, complement, scale, skip_zero):
+    """mean_i( num_i * scale / wsum_i ) of the masked sums -- one autograd node (``ops.masked_ratio_mean``); FCD_FUSED_GLUE=0: the
+    two halves through ATen (``ops.masked_sums`` + :func:`_per_sample_ratio`)."""
+    if os.environ.get('FCD_FUSED_GLUE', '1') == '0':
+        num, wsum = ops.masked_sums(a, b, m, kind, complement)
+        return _per_sample_ratio(num, wsum, scale, skip_zero)
+    return ops.masked_ratio_mean(a, b, m, kind, complement, scale, skip_zero)
+
+
 def _per_sample_ratio(num, wsum, scale, skip_zero):
     """mean_i( num_i * scale / wsum_i ), optionally skipping wsum_i == 0 samples
     (reference Loss.py:115-119 `continue`) -- on device, no host sync."""
@@ -250,8 +259,7 @@ class CNetLoss(nn.Module):
         C = target_image.shape[1]
         cmask = (torch.sign(cmap - 0.5) + 1) / 2
         # L1(mask_t_i, mask_g_i) * HW / num_wnc_i  ==  num_i / (C * wsum_i)   (no zero guard, as the reference)
-        num, wsum = ops.masked_sums(target_image, generate_image, cmap, 0, True)
-        generator_loss = _per_sample_ratio(num, wsum, 1.0 / C, skip_zero=False)
+        generator_loss = _masked_ratio(target_image, generate_image, cmap, 0, True, 1.0 / C, skip_zero=False)
         l1_loss = torch.mean(abs(cmap))
         n = target_image.shape[0]
         z = masked_pair(target_image, generate_image, cmap)
@@ -274,8 +282,7 @@ class CGeneratorLoss(nn.Module):
 
     def forward(self, target_image, generate_image, cmap):
         C = target_image.shape[1]
-        num, wsum = ops.masked_sums(target_image, generate_image, cmap, 1, True)
-        generator_loss = _per_sample_ratio(num, wsum, 1.0 / C, skip_zero=True)
+        generator_loss = _masked_ratio(target_image, generate_image, cmap, 1, True, 1.0 / C, skip_zero=True)
         n = target_image.shape[0]
         z = masked_pair(target_image, generate_image, cmap)
         ssim_loss = 1 - self.ssim(z[:n], z[n:])
@@ -295,5 +302,4 @@ def region_loss(cmap, region, criterion):
         kind = 1
     else:
         raise TypeError('region_loss: criterion must be nn.L1Loss / nn.MSELoss')
-    num, wsum = ops.masked_sums(cmap, None, region, kind, False)
-    return _per_sample_ratio(num, wsum, 1.0 / cmap.shape[1], skip_zero=True)
+    return _masked_ratio(cmap, None, region, kind, False, 1.0 / cmap.shape[1], skip_zero=True)

@@ -139,6 +139,8 @@ _SIGS = {
     'fcd_masked_recon_ws_bytes': (c_size_t, [c_int]),
     'fcd_masked_recon_fwd': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     'fcd_masked_recon_bwd': (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    'fcd_ratio_mean_fwd': (c_int, [P, c_int, c_float, c_int, P, P]),
+    'fcd_ratio_mean_bwd': (c_int, [P, P, c_int, c_float, c_int, P, P, P]),
     'fcd_ssim_ws_bytes': (c_size_t, [c_int, c_int, c_int]),
     'fcd_ssim_level_fwd': (c_int, [P, P, P, c_int, P, c_int, c_int, c_int, c_float, c_float, P, c_size_t, P]),
     'fcd_ssim_level_bwd': (c_int, [P, P, P, c_int, P, P, P, P, c_int, c_int, c_int, c_float, c_float, P, c_size_t, P]),

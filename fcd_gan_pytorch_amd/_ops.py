@@ -885,6 +885,50 @@ class _MaskedSums(torch.autograd.Function):
         return da, db, dm, None, None
 
 
+class _MaskedRatioMean(torch.autograd.Function):
+    """``mean_n(num[n] * scale / wsum[n])`` with (num, wsum) = ``masked_sums(a, b, m, kind, complement)`` as ONE node: the masked
+    per-sample losses of the criteria (reference Loss.py:82-84,115-119,135-138).  Through ATen the tail costs ~9 launches forward
+    (ne / where / mul / div / sum on N-element tensors) and ~10 backward per loss term, three terms per step."""
+
+    @staticmethod
+    def forward(ctx, a, b, m, kind, complement, scale, skip_zero):
+        a = _dev(a, 'masked-sum a')
+        b = _dev(b, 'masked-sum b') if b is not None else None
+        m = _dev(m, 'masked-sum mask')
+        N, C, H, W = a.shape
+        out = torch.empty(2 * N, dtype=torch.float32, device=a.device)
+        ws = _ws(lib.fcd_masked_recon_ws_bytes(N), a.device)
+        check(lib.fcd_masked_recon_fwd(_p(a), _p(b), _p(m), _p(out), N, C, H * W, kind, int(complement), _p(ws),
+                                       ws.numel(), _stream()), 'fcd_masked_recon_fwd')
+        loss = torch.empty((), dtype=torch.float32, device=a.device)
+        check(lib.fcd_ratio_mean_fwd(_p(out), N, float(scale), int(bool(skip_zero)), _p(loss), _stream()), 'fcd_ratio_mean_fwd')
+        ctx.save_for_backward(a, b, m, out)
+        ctx.cfg = (kind, int(complement), float(scale), int(bool(skip_zero)))
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b, m, out = ctx.saved_tensors
+        kind, complement, scale, skip_zero = ctx.cfg
+        N, C, H, W = a.shape
+        g = _dev(g, 'masked-ratio grad')
+        cc = torch.empty(2 * N, dtype=torch.float32, device=a.device)
+        coef, cw = cc[:N], cc[N:]
+        check(lib.fcd_ratio_mean_bwd(_p(g), _p(out), N, scale, skip_zero, _p(coef), _p(cw), _stream()), 'fcd_ratio_mean_bwd')
+        da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        db = torch.empty_like(a) if (b is not None and ctx.needs_input_grad[1]) else None
+        dm = torch.empty_like(m) if ctx.needs_input_grad[2] else None
+        if da is not None or db is not None or dm is not None:
+            check(lib.fcd_masked_recon_bwd(_p(a), _p(b), _p(m), _p(coef), _p(cw), _p(da), _p(db), _p(dm), N, C, H * W,
+                                           kind, complement, _stream()), 'fcd_masked_recon_bwd')
+        return da, db, dm, None, None, None, None
+
+
+def masked_ratio_mean(a, b, m, kind, complement, scale, skip_zero):
+    """mean_n( num[n] * scale / wsum[n] ), (num, wsum) as :func:`masked_sums`; ``skip_zero`` skips samples with wsum == 0."""
+    return _MaskedRatioMean.apply(a, b, m, kind, complement, scale, skip_zero)
+
+
 def masked_sums(a, b, m, kind, complement):
     """(num[N], wsum[N]) with d=(a-b)*w, w = (1-m) if complement else m."""
     out = _MaskedSums.apply(a, b, m, kind, complement)

@@ -324,6 +324,12 @@ int fcd_masked_recon_fwd(const float* a, const float* b, const float* m, float* 
 int fcd_masked_recon_bwd(const float* a, const float* b, const float* m, const float* coef,
                          const float* cw, float* da, float* db, float* dm, int N, int C, int HW,
                          int kind, int complement, void* stream);
+/* mean_n(num[n] * scale / wsum[n]) over the out2 = {num[N], wsum[N]} of fcd_masked_recon_fwd -- the tail of the per-sample loops
+ * Loss.py:82-84,115-119,135-138 (skip_zero: samples with wsum == 0 are skipped, the reference's `continue`, but still counted in
+ * the mean) -- and its adjoint in the form fcd_masked_recon_bwd takes: coef[n] = dL/dnum[n], cw[n] = dL/dwsum[n] for the upstream
+ * gradient g[0]. */
+int fcd_ratio_mean_fwd(const float* out2, int N, float scale, int skip_zero, float* loss, void* stream);
+int fcd_ratio_mean_bwd(const float* g, const float* out2, int N, float scale, int skip_zero, float* coef, float* cw, void* stream);
 
 /* SSIM level (ssim.py:55-92): 11-tap (win) separable VALID Gaussian window
  * statistics of X,Y -> per-(n,c) means of ssim_map and cs_map.

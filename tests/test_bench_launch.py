@@ -73,6 +73,7 @@ def test_bench_gpus8_self_launch_on_one_gpu():
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, r.stdout[-2000:]
+    assert [l for l in r.stdout.splitlines() if l.strip()][-1] == lines[0], r.stdout[-600:]      # ... and nothing behind it
     res = json.loads(lines[0])
     assert res['n_gpus'] == 8 and res['config']['world_size'] == 8 and res['config']['backend'] == 'gloo'
     assert res['config']['global_batch'] == 8 and res['value'] > 0
@@ -88,6 +89,8 @@ def test_bench_gpus8_self_launch_on_one_gpu():
                         '--force-exchange'],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    res = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+    out_lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert out_lines[-1].startswith('{'), out_lines[-6:]        # the record is the LAST line: RCCL's banner (C stdio) comes out before it
+    res = json.loads(out_lines[-1])
     assert res['n_gpus'] == 1 and res['config']['world_size'] == 1 and res['config']['backend'] == 'nccl'
     assert res['config']['grad_exchange_last_step']['S']['buckets'] == 4

@@ -339,6 +339,50 @@ def test_masked_sums(kind, complement):
     assert_close(mg.grad, mr.grad, what='dm')
 
 
+@pytest.mark.parametrize('kind', [0, 1])
+@pytest.mark.parametrize('skip_zero', [True, False])
+def test_masked_ratio_mean(kind, skip_zero):
+    """mean_i(num_i * scale / wsum_i) of the masked per-sample sums (reference Loss.py:82-84,115-119,135-138) as one autograd
+    node, against the same expression through fp64 autograd; with skip_zero one sample has an all-zero weight map (the
+    reference's `continue`) and still counts in the mean."""
+    ops = _ops()
+    N, C, H, W = 4, 5, 17, 23
+    a, b = rnd(N, C, H, W, seed=54), rnd(N, C, H, W, seed=55)
+    m = torch.sigmoid(rnd(N, 1, H, W, seed=56))
+    if skip_zero:
+        m[2] = 0.0                                     # w = m (complement False): sample 2 has wsum == 0
+    scale = 1.0 / C
+    ar, br_, mr = (t.double().requires_grad_(True) for t in (a, b, m))
+    d = (ar - br_) * mr
+    num = (d.abs() if kind == 0 else d * d).sum((1, 2, 3))
+    ws = mr.sum((1, 2, 3))
+    if skip_zero:
+        ok = ws != 0
+        terms = torch.where(ok, num * scale / torch.where(ok, ws, torch.ones_like(ws)), torch.zeros_like(num))
+    else:
+        terms = num * scale / ws
+    ref = terms.sum() / N
+    (ref * 1.7).backward()
+    ag, bg, mg = (t.cuda().requires_grad_(True) for t in (a, b, m))
+    out = ops.masked_ratio_mean(ag, bg, mg, kind, False, scale, skip_zero)
+    (out * 1.7).backward()
+    assert out.shape == ()
+    assert_close(out, ref, tol=2e-6, what='loss')
+    assert_close(ag.grad, ar.grad, tol=2e-6, what='da')
+    assert_close(bg.grad, br_.grad, tol=2e-6, what='db')
+    assert_close(mg.grad, mr.grad, tol=2e-6, what='dm')
+    # one-tensor form (region_loss: b = None, complement weights)
+    cg = a[:, :1].contiguous().cuda().requires_grad_(True)
+    o2 = ops.masked_ratio_mean(cg, None, m.cuda(), kind, True, 1.0, True)
+    cr = a[:, :1].double().requires_grad_(True)
+    w2 = 1 - m.double()
+    d2 = cr * w2
+    r2 = ((d2.abs() if kind == 0 else d2 * d2).sum((1, 2, 3)) / w2.sum((1, 2, 3))).mean()
+    o2.backward(); r2.backward()
+    assert_close(o2, r2, tol=2e-6, what='loss (one tensor)')
+    assert_close(cg.grad, cr.grad, tol=2e-6, what='dcmap')
+
+
 def test_adam_rmsprop_match_torch():
     ops = _ops()
     n = 10007
