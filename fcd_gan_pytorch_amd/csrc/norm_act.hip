@@ -225,12 +225,20 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const float* __restrict__ dz, const float* __restrict__ x, double* __restrict__ part, int C, int HW, int Ng,
     int split, int affine, const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ mean, const float* __restrict__ invstd, int act,
-    const float* __restrict__ slope_ptr, float slope_imm) {
+    const float* __restrict__ slope_ptr, float slope_imm, const float* __restrict__ gamma = nullptr,
+    const float* __restrict__ beta = nullptr) {
   __shared__ double red[16];
   const int c = blockIdx.x, g = blockIdx.y, sp = blockIdx.z;
   const int sidx = g * C + c;
-  const float sc = affine ? scale[sidx] : 1.f, sh = affine ? shift[sidx] : 0.f;
   const float mu = affine ? mean[sidx] : 0.f, is = affine ? invstd[sidx] : 1.f;
+  float sc = 1.f, sh = 0.f;
+  if (affine && gamma) {            // [r4] bn_train_prep_kernel's two lines, here instead of in a launch of their own
+    sc = gamma[c] * is;
+    sh = beta[c] - mu * sc;
+  } else if (affine) {
+    sc = scale[sidx];
+    sh = shift[sidx];
+  }
   const float slope = slope_ptr ? slope_ptr[0] : slope_imm;
   double s1 = 0.0, s2 = 0.0, s3 = 0.0;
   auto elem = [&](float xv, float dzv) {
@@ -320,18 +328,55 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const float* __restrict__ dz, const float* __restrict__ x, float* __restrict__ dx, int C, int HW, int Ng,
     int affine, int training, const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ mean, const float* __restrict__ invstd, const double* __restrict__ fin,
-    double inv_count, int act, const float* __restrict__ slope_ptr, float slope_imm) {
+    double inv_count, int act, const float* __restrict__ slope_ptr, float slope_imm,
+    const double* __restrict__ part = nullptr, int split = 0, int G = 0, const float* __restrict__ gamma = nullptr,
+    const float* __restrict__ beta = nullptr, float* __restrict__ dgamma = nullptr, float* __restrict__ dbeta = nullptr) {
   const int plane = blockIdx.x;
   const int n = plane / C, c = plane % C;
   const int sidx = (n / Ng) * C + c;
-  const float sc = affine ? scale[sidx] : 1.f, sh = affine ? shift[sidx] : 0.f;
   const float slope = slope_ptr ? slope_ptr[0] : slope_imm;
-  float mu = 0.f, is = 1.f, k1 = 0.f, k2 = 0.f;
-  if (affine && training) {
+  float sc = 1.f, sh = 0.f, mu = 0.f, is = 1.f, k1 = 0.f, k2 = 0.f;
+  if (affine && training && part) {
+    // [r4] the work of bn_train_prep_kernel and bn_bwd_finalize_kernel, per block instead of in two launches of a few
+    // microseconds each: the block sums the (<= 64) partial sums of its channel in the order the finalize kernel did
     mu = mean[sidx];
     is = invstd[sidx];
-    k1 = (float)(fin[(size_t)sidx * 3 + 0] * inv_count);
-    k2 = (float)(fin[(size_t)sidx * 3 + 1] * inv_count);
+    sc = gamma[c] * is;
+    sh = beta[c] - mu * sc;
+    double s1 = 0.0, s2 = 0.0;
+    const double* p = part + (size_t)sidx * split * 3;
+    for (int s = 0; s < split; ++s) {
+      s1 += p[s * 3];
+      s2 += p[s * 3 + 1];
+    }
+    k1 = (float)(s1 * inv_count);
+    k2 = (float)(s2 * inv_count);
+    if (n == 0 && blockIdx.y == 0 && threadIdx.x == 0 && (dgamma || dbeta)) {      // one block per channel: the parameter gradients
+      double tg = 0.0, tb = 0.0;
+      for (int g = 0; g < G; ++g) {
+        double a1 = 0.0, a2 = 0.0;
+        const double* q = part + (size_t)(g * C + c) * split * 3;
+        for (int s = 0; s < split; ++s) {
+          a1 += q[s * 3];
+          a2 += q[s * 3 + 1];
+        }
+        tb += a1;
+        tg += a2;
+      }
+      if (dgamma) dgamma[c] = (float)tg;
+      if (dbeta) dbeta[c] = (float)tb;
+    }
+  } else {
+    if (affine) {
+      sc = scale[sidx];
+      sh = shift[sidx];
+    }
+    if (affine && training) {
+      mu = mean[sidx];
+      is = invstd[sidx];
+      k1 = (float)(fin[(size_t)sidx * 3 + 0] * inv_count);
+      k2 = (float)(fin[(size_t)sidx * 3 + 1] * inv_count);
+    }
   }
   const float* xp = x + (size_t)plane * HW;
   const float* dp = dz + (size_t)plane * HW;
@@ -383,6 +428,18 @@ extern "C" int fcd_bn_act_bwd(const float* dz, const float* x, float* dx, int N,
     } else {
       FCD_CHECK_ARG(running_mean && running_var, "fcd_bn_act_bwd: eval needs running stats");
     }
+  }
+  // [r4] training-mode BatchNorm without a PReLU slope gradient: two launches (reduce, apply) instead of four
+  if (has_bn && training && !(act == FCD_ACT_PRELU && dslope)) {
+    const int split = pick_split(C, groups, (long long)Ng * HW);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, groups, split), dim3(256), 0, st, dz, x, w.part, C, HW, Ng, split, 1,
+                       (const float*)nullptr, (const float*)nullptr, mean, invstd, act, slope, slope_imm, gamma, beta);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, plane_grid(N * C, HW), dim3(256), 0, st, dz, x, dx, C, HW, Ng, 1, 1,
+                       (const float*)nullptr, (const float*)nullptr, mean, invstd, (const double*)nullptr,
+                       1.0 / ((double)Ng * HW), act, slope, slope_imm, (const double*)w.part, split, groups, gamma, beta, dgamma,
+                       dbeta);
+    FCD_LAUNCH_CHECK("bn_act_bwd");
+    return FCD_OK;
   }
   // scale/shift
   if (has_bn) {
