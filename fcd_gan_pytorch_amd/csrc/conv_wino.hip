@@ -593,6 +593,7 @@ struct WinoGemmArgs {
   long long c_batch;      // c_batch = floats per xi.  Read back by wino_output_blk_kernel.
   int bt;                 // split kernel, weight gradient: B is the FORWARD pass's V [xi][N / 32][bt_T][32] (GEMM row n = channel,
   long long bt_T;         // reduction = tile index): b_batch = elements per xi, the reduction runs to bt_T (rows clamped), b_ld / b_adv unused
+  unsigned long long* tbuf;   // YG_TIME builds: [workgroup][wave][8] cycle sums
 };
 
 template <int WM, int WN>      // waves along M / N, each 64 x 64: block tile (64 WM) x (64 WN)
@@ -750,6 +751,26 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void wino_gem
 // them to land); after the first group (bit 2) 1.53 / 1.285 / 0.706, after the third (bit 8) 1.51 / 1.264 / 0.709.  Bit 1 = s_setprio 2
 // over the MFMA part of a stage: no effect.  Bit 16 = the same move in the 128-tile kernel: no gain (9.73 - 9.86 vs 9.69 - 9.72 ms over the
 // 12 layer shapes of tools/bench_wino_gemm.py).
+// YG_TIME: attribution build of the 256-tile split GEMM (tools/gemm_segments.py): every wave stamps s_memtime at the segment borders
+// of its stage loop -- top of the stage, in front of the first MFMA group (after the stage's first LDS reads and the split of step 0),
+// behind the last MFMA group, behind the stage barrier -- and around the C store of a batch, and writes the per-segment cycle sums
+// {prologue, MFMA groups, DMA wait + barrier, C store, total} to a debug buffer.  Results stay correct; the stamps are scheduling
+// fences and wait for the wave's outstanding LDS reads.  Never defined in the product build.
+#ifndef YG_TIME
+#define YG_TIME 0
+#endif
+#ifndef YG_PLAINC
+#define YG_PLAINC 0     // experiment: the 256-tile kernel's C tile with plain instead of non-temporal stores
+#endif
+#if YG_TIME
+#define YG_T(var) __builtin_amdgcn_sched_barrier(0); const unsigned long long var = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0);
+#define YG_TACC(slot, t1, t0) ytacc[slot] += (t1) - (t0);
+unsigned long long* g_yg_tbuf = nullptr;
+extern "C" void fcd_wino_gemm_time_buf(void* p) { g_yg_tbuf = (unsigned long long*)p; }
+#else
+#define YG_T(var)
+#define YG_TACC(slot, t1, t0)
+#endif
 #ifndef FCD_YEXP
 #define FCD_YEXP 4
 #endif
@@ -1226,6 +1247,10 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split256_kernel(WinoGemmArgs
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+#if YG_TIME
+  unsigned long long ytacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  YG_T(y_begin)
   int fq = 0, fb = 0;
 #define Y_DMA(SA, SB)                                                                            \
   {                                                                                              \
@@ -1255,6 +1280,7 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split256_kernel(WinoGemmArgs
   Y_MFMA(IH, AL, BH) Y_MFMA(IH, AH, BL) Y_MFMA(IH, AM, BM_) Y_MFMA(IH, AM, BH) Y_MFMA(IH, AH, BM_) Y_MFMA(IH, AH, BH)
 #define Y_STEP(SA, SB, SAN, SBN)                                                                 \
   {                                                                                              \
+    YG_T(ys0)                                                                                    \
     if (!(FCD_SEXP & 8) && !(FCD_YEXP & 14)) if (fb < nb) Y_DMA(SAN, SBN)                         \
     f32x4 xa[2][2];                                                                              \
     u32x4 pah[2], pam[2], pal[2], qah[2], qam[2], qal[2];                                        \
@@ -1270,6 +1296,7 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split256_kernel(WinoGemmArgs
       xa[j][1] = (FCD_SEXP & 32) ? f32x4{(float)j, 3.f, (float)lane, 2.f} : *(const f32x4*)((SB) + boff[j] + ((3 ^ swb) * 4)); \
     }                                                                                            \
     if (FCD_YEXP & 1) __builtin_amdgcn_s_setprio(2);                                             \
+    YG_T(ys1)                                                                                    \
     Y_SIX(0, pah, pam, pal, bh0, bm0, bl0)                                                       \
     if ((FCD_YEXP & 2) && !(FCD_SEXP & 8)) if (fb < nb) Y_DMA(SAN, SBN)                          \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) WS_SPLIT(xa[j][0], xa[j][1], bh1[j], bm1[j], bl1[j]) \
@@ -1307,7 +1334,12 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split256_kernel(WinoGemmArgs
     __builtin_amdgcn_sched_group_barrier(0x008, 36, 0);                                          \
     __builtin_amdgcn_sched_barrier(0);                                                           \
     if (FCD_YEXP & 1) __builtin_amdgcn_s_setprio(0);                                             \
+    YG_T(ys2)                                                                                    \
+    if (YG_TIME) __builtin_amdgcn_s_waitcnt(0x0F70);        /* vmcnt(0): the wave's share of the next stage's LDS-DMA has landed */ \
+    YG_T(ys2b)                                                                                   \
     __syncthreads();                                                                             \
+    YG_T(ys3)                                                                                    \
+    YG_TACC(0, ys1, ys0) YG_TACC(1, ys2, ys1) YG_TACC(2, ys3, ys2b) YG_TACC(4, ys2b, ys2)         \
   }
 
   Y_DMA(sa0, sb0)
@@ -1318,6 +1350,7 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split256_kernel(WinoGemmArgs
       Y_STEP(sa0, sb0, sa1, sb1)
       if (qc + 1 < Q) Y_STEP(sa1, sb1, sa0, sb0)
     }
+    YG_T(yc0)
     if (a.c_blk) {
       float* Cb = a.C + (size_t)(b_first + cb) * a.c_batch;
 #pragma unroll
@@ -1330,11 +1363,13 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split256_kernel(WinoGemmArgs
 #pragma unroll
             for (int g = 0; g < 4; ++g)
               { const f32x4 cv_ = f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                __builtin_nontemporal_store(cv_, (f32x4*)(blk + g * 128)); }      /* M is consumed once, by the output transform: measured -2 ... -4 % on the 256-row launches and their output transforms; the 128-row kernels lose with the same hint */
+                if (YG_PLAINC) *(f32x4*)(blk + g * 128) = cv_; else __builtin_nontemporal_store(cv_, (f32x4*)(blk + g * 128)); }      /* M is consumed once, by the output transform: measured -2 ... -4 % on the 256-row launches and their output transforms; the 128-row kernels lose with the same hint */
           }
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         }
+      YG_T(yc1)
+      YG_TACC(3, yc1, yc0)
       continue;
     }
     int ldc = a.N;
@@ -1353,6 +1388,17 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split256_kernel(WinoGemmArgs
         }
       }
   }
+#if YG_TIME
+  {
+    const unsigned long long y_end = __builtin_readcyclecounter();
+    ytacc[6] = y_end - y_begin;
+    if (a.tbuf && lane == 0) {
+      const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a.tbuf[(wg * NW + wave) * 8 + i] = ytacc[i];
+    }
+  }
+#endif
 #undef Y_STEP
 #undef Y_SIX
 #undef Y_MFMA
@@ -1615,7 +1661,12 @@ static void wino_gemm_launch(WinoGemmArgs ga, int batches, int splits, hipStream
       ga.xb = wino_gemm_xb((long long)ga.m_tiles * ga.n_tiles * 2, batches, 1, ga.Kc / 32);
       const dim3 grid((unsigned)(ga.m_tiles * ga.n_tiles), (unsigned)cdiv(batches, ga.xb));
       if (big >= 4) hipLaunchKernelGGL((wino_gemm_split_pp_kernel<0>), grid, dim3(512), 0, st, ga);
-      else hipLaunchKernelGGL((wino_gemm_split256_kernel<0>), grid, dim3(512), 0, st, ga);
+      else {
+#if YG_TIME
+        ga.tbuf = g_yg_tbuf;
+#endif
+        hipLaunchKernelGGL((wino_gemm_split256_kernel<0>), grid, dim3(512), 0, st, ga);
+      }
       return;
     }
     ga.m_tiles = cdiv(ga.M, 128); ga.n_tiles = cdiv(ga.N, 128);
