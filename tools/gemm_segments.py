@@ -38,8 +38,8 @@ def main():
     s = ops._stream()
     tbuf = torch.zeros(1 << 21, dtype=torch.int64, device='cuda')         # [workgroup][8 waves][8]
     L = ['# 256-tile split GEMM: where a wave\'s cycles go (s_memtime stamps, tools/gemm_segments.py)', '',
-         'Attribution build (-DYG_TIME=1: the stamps are scheduling fences and wait for the wave\'s outstanding LDS reads; launch times are a few % above',
-         'the product build).  Forward Winograd calls of the perception VGG on %d band images; one workgroup (8 waves, 256 x 256 tile) resident per CU; a' % N,
+         'Attribution build (-DYG_TIME=1: the stamps are scheduling fences and wait for the wave\'s outstanding LDS reads; launch times are 20 - 25 % above',
+         'the product build: read the SHARES, not the microseconds).  Forward Winograd calls of the perception VGG on %d band images; one workgroup (8 waves, 256 x 256 tile) resident per CU; a' % N,
          'stage = 32 reduction elements = 96 MFMAs per wave.  One counter tick is calibrated against the launch time (workgroups run back to back on a CU).', '']
     for tag, C, HW, K in (('conv3_x  256 -> 256 @ 64 x 64', 256, 64, 256), ('conv4_x  512 -> 512 @ 32 x 32', 512, 32, 512),
                           ('conv3_1  128 -> 256 @ 64 x 64', 128, 64, 256)):
