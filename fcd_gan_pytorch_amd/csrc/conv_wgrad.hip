@@ -137,7 +137,25 @@ struct WgradArgs {
   int tiles_q, total_tiles, tiles_per_split;
   int c_tiles;
   long long split_stride;
+  int tkc;                      // [r4] split partials as [tap][K][C] (lanes along C: 128-B runs) instead of dw's [K][C][tap], where the 64 lanes
+                                //      of a store hit 64 different 36-B filters; the split reduction writes dw's layout
+  unsigned long long* tbuf;     // WG_TIME builds
 };
+
+// WG_TIME: attribution build of the generic weight-gradient kernel (tools/wgrad_segments.py): per-wave cycle sums {prologue, LDS-DMA issue
+// of the next tile, MFMA loop, barrier (+ wait for that DMA), epilogue, -, total} in a debug buffer.  Never defined in the product build.
+#ifndef WG_TIME
+#define WG_TIME 0
+#endif
+#if WG_TIME
+#define WG_T(var) __builtin_amdgcn_sched_barrier(0); const unsigned long long var = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0);
+#define WG_TACC(slot, t1, t0) wtacc[slot] += (t1) - (t0);
+unsigned long long* g_wg_tbuf = nullptr;
+extern "C" void fcd_wgrad_time_buf(void* p) { g_wg_tbuf = (unsigned long long*)p; }
+#else
+#define WG_T(var)
+#define WG_TACC(slot, t1, t0)
+#endif
 
 template <int R, int S, int RB, int STRIDE, int TW>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
@@ -160,6 +178,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
   const int split = blockIdx.y;
   const int sub = lane >> 4, col4 = (lane & 15) * 4;   // position within an instruction, channel quad
 
+#if WG_TIME
+  unsigned long long wtacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  WG_T(w_begin)
   f32x16 acc[T];
 #pragma unroll
   for (int t = 0; t < T; ++t)
@@ -206,9 +228,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
     FCD_WG_STAGE(tile_beg, 0)
   }
   __syncthreads();
+  WG_T(w_loop)
+  WG_TACC(0, w_loop, w_begin)
   int buf = 0;
   for (int tile = tile_beg; tile < tile_end; ++tile) {
+    WG_T(ws0)
     if (tile + 1 < tile_end) FCD_WG_STAGE(tile + 1, buf ^ 1)
+    WG_T(ws1)
     const float* xs = smem + buf * (XS_SZ + DYS_SZ);
     const float* a_base = xs + XS_SZ + half * 64 + wm * 32 + l31;
     const float* b_base = xs + half * STRIDE * 64 + wc * 32 + l31;
@@ -223,10 +249,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
           acc[rl * S + s] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[rl * S + s], 0, 0, 0);
         }
     }
+    WG_T(ws2)
     __syncthreads();
+    WG_T(ws3)
+    WG_TACC(1, ws1, ws0) WG_TACC(2, ws2, ws1) WG_TACC(3, ws3, ws2)
     buf ^= 1;
   }
 #undef FCD_WG_STAGE
+  WG_T(w_epi)
 
   float* out = a.out + (size_t)split * a.split_stride;
   const int c = c0 + wc * 32 + l31;
@@ -237,10 +267,21 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int ko = ko0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
-        if (ko < a.K) out[(((size_t)ko * a.C + c) * R + r) * S + s] = acc[t][reg];
+        if (ko < a.K) out[a.tkc ? ((size_t)(r * S + s) * a.K + ko) * a.C + c : (((size_t)ko * a.C + c) * R + r) * S + s] = acc[t][reg];
       }
     }
   }
+#if WG_TIME
+  {
+    const unsigned long long w_end = __builtin_readcyclecounter();
+    wtacc[4] = w_end - w_epi; wtacc[6] = w_end - w_begin;
+    if (a.tbuf && lane == 0) {
+      const size_t wg = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a.tbuf[(wg * 4 + wave) * 8 + i] = wtacc[i];
+    }
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -369,7 +410,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_roll_kernel(WgradArgs a) {
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int ko = ko0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
-        if (ko < a.K) out[(((size_t)ko * a.C + c) * 3 + t / 3) * 3 + t % 3] = acc[t][reg];
+        if (ko < a.K) out[a.tkc ? ((size_t)t * a.K + ko) * a.C + c : (((size_t)ko * a.C + c) * 3 + t / 3) * 3 + t % 3] = acc[t][reg];
       }
     }
   }
@@ -377,8 +418,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_roll_kernel(WgradArgs a) {
 
 // dw = sum over split-K partials (fixed order => deterministic).  float4 streams, four independent
 // loads in flight per partial; n4 = n / 4 vectors, the (n % 4) tail is handled by the last threads.
+// (kc > 0: the partials are laid out [tap][K][C], kc = K * C, rs = taps: element e goes to dw[(e % kc) * rs + e / kc])
+__device__ __forceinline__ long long wgrad_dst(long long e, long long kc, int rs) { return kc > 0 ? (e % kc) * rs + e / kc : e; }
+
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
-                                                           long long n, int splits) {
+                                                           long long n, int splits, long long kc = 0, int rs = 1) {
   typedef float v4 __attribute__((ext_vector_type(4)));
   const long long n4 = n >> 2;
   const long long stride = (long long)gridDim.x * blockDim.x;
@@ -388,14 +432,19 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
       v4 s = *(const v4*)(part + 4 * i);
       for (int k = 1; k < splits; ++k) s += *(const v4*)(part + (long long)k * n + 4 * i);
-      *(v4*)(dw + 4 * i) = s;
+      if (kc > 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dw[wgrad_dst(4 * i + e, kc, rs)] = s[e];
+      } else {
+        *(v4*)(dw + 4 * i) = s;
+      }
     }
     return;
   }
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     float s = 0.f;
     for (int k = 0; k < splits; ++k) s += part[(long long)k * n + i];
-    dw[i] = s;
+    dw[wgrad_dst(i, kc, rs)] = s;
   }
 }
 
@@ -403,7 +452,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // block, the partials dealt round-robin to 4 groups of 64 threads (4 loads in flight each), group
 // sums combined in fixed order through LDS => deterministic.
 __global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(const float* __restrict__ part, float* __restrict__ dw,
-                                                                long long n, int splits) {
+                                                                long long n, int splits, long long kc = 0, int rs = 1) {
   typedef float v4 __attribute__((ext_vector_type(4)));
   __shared__ v4 red[4][64];
   const int tx = threadIdx.x & 63, g = threadIdx.x >> 6;
@@ -425,7 +474,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(const float* __r
   if (g == 0 && i < n4) {
     v4 t = red[0][tx];
     t += red[1][tx]; t += red[2][tx]; t += red[3][tx];
-    *(v4*)(dw + 4 * i) = t;
+    if (kc > 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dw[wgrad_dst(4 * i + e, kc, rs)] = t[e];
+    } else {
+      *(v4*)(dw + 4 * i) = t;
+    }
   }
 }
 
@@ -489,6 +543,19 @@ struct WgradPlan {
   size_t xt_bytes, dyt_bytes, part_bytes, zero_bytes, psum_bytes;
 };
 
+// Workgroups the split count aims at (FCD_WGRAD_WGS for A/B).  [r4] 512 = ONE round of the 512 resident slots (two 59-KB workgroups per CU):
+// every workgroup pays a prologue and a 147-KB partial store, and every split adds a pass to the reduction -- 1024 (rounds 1-3) measured
+// 0.30 / 0.25 / 0.23 ms on the Discriminator's stride-2 layers against 0.27 / 0.23 / 0.21 with 512, 2048: 0.36 / 0.33 / 0.29.
+static int wgrad_target_wgs() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("FCD_WGRAD_WGS");
+    v = e ? atoi(e) : 512;
+    if (v < 1) v = 512;
+  }
+  return v;
+}
+
 static bool wgrad_plan(const fcd_conv_desc* d, WgradPlan* pl) {
   const int R = d->R, S = d->S, st = d->stride;
   if (R == 3 && S == 3 && st == 1) { pl->TW = 32; pl->RB = 3; }
@@ -506,7 +573,7 @@ static bool wgrad_plan(const fcd_conv_desc* d, WgradPlan* pl) {
   pl->Cp = pl->c_tiles * 64;
   pl->Kp = pl->k_tiles * 64;
   const int base = pl->k_tiles * pl->c_tiles * pl->r_groups;
-  int splits = cdiv(1024, base);
+  int splits = cdiv(wgrad_target_wgs(), base);
   const long long dw_bytes = 4LL * d->K * d->C * R * S;
   const long long cap = std::max<long long>(1, (512LL << 20) / dw_bytes);
   if (splits > cap) splits = (int)cap;
@@ -543,6 +610,15 @@ extern "C" size_t fcd_conv2d_bwd_weight_ws_bytes(const fcd_conv_desc* d) {
                            fcd_wino_wgrad_ws_bytes(d)), fcd_wgrad_thin_ws_bytes(d));
 }
 
+static int wgrad_tkc() {       // FCD_WGRAD_TKC=0: split partials in dw's own layout (round-3 behaviour)
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("FCD_WGRAD_TKC");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v;
+}
+
 static int wgrad_roll() {
   static int v = -1;
   if (v < 0) {
@@ -555,7 +631,13 @@ static int wgrad_roll() {
 template <int R, int S, int RB, int STRIDE, int TW>
 static void launch_wgrad(const WgradArgs& a, const WgradPlan& pl, hipStream_t st) {
   dim3 grid((unsigned)(pl.k_tiles * pl.c_tiles), (unsigned)pl.splits, (unsigned)pl.r_groups);
+#if WG_TIME
+  WgradArgs b = a;
+  b.tbuf = g_wg_tbuf;
+  hipLaunchKernelGGL((conv_wgrad_kernel<R, S, RB, STRIDE, TW>), grid, dim3(256), 0, st, b);
+#else
   hipLaunchKernelGGL((conv_wgrad_kernel<R, S, RB, STRIDE, TW>), grid, dim3(256), 0, st, a);
+#endif
 }
 
 extern "C" int fcd_conv2d_bwd_weight_bias(const fcd_conv_desc* d, const float* x, const float* dy,
@@ -632,6 +714,7 @@ extern "C" int fcd_conv2d_bwd_weight_bias(const fcd_conv_desc* d, const float* x
   a.tiles_q = pl.tiles_q; a.total_tiles = pl.total_tiles;
   a.tiles_per_split = pl.tiles_per_split; a.c_tiles = pl.c_tiles;
   a.split_stride = (long long)d->K * d->C * d->R * d->S;
+  a.tkc = (pl.splits > 1 && wgrad_tkc()) ? 1 : 0;
   const int R = d->R, S = d->S, sd = d->stride;
   const bool narrow = pl.TW == 16;
   if (R == 3 && S == 3 && sd == 1 && d->pad == 1 && wgrad_roll()) {
@@ -655,10 +738,11 @@ extern "C" int fcd_conv2d_bwd_weight_bias(const fcd_conv_desc* d, const float* x
     const long long n = a.split_stride;
     if (pl.splits >= 8 && (n & 3) == 0 && (((size_t)part | (size_t)dw) & 15) == 0) {
       hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3((unsigned)cdiv64(n >> 2, 64)), dim3(256), 0, st,
-                         (const float*)part, dw, n, pl.splits);
+                         (const float*)part, dw, n, pl.splits, a.tkc ? (long long)d->K * d->C : 0LL, d->R * d->S);
     } else {
       const int grid = (int)std::min<long long>(cdiv64(cdiv64(n, 4), 256), 4096);
-      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, (const float*)part, dw, n, pl.splits);
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, (const float*)part, dw, n, pl.splits,
+                         a.tkc ? (long long)d->K * d->C : 0LL, d->R * d->S);
     }
     FCD_LAUNCH_CHECK("wgrad_reduce");
   }
