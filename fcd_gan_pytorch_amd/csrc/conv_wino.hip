@@ -2580,7 +2580,9 @@ int fcd_wino_wgrad_plan(const fcd_conv_desc* d, WinoWgPlan* pl) {
   pl->Tpad = (pl->T + 31) / 32 * 32;
   pl->stages = (int)(pl->Tpad / 32);
   const int blocks = cdiv(d->K, 128) * cdiv(d->C, 128) * 36;
-  int splits = cdiv(1536, blocks);
+  static int wg_wgs = -1;             // FCD_WINO_WG_WGS: workgroups the reduction split aims at
+  if (wg_wgs < 0) { const char* e = getenv("FCD_WINO_WG_WGS"); wg_wgs = e ? atoi(e) : 1024; if (wg_wgs < 1) wg_wgs = 1024; }   // [r4] 1024 (was 1536): -2 % over the Segmentor's 16 layers
+  int splits = cdiv(wg_wgs, blocks);
   if (splits > pl->stages) splits = pl->stages;
   if (splits > 64) splits = 64;
   if (splits < 1) splits = 1;
