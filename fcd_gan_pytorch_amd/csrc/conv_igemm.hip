@@ -64,7 +64,24 @@ struct ConvArgs {
   // sub-pixel epilogue (register-staged kernel; data gradient of stride-2 convolutions): output row ko = cls * shuf_C + c of
   // the pseudo-convolution is pixel (2 p + (cls >> 1), 2 q + (cls & 1)) of channel c of a (N, shuf_C, shuf_H, shuf_W) tensor
   int shuf_C, shuf_H, shuf_W;
+  unsigned long long* tbuf;   // IG_TIME builds
 };
+
+// IG_TIME: attribution build of the register-staged implicit-GEMM kernel (tools/igemm_segments.py): per-wave cycle sums {prologue, global
+// loads of the next step issued, MFMA block, first barrier, LDS commit of the next step (waits for its loads), second barrier, epilogue,
+// total} in a debug buffer.  Never defined in the product build.
+#ifndef IG_TIME
+#define IG_TIME 0
+#endif
+#if IG_TIME
+#define IG_T(var) __builtin_amdgcn_sched_barrier(0); const unsigned long long var = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0);
+#define IG_TACC(slot, t1, t0) itacc[slot] += (t1) - (t0);
+unsigned long long* g_ig_tbuf = nullptr;
+extern "C" void fcd_igemm_time_buf(void* p) { g_ig_tbuf = (unsigned long long*)p; }
+#else
+#define IG_T(var)
+#define IG_TACC(slot, t1, t0)
+#endif
 
 template <int R, int S, int RCH, int STRIDE, int DIL, int CB, int MI, int NI, int WM, int WN, int TH,
           int TW>
@@ -89,6 +106,10 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_kernel(ConvArgs a) {
   float* Ws = smem;
   float* Xs = smem + KC * BM;
 
+#if IG_TIME
+  unsigned long long itacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  IG_T(i_begin)
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
@@ -209,8 +230,11 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_kernel(ConvArgs a) {
   FCD_STORE_X()
   FCD_STORE_W()
   __syncthreads();
+  IG_T(i_loop)
+  IG_TACC(0, i_loop, i_begin)
 
   for (int step = 0; step < nsteps; ++step) {
+    IG_T(is0)
     const int nxt = step + 1;
     const int rr = (NR == 1) ? 0 : step % NR;
     const bool have_next = nxt < nsteps;
@@ -219,6 +243,7 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_kernel(ConvArgs a) {
       if (next_patch) FCD_LOAD_X(nxt / NR)
       FCD_LOAD_W(nxt / NR, (NR == 1) ? 0 : nxt % NR)
     }
+    IG_T(is1)
 
     const float* wl = Ws + woff;
     const float* xl = Xs + rr * RCH * PWP;
@@ -242,13 +267,19 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_kernel(ConvArgs a) {
         }
       }
     }
+    IG_T(is2)
     __syncthreads();
+    IG_T(is3)
     if (have_next) {
       if (next_patch) FCD_STORE_X()
       FCD_STORE_W()
     }
+    IG_T(is4)
     __syncthreads();
+    IG_T(is5)
+    IG_TACC(1, is1, is0) IG_TACC(2, is2, is1) IG_TACC(3, is3, is2) IG_TACC(4, is4, is3) IG_TACC(5, is5, is4)
   }
+  IG_T(i_epi)
 #undef FCD_LOAD_W
 #undef FCD_STORE_W
 #undef FCD_LOAD_X
@@ -284,6 +315,17 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_kernel(ConvArgs a) {
       }
     }
   }
+#if IG_TIME
+  {
+    const unsigned long long i_end = __builtin_readcyclecounter();
+    itacc[6] = i_end - i_epi; itacc[7] = i_end - i_begin;
+    if (a.tbuf && lane == 0) {
+      const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a.tbuf[(wg * 4 + wave) * 8 + i] = itacc[i];
+    }
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -894,6 +936,9 @@ static int launch_cfg(const ConvArgs& a0, hipStream_t st) {
     return -1;
   } else {
     a.nchunks = cdiv(a.C, CB);
+#if IG_TIME
+    a.tbuf = g_ig_tbuf;
+#endif
     hipLaunchKernelGGL((conv_igemm_kernel<R, S, RCH, STRIDE, DIL, CB, MI, NI, WM, WN, TH, TW>), grid,
                        dim3(256), 0, st, a);
     return 0;
