@@ -22,6 +22,9 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef WT_XPRE
+#define WT_XPRE 0     // 1: also the input patch of the stride-1 layer through registers (14 per thread) -- spills, measured slower (0.38 vs 0.30 ms)
+#endif
 namespace {
 constexpr int WT_TH = 2, WT_TW = 64;            // output pixels per tile
 constexpr int WT_DYP = WT_TH * WT_TW + 4;       // dY row pitch (floats); 16-B aligned rows for the float4 stores (column reads: 4-way, off the critical path)
@@ -74,59 +77,103 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_thin_kernel(WgThinArgs a) {
       for (int r = 0; r < 16; ++r) acc[i][b][r] = 0.f;
 
   const size_t x_plane = (size_t)a.H * a.W, y_plane = (size_t)a.P * a.Q;
-  for (int t = blockIdx.x; t < a.total_tiles; t += gridDim.x) {
+  // [r4] The next tile's dY slab and input patch are requested into registers BEFORE the MFMA block of the current tile and
+  // committed to LDS behind it (the kernel used to load, wait, store and only then multiply: two workgroups per CU were all that
+  // hid the loads).
+  constexpr int DY_PER_T = (WT_ROWS * WT_TH * WT_TW / 4) / 256;        // 8 float4
+  constexpr bool XPRE = STRIDE == 1 && WT_XPRE;                                   // (the 5 x 129 patch of the stride-2 layer does not fit the registers: 36 per thread)
+  constexpr int X_PER_T = XPRE ? (CMAX * XR * XC + 255) / 256 : 1;
+  const bool vec = (a.Q & 3) == 0;
+  const int xtotal = a.C * XR * XC;
+  f32x4 dyr[DY_PER_T];
+  float xr[X_PER_T];
+  auto issue = [&](int t) {
     const int tq = t % a.tiles_q;
     const int tp = (t / a.tiles_q) % a.tiles_p;
     const int n = t / (a.tiles_q * a.tiles_p);
     const int p0 = tp * WT_TH, q0 = tq * WT_TW;
-    __syncthreads();                                       // previous tile fully consumed
-    // ---- dY tile: 64 rows (k) x 2 x 64 pixels, float4 where the row allows it
-    {
-      const float* dyn = a.dy + (size_t)n * a.K * y_plane;
-      const float* mn = a.mask ? a.mask + (size_t)n * a.K * y_plane : nullptr;
-      const bool vec = (a.Q & 3) == 0;
+    const float* dyn = a.dy + (size_t)n * a.K * y_plane;
+    const float* mn = a.mask ? a.mask + (size_t)n * a.K * y_plane : nullptr;
 #pragma unroll
-      for (int j = 0; j < (WT_ROWS * WT_TH * WT_TW / 4) / 256; ++j) {
-        const int idx = tid + 256 * j;                     // (k, row, 16 float4)
-        const int c4 = idx & 15, row = (idx >> 4) & (WT_TH - 1), k = idx >> 5;
-        const int p = p0 + row, q = q0 + 4 * c4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (k < a.K && p < a.P && q < a.Q) {
-          const size_t off = (size_t)k * y_plane + (size_t)p * a.Q + q;
-          if (vec) {
-            v = *(const f32x4*)(dyn + off);
-            if (mn) {
-              const f32x4 m = *(const f32x4*)(mn + off);
+    for (int j = 0; j < DY_PER_T; ++j) {
+      const int idx = tid + 256 * j;                     // (k, row, 16 float4)
+      const int c4 = idx & 15, row = (idx >> 4) & (WT_TH - 1), k = idx >> 5;
+      const int p = p0 + row, q = q0 + 4 * c4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (k < a.K && p < a.P && q < a.Q) {
+        const size_t off = (size_t)k * y_plane + (size_t)p * a.Q + q;
+        if (vec) {
+          v = *(const f32x4*)(dyn + off);
+          if (mn) {
+            const f32x4 m = *(const f32x4*)(mn + off);
 #pragma unroll
-              for (int e = 0; e < 4; ++e) if (!(m[e] > 0.f)) v[e] = 0.f;
-            }
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (q + e < a.Q) {
-                float s = dyn[off + e];
-                if (mn && !(mn[off + e] > 0.f)) s = 0.f;
-                v[e] = s;
-              }
+            for (int e = 0; e < 4; ++e) if (!(m[e] > 0.f)) v[e] = 0.f;
           }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (q + e < a.Q) {
+              float sv = dyn[off + e];
+              if (mn && !(mn[off + e] > 0.f)) sv = 0.f;
+              v[e] = sv;
+            }
         }
-        *(f32x4*)(sdy + k * WT_DYP + row * WT_TW + 4 * c4) = v;
       }
+      dyr[j] = v;
     }
-    // ---- input patch: C x XR x XC, zero outside the image
-    {
+    if (XPRE) {
       const float* xn = a.x + (size_t)n * a.C * x_plane;
       const int ih0 = p0 * STRIDE - 1, iw0 = q0 * STRIDE - 1;
-      const int total = a.C * XR * XC;
-      for (int idx = tid; idx < total; idx += 256) {
-        const int j = idx % XC, rr = (idx / XC) % XR, c = idx / (XC * XR);
-        const int ih = ih0 + rr, iw = iw0 + j;
+#pragma unroll
+      for (int j = 0; j < X_PER_T; ++j) {
+        const int idx = tid + 256 * j;
         float v = 0.f;
-        if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) v = xn[(size_t)c * x_plane + (size_t)ih * a.W + iw];
-        sx[(c * XR + rr) * XP + j] = v;
+        if (idx < xtotal) {
+          const int jj = idx % XC, rr = (idx / XC) % XR, c = idx / (XC * XR);
+          const int ih = ih0 + rr, iw = iw0 + jj;
+          if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) v = xn[(size_t)c * x_plane + (size_t)ih * a.W + iw];
+        }
+        xr[j] = v;
       }
     }
+  };
+  auto commit = [&](int t) {
+#pragma unroll
+    for (int j = 0; j < DY_PER_T; ++j) {
+      const int idx = tid + 256 * j;
+      const int c4 = idx & 15, row = (idx >> 4) & (WT_TH - 1), k = idx >> 5;
+      *(f32x4*)(sdy + k * WT_DYP + row * WT_TW + 4 * c4) = dyr[j];
+    }
+    if (XPRE) {
+#pragma unroll
+      for (int j = 0; j < X_PER_T; ++j) {
+        const int idx = tid + 256 * j;
+        if (idx < xtotal) {
+          const int jj = idx % XC, rr = (idx / XC) % XR, c = idx / (XC * XR);
+          sx[(c * XR + rr) * XP + jj] = xr[j];
+        }
+      }
+    } else {
+      const int tq = t % a.tiles_q;
+      const int tp = (t / a.tiles_q) % a.tiles_p;
+      const int n = t / (a.tiles_q * a.tiles_p);
+      const float* xn = a.x + (size_t)n * a.C * x_plane;
+      const int ih0 = tp * WT_TH * STRIDE - 1, iw0 = tq * WT_TW * STRIDE - 1;
+      for (int idx = tid; idx < xtotal; idx += 256) {
+        const int jj = idx % XC, rr = (idx / XC) % XR, c = idx / (XC * XR);
+        const int ih = ih0 + rr, iw = iw0 + jj;
+        float v = 0.f;
+        if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) v = xn[(size_t)c * x_plane + (size_t)ih * a.W + iw];
+        sx[(c * XR + rr) * XP + jj] = v;
+      }
+    }
+  };
+  if ((int)blockIdx.x < a.total_tiles) issue(blockIdx.x);
+  for (int t = blockIdx.x; t < a.total_tiles; t += gridDim.x) {
+    __syncthreads();                                       // previous tile fully consumed
+    commit(t);
     __syncthreads();
+    if (t + (int)gridDim.x < a.total_tiles) issue(t + gridDim.x);
     // ---- 16 pixel pairs of this wave x 8 MFMAs
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
