@@ -603,11 +603,17 @@ size_t fcd_wgrad_thin_ws_bytes(const fcd_conv_desc* d);
 int fcd_wgrad_thin_run(const fcd_conv_desc* d, const float* x, const float* dy, const float* relu_out, float* dw, float* db,
                        void* ws, hipStream_t st);
 
+// conv_wgrad_thin9.hip [r4]: the 9x9 layers with <= 4 channels on one side (the Generator's first / last convolution on 3- / 4-band data)
+int fcd_wgrad_thin9_plan(const fcd_conv_desc* d);
+size_t fcd_wgrad_thin9_ws_bytes(const fcd_conv_desc* d);
+int fcd_wgrad_thin9_run(const fcd_conv_desc* d, const float* x, const float* dy, const float* relu_out, float* dw, float* db,
+                        void* ws, hipStream_t st);
+
 extern "C" size_t fcd_conv2d_bwd_weight_ws_bytes(const fcd_conv_desc* d) {
   WgradPlan pl;
   if (!d || !wgrad_plan(d, &pl)) return 0;
-  return std::max(std::max(pl.zero_bytes + pl.xt_bytes + pl.dyt_bytes + pl.part_bytes + pl.psum_bytes,
-                           fcd_wino_wgrad_ws_bytes(d)), fcd_wgrad_thin_ws_bytes(d));
+  return std::max(std::max(std::max(pl.zero_bytes + pl.xt_bytes + pl.dyt_bytes + pl.part_bytes + pl.psum_bytes,
+                                    fcd_wino_wgrad_ws_bytes(d)), fcd_wgrad_thin_ws_bytes(d)), fcd_wgrad_thin9_ws_bytes(d));
 }
 
 static int wgrad_tkc() {       // FCD_WGRAD_TKC=0: split partials in dw's own layout (round-3 behaviour)
@@ -674,6 +680,13 @@ extern "C" int fcd_conv2d_bwd_weight_bias(const fcd_conv_desc* d, const float* x
   FcdProfScope prof(FCD_K_CONV_WGRAD, st, flops, bytes, fcd_prof_tag_desc("wgrad", d));
   if (fcd_wino_wgrad_ws_bytes(d) > 0 && fcd_wino_wgrad_run(d, x, dy, relu_out, dw, db, ws, st) == 0) {
     FCD_LAUNCH_CHECK("conv2d_bwd_weight(winograd)");
+    return FCD_OK;
+  }
+  if (fcd_wgrad_thin9_plan(d)) {
+    if (fcd_wgrad_thin9_run(d, x, dy, relu_out, dw, db, ws, st) != 0) {
+      fcd_set_error("fcd_conv2d_bwd_weight: 9x9 thin-channel kernel launch failed");
+      return FCD_ERR_LAUNCH;
+    }
     return FCD_OK;
   }
   if (fcd_wgrad_thin_plan(d)) {

@@ -71,6 +71,12 @@ CONV_CASES = [
     (2, 13, 96, 130, 64, 3, 2, 1),
     (4, 3, 64, 64, 64, 3, 2, 1),
     (1, 14, 66, 64, 33, 3, 1, 1),
+    # 9x9 weight gradient with <= 4 channels on one side (conv_wgrad_thin9.hip: N P Q >= 4096): first-layer form (bands -> filters) and
+    # last-layer form (filters -> bands, operands swapped, taps un-flipped), ragged tiles, rows that are not float4 multiples
+    (2, 4, 72, 136, 64, 9, 1, 4),
+    (3, 3, 55, 70, 48, 9, 1, 4),
+    (2, 64, 66, 64, 4, 9, 1, 4),
+    (2, 40, 50, 130, 3, 9, 1, 4),
     # filter-resident split GEMM (one 128-row tile, Kc <= 128, >= 512 column-tile x position work items): two and three
     # reduction stages, a ragged last column tile
     (4, 64, 128, 128, 128, 3, 1, 1),
