@@ -206,19 +206,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin9_finish_kernel(const floa
   }
 }
 
-// db[k] = sum_{n,p,q} dY[n,k,p,q] (* [mask > 0]) for the last-layer form (<= 4 filters): one workgroup per filter, fp64, fixed order
-__global__ __launch_bounds__(256) void thin9_bias_kernel(const float* __restrict__ dy, const float* __restrict__ mask, float* __restrict__ db,
-                                                         int N, int K, int HW) {
+// db[k] = sum_{n,p,q} dY[n,k,p,q] (* [mask > 0]) for the last-layer form (<= 4 filters): grid (K, T9_BSPLIT) fp64 partials over
+// (sample, pixel) chunks, then one thread per filter adds them in a fixed order
+constexpr int T9_BSPLIT = 128;
+__global__ __launch_bounds__(256) void thin9_bias_part_kernel(const float* __restrict__ dy, const float* __restrict__ mask,
+                                                              double* __restrict__ part, int N, int K, int HW) {
   __shared__ double red[256];
-  const int k = blockIdx.x;
+  const int k = blockIdx.x, sp = blockIdx.y;
+  const long long total = (long long)N * HW;
+  const long long chunk = (total + T9_BSPLIT - 1) / T9_BSPLIT;
+  const long long beg = sp * chunk, end = min(beg + chunk, total);
   double s = 0.0;
-  for (int n = 0; n < N; ++n) {
-    const size_t base = ((size_t)n * K + k) * HW;
-    for (int i = threadIdx.x; i < HW; i += 256) {
-      float v = dy[base + i];
-      if (mask && !(mask[base + i] > 0.f)) v = 0.f;
-      s += (double)v;
-    }
+  for (long long e = beg + threadIdx.x; e < end; e += 256) {
+    const int n = (int)(e / HW), i = (int)(e % HW);
+    const size_t off = ((size_t)n * K + k) * HW + i;
+    float v = dy[off];
+    if (mask && !(mask[off] > 0.f)) v = 0.f;
+    s += (double)v;
   }
   red[threadIdx.x] = s;
   __syncthreads();
@@ -226,7 +230,15 @@ __global__ __launch_bounds__(256) void thin9_bias_kernel(const float* __restrict
     if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
     __syncthreads();
   }
-  if (threadIdx.x == 0) db[k] = (float)red[0];
+  if (threadIdx.x == 0) part[(size_t)k * T9_BSPLIT + sp] = red[0];
+}
+
+__global__ void thin9_bias_fin_kernel(const double* __restrict__ part, float* __restrict__ db, int K) {
+  const int k = threadIdx.x;
+  if (k >= K) return;
+  double s = 0.0;
+  for (int i = 0; i < T9_BSPLIT; ++i) s += part[(size_t)k * T9_BSPLIT + i];
+  db[k] = (float)s;
 }
 
 int t9_env() {
@@ -250,7 +262,7 @@ int fcd_wgrad_thin9_plan(const fcd_conv_desc* d) {
 }
 
 size_t fcd_wgrad_thin9_ws_bytes(const fcd_conv_desc* d) {
-  return fcd_wgrad_thin9_plan(d) ? (size_t)T9_MAX_PARTS * T9_ROWS * T9_COLS * sizeof(float) : 0;
+  return fcd_wgrad_thin9_plan(d) ? (size_t)T9_MAX_PARTS * T9_ROWS * T9_COLS * sizeof(float) + T9_CMAX * T9_BSPLIT * sizeof(double) : 0;
 }
 
 int fcd_wgrad_thin9_run(const fcd_conv_desc* d, const float* x, const float* dy, const float* relu_out, float* dw, float* db,
@@ -277,7 +289,10 @@ int fcd_wgrad_thin9_run(const fcd_conv_desc* d, const float* x, const float* dy,
   hipLaunchKernelGGL(conv_wgrad_thin9_kernel, dim3(nparts), dim3(256), 0, st, a);
   hipLaunchKernelGGL(conv_wgrad_thin9_finish_kernel, dim3(T9_ROWS * T9_COLS / 256), dim3(256), 0, st, (const float*)ws, dw, db,
                      nparts, a.Cw, a.Ct, form == 2 ? 1 : 0);
-  if (form == 2 && db)
-    hipLaunchKernelGGL(thin9_bias_kernel, dim3(d->K), dim3(256), 0, st, dy, relu_out, db, d->N, d->K, d->P * d->Q);
+  if (form == 2 && db) {
+    double* bp = (double*)((char*)ws + (size_t)T9_MAX_PARTS * T9_ROWS * T9_COLS * sizeof(float));
+    hipLaunchKernelGGL(thin9_bias_part_kernel, dim3(d->K, T9_BSPLIT), dim3(256), 0, st, dy, relu_out, bp, d->N, d->K, d->P * d->Q);
+    hipLaunchKernelGGL(thin9_bias_fin_kernel, dim3(1), dim3(64), 0, st, (const double*)bp, db, d->K);
+  }
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
