@@ -310,6 +310,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_roll_kernel(WgradArgs a) {
   const int split = blockIdx.y;
   const int sub = lane >> 4, col4 = (lane & 15) * 4;
 
+#if WG_TIME
+  unsigned long long wtacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  WG_T(w_begin)
   f32x16 acc[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t)
@@ -364,8 +368,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_roll_kernel(WgradArgs a) {
     FCD_ROLL_LOAD_DY(n0, tq0, p0, 0)
   }
   __syncthreads();
+  WG_T(w_loop)
+  WG_TACC(0, w_loop, w_begin)
   int buf = 0;
   for (int tile = tile_beg; tile < tile_end; ++tile) {
+    WG_T(ws0)
     FCD_ROLL_DECODE(tile, n, tq, p)
     const bool have_next = tile + 1 < tile_end;
     const bool same_strip = have_next && (p + 1 < a.P);
@@ -374,6 +381,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_roll_kernel(WgradArgs a) {
       FCD_ROLL_LOAD_DY(nn, tqn, pn, buf ^ 1)
       if (same_strip) FCD_ROLL_LOAD_ROW(n, tq, p + 2)       // the one new row of the next tile
     }
+    WG_T(ws1)
     const float* a_base = dybuf + buf * DYS + half * 64 + wm * 32 + l31;
     const float* b0 = ring + ((p + 0) & 3) * SLOT + half * 64 + wc * 32 + l31;   // input row p-1
     const float* b1 = ring + ((p + 1) & 3) * SLOT + half * 64 + wc * 32 + l31;   // row p
@@ -388,7 +396,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_roll_kernel(WgradArgs a) {
         acc[6 + s] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b2[(2 * t2 + s) * 64], acc[6 + s], 0, 0, 0);
       }
     }
+    WG_T(ws2)
     __syncthreads();
+    WG_T(ws3)
+    WG_TACC(1, ws1, ws0) WG_TACC(2, ws2, ws1) WG_TACC(3, ws3, ws2)
     if (have_next && !same_strip) {      // strip change: (re)load the three rows of the new strip
       FCD_ROLL_DECODE(tile + 1, nn, tqn, pn)
       FCD_ROLL_LOAD_ROW(nn, tqn, pn - 1)
@@ -401,6 +412,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_roll_kernel(WgradArgs a) {
 #undef FCD_ROLL_DECODE
 #undef FCD_ROLL_LOAD_ROW
 #undef FCD_ROLL_LOAD_DY
+  WG_T(w_epi)
 
   float* out = a.out + (size_t)split * a.split_stride;
   const int c = c0 + wc * 32 + l31;
@@ -414,6 +426,17 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_roll_kernel(WgradArgs a) {
       }
     }
   }
+#if WG_TIME
+  {
+    const unsigned long long w_end = __builtin_readcyclecounter();
+    wtacc[4] = w_end - w_epi; wtacc[6] = w_end - w_begin;
+    if (a.tbuf && lane == 0) {
+      const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a.tbuf[(wg * 4 + wave) * 8 + i] = wtacc[i];
+    }
+  }
+#endif
 }
 
 // dw = sum over split-K partials (fixed order => deterministic).  float4 streams, four independent
@@ -733,6 +756,9 @@ extern "C" int fcd_conv2d_bwd_weight_bias(const fcd_conv_desc* d, const float* x
   if (R == 3 && S == 3 && sd == 1 && d->pad == 1 && wgrad_roll()) {
     // p-fastest tile order + rolling 4-row ring (see conv_wgrad_roll_kernel)
     dim3 grid((unsigned)(pl.k_tiles * pl.c_tiles), (unsigned)pl.splits, 1);
+#if WG_TIME
+    a.tbuf = g_wg_tbuf;
+#endif
     if (narrow) hipLaunchKernelGGL(conv_wgrad_roll_kernel<16>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(conv_wgrad_roll_kernel<32>, grid, dim3(256), 0, st, a);
   } else if (R == 3 && S == 3 && sd == 1) {

@@ -31,11 +31,11 @@ def main():
     tbuf = torch.zeros(1 << 21, dtype=torch.int64, device='cuda')
     L = ['# Generic direct weight-gradient kernel on the stride-2 layers: where a wave\'s cycles go (tools/wgrad_segments.py)', '',
          'Attribution build (-DWG_TIME=1).  4 waves per workgroup (64 k x 64 c x 9 taps), two workgroups resident per CU, one tile = 16 output positions.', '']
-    for tag, N, C, HW, K in (('D 64->128 s2 @128 (N=32)', 32, 64, 128, 128), ('D 128->256 s2 @64 (N=32)', 32, 128, 64, 256),
-                             ('D 256->512 s2 @32 (N=32)', 32, 256, 32, 512)):
+    for tag, N, C, HW, K, ST in (('G / S 64->64 @256 (N=16), rolling 3x3 kernel', 16, 64, 256, 64, 1), ('D 64->128 s2 @128 (N=32)', 32, 64, 128, 128, 2), ('D 128->256 s2 @64 (N=32)', 32, 128, 64, 256, 2),
+                             ('D 256->512 s2 @32 (N=32)', 32, 256, 32, 512, 2)):
         x = torch.randn(N, C, HW, HW, device='cuda')
         w = torch.randn(K, C, 3, 3, device='cuda') * 0.05
-        d = ops._desc(x.shape, w.shape, 2, 1)
+        d = ops._desc(x.shape, w.shape, ST, 1)
         dy = torch.randn(N, K, d.P, d.Q, device='cuda')
         dw = torch.empty_like(w)
         nb = lib.fcd_conv2d_bwd_weight_ws_bytes(ctypes.byref(d))
