@@ -126,6 +126,17 @@ class PerceptionLoss(nn.Module):
         i = 0
         while i < len(layers):
             layer = layers[i]
+            run = self._frozen_run(layers, i) if isinstance(layer, nn.Conv2d) and i > 0 else None
+            if run is not None and ops.frozen_chain_ok(z, [c.weight for c in run[0]]):
+                # conv + ReLU pairs up to the next max-pool / tapped activation as ONE node: the activations between them
+                # are never written (ops.frozen_conv_chain)
+                convs, pool, nxt = run
+                z = ops.frozen_conv_chain(z, [c.weight for c in convs], [c.bias for c in convs], pool=pool)
+                last = nxt - 1              # index of the entry that produced z (ReLU, or the fused max-pool)
+                if last in self.feature_layer_list:
+                    taps[last] = z
+                i = nxt
+                continue
             if isinstance(layer, nn.Conv2d):
                 fuse = i + 1 < len(layers) and isinstance(layers[i + 1], nn.ReLU)
                 # conv + bias + ReLU in one kernel (epilogue); the ReLU mask is re-derived from
@@ -149,6 +160,23 @@ class PerceptionLoss(nn.Module):
                 taps[i] = z
             i += 1
         return taps
+
+    def _frozen_run(self, layers, i):
+        """The run of (Conv2d, ReLU) pairs starting at entry ``i`` with no tapped activation inside: (convs, pool, next index),
+        ``pool`` = the run ends in a MaxPool2d that is fused into its last layer (only when that layer's ReLU is not tapped);
+        None for runs shorter than two layers or frozen-ness / bias conditions the chain does not cover."""
+        convs, k = [], i
+        while (k + 1 < len(layers) and isinstance(layers[k], nn.Conv2d) and isinstance(layers[k + 1], nn.ReLU)
+               and not layers[k].weight.requires_grad and layers[k].bias is not None and not layers[k].bias.requires_grad):
+            convs.append(layers[k])
+            k += 2
+            if (k - 1) in self.feature_layer_list:
+                break
+        if len(convs) < 2:
+            return None
+        pool = (k < len(layers) and isinstance(layers[k], nn.MaxPool2d) and (k - 1) not in self.feature_layer_list
+                and k not in self.feature_layer_list)
+        return convs, pool, (k + 1 if pool else k)
 
     def forward(self, target_image, generate_image, cmask, stacked=None):
         """``stacked``: ``masked_pair(target_image, generate_image, cmask)`` when the caller has it already (the criteria

@@ -88,6 +88,11 @@ _SIGS = {
     'fcd_conv_wino_relu_bits_bytes': (c_size_t, [POINTER(ConvDesc)]),
     'fcd_conv2d_fwd_wino_relu_bits': (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, c_size_t, P]),
     'fcd_conv2d_bwd_data_wino_bits': (c_int, [POINTER(ConvDesc), P, P, P, P, P, c_size_t, P]),
+    'fcd_conv_wino_chain_ok': (c_int, [P, c_int, c_int]),
+    'fcd_conv_wino_chain_ws_bytes': (c_size_t, [P, c_int, c_int]),
+    'fcd_conv_wino_chain_bits_bytes': (c_size_t, [POINTER(ConvDesc)]),
+    'fcd_conv2d_fwd_wino_chain': (c_int, [P, c_int, P, P, P, P, P, P, P, P, c_size_t, P]),
+    'fcd_conv2d_bwd_data_wino_chain': (c_int, [P, c_int, P, P, P, P, P, P, P, c_size_t, P]),
     'fcd_conv2d_fwd_wino_keepv': (c_int, [POINTER(ConvDesc), P, P, P, P, c_int, P, P, P, c_size_t, P, P]),
     'fcd_conv2d_fwd_wino_cat_keepv': (c_int, [P, P, P, c_int, P, P, P, c_int, P, c_size_t, P, P]),
     'fcd_conv2d_bwd_weight_bias_v': (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, c_size_t, P]),

@@ -465,6 +465,118 @@ def conv2d_relu_maxpool2(x, weight, bias):
     return maxpool2(conv2d(x, weight, bias, 1, 1, relu=True))
 
 
+def _desc_array(descs):
+    arr = (ConvDesc * len(descs))()
+    for i, d in enumerate(descs):
+        for f, _ in ConvDesc._fields_:
+            setattr(arr[i], f, getattr(d, f))
+    return arr
+
+
+def _chain_descs(xshape, weights):
+    N, C, H, W = xshape
+    out = []
+    for w in weights:
+        out.append(_desc((N, C, H, W), w.shape, 1, 1))
+        C = w.shape[0]
+    return out
+
+
+def _chain_bwd_start(descs):
+    """First layer of the longest SUFFIX of the run whose data gradients form an F(4x4) chain (len(descs): none)."""
+    n = len(descs)
+    for j in range(n):
+        if lib.fcd_conv_wino_chain_ok(_desc_array(descs[j:]), n - j, 1):
+            return j
+    return n
+
+
+def frozen_chain_ok(x, weights):
+    """True when :func:`frozen_conv_chain` can run ``weights`` (frozen 3x3 filters, >= 2 layers) as one run on ``x``: the
+    forward run qualifies, and its data gradient is an F(4x4) run over all layers but at most the first (whose own kernel
+    then receives an already gated gradient)."""
+    if os.environ.get('FCD_WINO_CHAIN') == '0' or len(weights) < 2 or len(weights) > 8 or not x.is_cuda or x.dim() != 4:
+        return False
+    if any(w.requires_grad or tuple(w.shape[2:]) != (3, 3) for w in weights):
+        return False
+    descs = _chain_descs(x.shape, weights)
+    if not lib.fcd_conv_wino_chain_ok(_desc_array(descs), len(descs), 0):
+        return False
+    return _chain_bwd_start(descs) <= 1
+
+
+class _FrozenChain(torch.autograd.Function):
+    """relu(conv(... relu(conv(x, w0) + b0) ...)) [+ MaxPool2d(2)] over a run of FROZEN 3x3 layers (the conv + ReLU pairs
+    between two max-pools of the VGG16 stack, reference Loss.py:25-36) as ONE node: the activations between the layers
+    are never tensors (``fcd_conv2d_fwd_wino_chain``), the tape holds 16 sign bits per 4 x 4 tile and layer (one code byte
+    per pooled element for the last layer when pooling), and the backward pass is the mirrored run
+    (``fcd_conv2d_bwd_data_wino_chain``).  Bit-identical to the layer-by-layer ops."""
+
+    @staticmethod
+    def forward(ctx, x, pool, *wb):
+        x = _dev(x, 'conv input')
+        n = len(wb) // 2
+        weights, biases = list(wb[:n]), [_dev(b, 'conv bias') for b in wb[n:]]
+        descs = _chain_descs(x.shape, weights)
+        darr = _desc_array(descs)
+        N, H, W = descs[0].N, descs[0].H, descs[0].W
+        K = descs[-1].K
+        dev = x.device
+        want = ctx.needs_input_grad[0]
+        bits = []
+        if want:
+            for i in range(n - (1 if pool else 0)):
+                bits.append(torch.empty(lib.fcd_conv_wino_chain_bits_bytes(ctypes.byref(descs[i])) // 2, dtype=torch.int16, device=dev))
+        y = yp = code = None
+        if pool:
+            yp = torch.empty((N, K, H // 2, W // 2), dtype=torch.float32, device=dev)
+            code = torch.empty(yp.shape, dtype=torch.uint8, device=dev)
+        else:
+            y = torch.empty((N, K, H, W), dtype=torch.float32, device=dev)
+        Us = [wino_weight(w, 0, 4) for w in weights]
+        ws = _ws(lib.fcd_conv_wino_chain_ws_bytes(darr, n, 0), dev)
+        bptr = _ptr_list([b.data_ptr() for b in bits] + [None] * (n - len(bits))) if want else None
+        check(lib.fcd_conv2d_fwd_wino_chain(darr, n, _p(x), _ptr_list([u.data_ptr() for u in Us]),
+                                            _ptr_list([b.data_ptr() for b in biases]), _p(y), _p(yp), _p(code), bptr, _p(ws),
+                                            ws.numel(), _stream()), 'fcd_conv2d_fwd_wino_chain')
+        ctx.save_for_backward(code, *weights, *bits)
+        ctx.geom = (tuple(x.shape), n, bool(pool))
+        return yp if pool else y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xshape, n, pool = ctx.geom
+        saved = ctx.saved_tensors
+        code, weights, bits = saved[0], list(saved[1:1 + n]), list(saved[1 + n:])
+        dy = _dev(dy, 'conv grad')
+        if not ctx.needs_input_grad[0]:
+            return (None,) * (2 + 2 * n)
+        descs = _chain_descs(xshape, weights)
+        j = _chain_bwd_start(descs)
+        if j > 1:
+            raise _lib.FcdError('frozen_conv_chain: no backward run for these layers (frozen_chain_ok was not consulted)')
+        dev = dy.device
+        dx = torch.empty((xshape[0], descs[j].C) + tuple(xshape[2:]), dtype=torch.float32, device=dev)
+        darr = _desc_array(descs[j:])
+        m = n - j
+        ws = _ws(lib.fcd_conv_wino_chain_ws_bytes(darr, m, 1), dev)
+        blist = [(bits[i].data_ptr() if i < len(bits) else None) for i in range(j, n)]
+        U1 = [wino_weight(w, 1, 4) for w in weights[j:]]
+        check(lib.fcd_conv2d_bwd_data_wino_chain(darr, m, _p(dy), _p(code) if pool else None, _ptr_list(blist),
+                                                 _p(bits[0]) if j == 1 else None, _ptr_list([u.data_ptr() for u in U1]),
+                                                 _p(dx), _p(ws), ws.numel(), _stream()), 'fcd_conv2d_bwd_data_wino_chain')
+        if j == 1:          # the run's first layer on its own kernel; its ReLU gate is already in dx
+            dx0 = torch.empty(xshape, dtype=torch.float32, device=dev)
+            _bwd_data_conv(descs[0], dx, weights[0], dx0)
+            dx = dx0
+        return (dx, None) + (None,) * (2 * n)
+
+
+def frozen_conv_chain(x, weights, biases, pool=False):
+    """See :class:`_FrozenChain`; check :func:`frozen_chain_ok` first."""
+    return _FrozenChain.apply(x, bool(pool), *weights, *biases)
+
+
 class _ConvT2x2(torch.autograd.Function):
     """ConvTranspose2d(k=2, s=2) (Module.py:63) == data-gradient of the 2x2/stride-2
     convolution whose filter tensor is the transposed-conv weight (Cin, Cout, 2, 2)."""

@@ -21,69 +21,11 @@
 // weight version (fcd_conv_wino_pack): mode 0 forward, mode 1 data gradient (flipped taps, channels swapped).
 // The same arithmetic order is used for every launch => bit-reproducible; fp32 rounding of the
 // m = 4 transforms is ~1e-5 relative (tests/test_gpu_ops.py), m = 2 ~3e-7.
-#include <stdlib.h>
+#include "conv_wino.h"
 
-#include "common.h"
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef FCD_NT_EXP
 #define FCD_NT_EXP 0  // experiments with non-temporal hints: 2 input-transform x loads, 4 B stream of the filter-resident GEMM, 8 blocked C stores
 #endif
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef __attribute__((address_space(1))) const void gbl_void_t;
-
-// --------------------------------------------------------------------------------------------
-// transform matrices
-template <int M> struct WinoMat;
-template <> struct WinoMat<2> {
-  static constexpr int A = 4;
-  __host__ __device__ static constexpr float BT(int i, int j) {
-    constexpr float t[4][4] = {{1, 0, -1, 0}, {0, 1, 1, 0}, {0, -1, 1, 0}, {0, 1, 0, -1}};
-    return t[i][j];
-  }
-  __host__ __device__ static constexpr float G(int i, int j) {
-    constexpr float t[4][3] = {{1, 0, 0}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0, 0, 1}};
-    return t[i][j];
-  }
-  __host__ __device__ static constexpr float AT(int i, int j) {
-    constexpr float t[2][4] = {{1, 1, 1, 0}, {0, 1, -1, -1}};
-    return t[i][j];
-  }
-};
-// F(4x4, 3x3): Toom-Cook on the points {0, +-5/8, +-3/2, inf} [r4] instead of the textbook {0, +-1, +-2, inf}.  Same sparsity
-// pattern (symmetric pairs, 0 and infinity), hence the same instruction count in every transform kernel -- they are all driven by
-// these tables -- but 2.2x less rounding error per layer on the forward / data-gradient pass and on the Winograd-form weight gradient
-// (tools/wino_points.py: fp32 pipeline vs fp64 over 30 symmetric candidates; rms 0.66e-6 vs 1.45e-6 of the output rms, max 1.0e-6
-// vs 3.6e-6 of the output max at 256 - 512 channels): the large powers 4, 8, 16 in A^T / B^T of the textbook points amplify the
-// cancellation in the transforms.  All entries of B^T and A^T are dyadic (exact in fp32); the rows of B^T are scaled by powers of two to
-// max |entry| in [1, 2) (V stays at the activations' magnitude), the inverse factors live in G.
-template <> struct WinoMat<4> {
-  static constexpr int A = 6;
-  __host__ __device__ static constexpr float BT(int i, int j) {
-    constexpr float t[6][6] = {{225.f / 512, 0, -169.f / 128, 0, 1.f / 2, 0},   {0, -45.f / 64, -9.f / 8, 5.f / 16, 1.f / 2, 0},
-                               {0, 45.f / 64, -9.f / 8, -5.f / 16, 1.f / 2, 0}, {0, -75.f / 128, -25.f / 64, 3.f / 2, 1, 0},
-                               {0, 75.f / 128, -25.f / 64, -3.f / 2, 1, 0},     {0, 225.f / 512, 0, -169.f / 128, 0, 1.f / 2}};
-    return t[i][j];
-  }
-  __host__ __device__ static constexpr float G(int i, int j) {
-    constexpr float t[6][3] = {{512.f / 225, 0, 0},
-                               {-4096.f / 2975, -512.f / 595, -64.f / 119},
-                               {-4096.f / 2975, 512.f / 595, -64.f / 119},
-                               {128.f / 1071, 64.f / 357, 32.f / 119},
-                               {128.f / 1071, -64.f / 357, 32.f / 119},
-                               {0, 0, 2}};
-    return t[i][j];
-  }
-  __host__ __device__ static constexpr float AT(int i, int j) {
-    constexpr float t[4][6] = {{1, 1, 1, 1, 1, 0},
-                               {0, 5.f / 8, -5.f / 8, 3.f / 2, -3.f / 2, 0},
-                               {0, 25.f / 64, 25.f / 64, 9.f / 4, 9.f / 4, 0},
-                               {0, 125.f / 512, -125.f / 512, 27.f / 8, -27.f / 8, 1}};
-    return t[i][j];
-  }
-};
 
 // --------------------------------------------------------------------------------------------
 // filter transform: U[xi][row][kc] = (G g G^T)[xi]
@@ -166,35 +108,6 @@ __global__ void wino_filter_kernel(const float* __restrict__ w, float* __restric
 // The raw (m+2)-row strip is staged in LDS with coalesced row reads (source gating applied here),
 // then every thread transforms (tile, channel) items with the channel fastest across lanes, so
 // that each V row [t][32 ch] is written as one 128-B segment.
-// Virtual channel concatenation (the U-Net decoder's cat([branch-1 skip, branch-2 skip, upsampled], dim=1)): up to three
-// (N, c[i], H, W) tensors stand for ONE (N, sum c[i], H, W) operand, c[i] % 32 == 0.  n == 0: plain single tensor.
-struct WinoCat {
-  const float* p[3];
-  int c[3];
-  int n;
-};
-// tensor and its channel count holding concatenated channel ch; ch becomes the channel inside that tensor
-__device__ __forceinline__ const float* wino_cat_pick(const WinoCat& k, int& ch, int& chans) {
-  int s = 0;
-  if (k.n > 1 && ch >= k.c[0]) { ch -= k.c[0]; s = 1; if (k.n > 2 && ch >= k.c[1]) { ch -= k.c[1]; s = 2; } }
-  chans = k.c[s];
-  return k.p[s];
-}
-
-struct WinoInArgs {
-  const float* x;             // SRC 0/1: (N, C, H, W); SRC 2: pooled gradient (N, C, Hp, Wp)
-  const float* mask;          // SRC 1: ReLU output, same shape as x ...
-  const unsigned short* mbits;  // ... or [r3] its sign as 16 bits per (n, c, 4 x 4 tile), bit 4 i + j = [y(4 ty + i, 4 tx + j) > 0],
-                              // written by the forward pass's output transform (1 / 32 of the mask traffic)
-  const unsigned char* code;  // SRC 2: argmax code of the pooled tensor
-  float* V;                   // [xi][Q][T][32]
-  int N, C, H, W, Hp, Wp, TH, TW, Q;
-  long long T;
-  int exp;                    // diagnostics (FCD_WINO_IN_EXP): 2 = no V stores, 4 = no source loads
-  int xcd;                    // 1: blocks renumbered so that each XCD (own L2) walks a contiguous range
-  WinoCat cat;                // plain source of the rolling kernel only: x = cat(cat.p[...]) (cat.n > 0)
-};
-
 // ReLU mask of source element (plane index pc = n * C + c, row ih, column iw .. iw + 3, iw % 4 == 0) as 0 / 1 floats: from
 // the fp32 activation (off = its element offset) or from the 16-bit tile words
 __device__ __forceinline__ f32x4 wino_mask4(const WinoInArgs& a, size_t off, size_t pc, int ih, int iw) {
@@ -207,14 +120,6 @@ __device__ __forceinline__ f32x4 wino_mask4(const WinoInArgs& a, size_t off, siz
 __device__ __forceinline__ float wino_mask1(const WinoInArgs& a, size_t off, size_t pc, int ih, int iw) {
   if (a.mbits) return (float)((a.mbits[(pc * a.TH + (ih >> 2)) * a.TW + (iw >> 2)] >> (4 * (ih & 3) + (iw & 3))) & 1u);
   return a.mask[off];
-}
-
-// Workgroups are handed to the 8 XCDs round-robin in launch order, so neighbouring strips of one plane --
-// which share their halo rows -- would land on 8 different L2s and fetch the shared rows from HBM again.
-// Renumber: XCD j (launch ids j, j+8, ...) takes the contiguous range of blocks [start_j, start_j + count_j).
-__device__ __forceinline__ unsigned xcd_contiguous_id(unsigned lin, unsigned total) {
-  const unsigned j = lin & 7u, i = lin >> 3, q8 = total >> 3, r8 = total & 7u;
-  return j * q8 + (j < r8 ? j : r8) + i;
 }
 
 // TRB x TWB tiles per block (16 tiles for m = 4, 32 for m = 2): 1 x 16 strips for wide maps, 2 x 8 / 4 x 4
@@ -346,26 +251,14 @@ __global__ __launch_bounds__(256) void wino_input_kernel(WinoInArgs a) {
 #pragma unroll
       for (int j = 0; j < A; ++j) d[i][j] = tile[c * PL + (tr * MM + i) * CW + tc * MM + j];
     float t1[A][A];   // B^T d
-#pragma unroll
-    for (int i = 0; i < A; ++i)
-#pragma unroll
-      for (int j = 0; j < A; ++j) {
-        float s = 0.f;
-#pragma unroll
-        for (int k = 0; k < A; ++k)
-          if (WinoMat<MM>::BT(i, k) != 0.f) s += WinoMat<MM>::BT(i, k) * d[k][j];
-        t1[i][j] = s;
-      }
+    wino_in_rows<MM>(d, t1);
     const size_t t = ((size_t)n * a.TH + ty) * a.TW + tx;
     float* vout = a.V + ((size_t)q * a.T + t) * 32 + c;
 #pragma unroll
     for (int i = 0; i < A; ++i)
 #pragma unroll
       for (int j = 0; j < A; ++j) {   // (B^T d) B : column j of B = row j of B^T
-        float s = 0.f;
-#pragma unroll
-        for (int k = 0; k < A; ++k)
-          if (WinoMat<MM>::BT(j, k) != 0.f) s += t1[i][k] * WinoMat<MM>::BT(j, k);
+        const float s = wino_in_col<MM>(t1, i, j);
         if (!(a.exp & 2) || s == 1.2345e-30f) vout[(size_t)(i * A + j) * xi_stride] = s;
       }
   }
@@ -534,28 +427,13 @@ __global__ __launch_bounds__(256) void wino_input_roll_kernel(WinoInArgs a, int 
 #pragma unroll
         for (int j = 0; j < A; ++j) d[i][j] = tile[c * PL + (tr * MM + i) * CW + tc * MM + j];
       float t1[A][A];
-#pragma unroll
-      for (int i = 0; i < A; ++i)
-#pragma unroll
-        for (int j = 0; j < A; ++j) {
-          float s = 0.f;
-#pragma unroll
-          for (int k = 0; k < A; ++k)
-            if (WinoMat<MM>::BT(i, k) != 0.f) s += WinoMat<MM>::BT(i, k) * d[k][j];
-          t1[i][j] = s;
-        }
+      wino_in_rows<MM>(d, t1);
       const size_t t = ((size_t)n * a.TH + ty) * a.TW + tx;
       float* vout = a.V + ((size_t)q * a.T + t) * 32 + c;
 #pragma unroll
       for (int i = 0; i < A; ++i)
 #pragma unroll
-        for (int j = 0; j < A; ++j) {
-          float s = 0.f;
-#pragma unroll
-          for (int k = 0; k < A; ++k)
-            if (WinoMat<MM>::BT(j, k) != 0.f) s += t1[i][k] * WinoMat<MM>::BT(j, k);
-          vout[(size_t)(i * A + j) * xi_stride] = s;
-        }
+        for (int j = 0; j < A; ++j) vout[(size_t)(i * A + j) * xi_stride] = wino_in_col<MM>(t1, i, j);
     }
     if (ty0 + TRB < ty_end) {
       __syncthreads();       // every thread is done reading this strip
@@ -576,26 +454,6 @@ __global__ __launch_bounds__(256) void wino_input_roll_kernel(WinoInArgs a, int 
 #ifndef FCD_GEXP
 #define FCD_GEXP 0   // diagnostic builds only (wrong results): 1 no DMA in the loop, 2 operands from registers, 4 no barrier
 #endif
-struct WinoGemmArgs {
-  const float* A;   // row m of batch b at A + b * a_batch + m * a_ld, stage q at + q * 32 floats
-  const float* B;   // row n of batch b at B + b * b_batch + n * b_ld, stage q at + q * b_adv floats
-  float* C;         // [split][batch][M][N]
-  int M, N, Kc, m_tiles, n_tiles, xcd_remap;
-  long long a_ld, a_batch, b_ld, b_adv, b_batch;
-  int stages_per_split;   // blockIdx.z = split of the reduction: stages [z * sps, min((z + 1) * sps, Kc / 32))
-  const unsigned short* As;   // split kernel: bf16 planes (high, middle, low part) of A, plane p at As + p * as_plane,
-  long long as_plane;         // each laid out like A (a_ld, a_batch in elements)
-  int batches, xb;        // blockIdx.y = group of xb consecutive batches (transform positions) run by ONE workgroup as a
-                          // single software pipeline: the first slabs of batch b + 1 are in flight while batch b's last
-                          // MFMAs run and its C tile is stored -- no pipeline refill per batch
-  int c_blk;              // split kernels: C in MFMA-native 32 x 32 blocks [xi][M/32][c_tblk][half*4 + r/4][32 cols][r%4] (one
-  int c_mblk, c_tblk;     // dwordx4 store per four accumulator registers: 16 / 32 stores per lane and batch instead of 64 / 128);
-  long long c_batch;      // c_batch = floats per xi.  Read back by wino_output_blk_kernel.
-  int bt;                 // split kernel, weight gradient: B is the FORWARD pass's V [xi][N / 32][bt_T][32] (GEMM row n = channel,
-  long long bt_T;         // reduction = tile index): b_batch = elements per xi, the reduction runs to bt_T (rows clamped), b_ld / b_adv unused
-  unsigned long long* tbuf;   // YG_TIME builds: [workgroup][wave][8] cycle sums
-};
-
 template <int WM, int WN>      // waves along M / N, each 64 x 64: block tile (64 WM) x (64 WN)
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void wino_gemm_kernel(WinoGemmArgs a) {
   constexpr int KC = 32;                   // reduction elements per pipeline stage
@@ -1700,55 +1558,23 @@ static void wino_gemm_launch(WinoGemmArgs ga, int batches, int splits, hipStream
 
 // --------------------------------------------------------------------------------------------
 // output transform + epilogue.  Thread = (output channel k, tile t), t fastest.
-struct WinoOutArgs {
-  const float* Mb;      // [xi][K][T]
-  const float* bias;
-  float* y;             // (N, K, P, Q) or NULL when pooling
-  float* pool_y;        // (N, K, P/2, Q/2)
-  unsigned char* code;
-  int K, P, Q, TH, TW, relu;
-  long long T;
-  WinoCat cat;          // data gradient of a virtually concatenated input: channel k of dx goes to its own tensor (cat.n > 0)
-  int tblk;             // wino_output_blk_kernel: Mb in the split GEMM's 32 x 32 blocks (WinoGemmArgs.c_blk): blocks per
-  long long xs_blk;     // row block, floats per xi
-  unsigned short* bits; // [r3] m = 4, relu, no pooling: sign of the outputs, 16 bits per (n, k, tile) (WinoInArgs.mbits)
-  double* bn_part;      // [r3] wino_output_blk_kernel: per-workgroup {sum y, sum y^2} of each channel for the BatchNorm that follows
-  int bn_bpg;           //      (reference Module.py:25-31: Conv2d -> BatchNorm2d): part[((g K + k) bn_bpg + block in group) 3 + {0, 1}],
-                        //      bn_bpg = workgroups per sample group (a workgroup's 256 tiles never straddle two groups: host-checked)
-};
-
 template <int MM>
 __device__ __forceinline__ void wino_out_one(const WinoOutArgs& a, const float (&mv)[WinoMat<MM>::A][WinoMat<MM>::A], int k,
                                              long long t, double* s1 = nullptr, double* s2 = nullptr) {
   constexpr int A = WinoMat<MM>::A;
-  float t1[MM][A];   // A^T M
-#pragma unroll
-  for (int i = 0; i < MM; ++i)
-#pragma unroll
-    for (int j = 0; j < A; ++j) {
-      float s = 0.f;
-#pragma unroll
-      for (int q = 0; q < A; ++q)
-        if (WinoMat<MM>::AT(i, q) != 0.f) s += WinoMat<MM>::AT(i, q) * mv[q][j];
-      t1[i][j] = s;
-    }
   const float b = a.bias ? a.bias[k] : 0.f;
   float o[MM][MM];
-#pragma unroll
-  for (int i = 0; i < MM; ++i)
-#pragma unroll
-    for (int j = 0; j < MM; ++j) {
-      float s = 0.f;
-#pragma unroll
-      for (int q = 0; q < A; ++q)
-        if (WinoMat<MM>::AT(j, q) != 0.f) s += t1[i][q] * WinoMat<MM>::AT(j, q);
-      s += b;
-      if (a.relu) s = s > 0.f ? s : 0.f;
-      o[i][j] = s;
-    }
+  wino_out_tile<MM>(mv, b, a.relu, o);
   const int tx = (int)(t % a.TW);
   const long long r2 = t / a.TW;
   const int ty = (int)(r2 % a.TH), n = (int)(r2 / a.TH);
+  if (MM == 4 && a.gate != nullptr) {      // data gradient handed to a consumer that cannot gate it itself (chain, fused F(2x2) kernel)
+    const unsigned gw = a.gate[(((size_t)n * a.K + k) * a.TH + ty) * a.TW + tx];
+#pragma unroll
+    for (int i = 0; i < MM; ++i)
+#pragma unroll
+      for (int j = 0; j < MM; ++j) o[i][j] = ((gw >> (4 * i + j)) & 1u) ? o[i][j] : 0.f;
+  }
   if (s1 != nullptr) {           // statistics of the outputs that exist (ragged last tile row / column left out)
     double a1 = 0.0, a2 = 0.0;
 #pragma unroll
@@ -1961,12 +1787,6 @@ extern "C" int fcd_conv_wino_plan(const fcd_conv_desc* d, int mode) {
   return wino_env();
 }
 
-struct WinoPlan {
-  int m, A2, rows, red, Kc, Q, TH, TW;
-  long long T;
-  size_t v_bytes, m_bytes;
-};
-
 static bool wino_plan(const fcd_conv_desc* d, int mode, WinoPlan* pl) {
   pl->m = fcd_conv_wino_plan(d, mode);
   if (!pl->m) return false;
@@ -2090,34 +1910,34 @@ static bool wino_blk_path(const WinoPlan& pl) {
   return cblk_on && pl.m == 4 && pl.rows > 64 && wino_split() && (pl.rows & 3) == 0;
 }
 
-static int wino_run(const WinoPlan& pl, int N, int in_ch, int H, int W, const float* src, const float* mask,
-                    const unsigned char* code_in, int Hp, int Wp, const float* U, const float* bias, int relu, float* y,
-                    float* pool_y, unsigned char* code_out, void* ws, hipStream_t st,
-                    const WinoCat* in_cat = nullptr, const WinoCat* out_cat = nullptr, float* v_keep = nullptr,
-                    const unsigned short* mask_bits = nullptr, unsigned short* relu_bits_out = nullptr,
-                    double* bn_part = nullptr, int bn_bpg = 0) {
-  float* V = v_keep ? v_keep : (float*)ws;       // v_keep: the caller keeps the transformed input for the weight gradient
-  float* Mb = (float*)((char*)ws + ((pl.v_bytes + 255) & ~(size_t)255));
+// The three stages of a layer call.  wino_run = input -> GEMM -> output; the chains further down put the fused output -> input
+// kernel of conv_wino_chain.hip between the GEMMs of consecutive layers.
+struct WinoInSrc {
+  const float* src; const float* mask; const unsigned short* mask_bits; const unsigned char* code; int Hp, Wp;
+  const WinoCat* cat;
+};
+static void wino_stage_input(const WinoPlan& pl, int N, int in_ch, int H, int W, const WinoInSrc& in, float* V, hipStream_t st) {
   WinoInArgs ia;
   memset(&ia, 0, sizeof(ia));
-  if (in_cat) ia.cat = *in_cat;
-  ia.x = src; ia.mask = mask; ia.mbits = mask_bits; ia.code = code_in; ia.V = V;
-  ia.N = N; ia.C = in_ch; ia.H = H; ia.W = W; ia.Hp = Hp; ia.Wp = Wp;
+  if (in.cat) ia.cat = *in.cat;
+  ia.x = in.src; ia.mask = in.mask; ia.mbits = in.mask_bits; ia.code = in.code; ia.V = V;
+  ia.N = N; ia.C = in_ch; ia.H = H; ia.W = W; ia.Hp = in.Hp; ia.Wp = in.Wp;
   ia.TH = pl.TH; ia.TW = pl.TW; ia.Q = pl.Q; ia.T = pl.T;
-  const int srcmode = code_in ? 2 : ((mask || mask_bits) ? 1 : 0);
+  const int srcmode = in.code ? 2 : ((in.mask || in.mask_bits) ? 1 : 0);
   {
     static int exp = -1;
     if (exp < 0) { const char* e = getenv("FCD_WINO_IN_EXP"); exp = e ? atoi(e) : 0; }
     ia.exp = exp;
     ia.xcd = (wino_xcd() && !(exp & 8)) ? 1 : 0;
   }
-  const double in_elems = (double)N * in_ch * H * W, mm = pl.m * pl.m;
-  {
-    FcdProfScope p1(FCD_K_WINO_XFORM, st, 0.0, 4.0 * in_elems * (srcmode == 1 ? (mask_bits ? 1.03125 : 2.0) : 1.0) + (double)pl.v_bytes,
-                    fcd_prof_tagf("in src=%d C=%d img=%dx%dx%d", srcmode, in_ch, N, H, W));
-    if (pl.m == 2) wino_launch_input<2>(ia, srcmode, st); else wino_launch_input<4>(ia, srcmode, st);
-  }
+  const double in_elems = (double)N * in_ch * H * W;
+  FcdProfScope p1(FCD_K_WINO_XFORM, st, 0.0, 4.0 * in_elems * (srcmode == 1 ? (in.mask_bits ? 1.03125 : 2.0) : 1.0) + (double)pl.v_bytes,
+                  fcd_prof_tagf("in src=%d C=%d img=%dx%dx%d", srcmode, in_ch, N, H, W));
+  if (pl.m == 2) wino_launch_input<2>(ia, srcmode, st); else wino_launch_input<4>(ia, srcmode, st);
+}
 
+// M = U V; returns the launch's arguments (the output stage needs the block geometry of M)
+static WinoGemmArgs wino_stage_gemm(const WinoPlan& pl, const float* U, const float* V, float* Mb, int N, int H, int W, hipStream_t st) {
   WinoGemmArgs ga;
   memset(&ga, 0, sizeof(ga));
   ga.A = U; ga.B = V; ga.C = Mb;
@@ -2129,41 +1949,60 @@ static int wino_run(const WinoPlan& pl, int N, int in_ch, int H, int W, const fl
   ga.As = (const unsigned short*)(U + ga.as_plane);
   ga.b_ld = 32; ga.b_adv = (long long)pl.T * 32; ga.b_batch = (long long)pl.Q * pl.T * 32;   // V [xi][Q][T][32]
   ga.stages_per_split = pl.Q;
-  const bool blk = wino_blk_path(pl);
-  if (blk) {
+  if (wino_blk_path(pl)) {
     ga.c_blk = 1; ga.c_mblk = cdiv(pl.rows, 32); ga.c_tblk = (int)((pl.T + 31) / 32);
     ga.c_batch = (long long)ga.c_mblk * ga.c_tblk * 1024;
   }
-  {
-    const bool split = pl.rows > 64 && wino_split();
-    FcdProfScope p2(split ? FCD_K_WINO_GEMM_SPLIT : FCD_K_WINO_GEMM, st, 2.0 * pl.A2 * pl.rows * (double)pl.Kc * (double)pl.T,
-                    (double)pl.v_bytes + (double)pl.m_bytes + (split ? 6.0 : 4.0) * pl.A2 * pl.rows * pl.Kc,
-                    fcd_prof_tagf("conv M=%d N=%lld Kc=%d batch=%d img=%dx%dx%d", pl.rows, pl.T, pl.Kc, pl.A2, N, H, W));
-    wino_gemm_launch(ga, pl.A2, 1, st);
-  }
+  const bool split = pl.rows > 64 && wino_split();
+  FcdProfScope p2(split ? FCD_K_WINO_GEMM_SPLIT : FCD_K_WINO_GEMM, st, 2.0 * pl.A2 * pl.rows * (double)pl.Kc * (double)pl.T,
+                  (double)pl.v_bytes + (double)pl.m_bytes + (split ? 6.0 : 4.0) * pl.A2 * pl.rows * pl.Kc,
+                  fcd_prof_tagf("conv M=%d N=%lld Kc=%d batch=%d img=%dx%dx%d", pl.rows, pl.T, pl.Kc, pl.A2, N, H, W));
+  wino_gemm_launch(ga, pl.A2, 1, st);
+  return ga;
+}
 
+struct WinoOutDst {
+  const float* bias; int relu; float* y; float* pool_y; unsigned char* code;
+  const WinoCat* cat; unsigned short* bits; const unsigned short* gate; double* bn_part; int bn_bpg;
+};
+static void wino_stage_output(const WinoPlan& pl, const WinoGemmArgs& ga, const float* Mb, int N, int H, int W, const WinoOutDst& o,
+                              hipStream_t st) {
   WinoOutArgs oa;
   memset(&oa, 0, sizeof(oa));
-  if (out_cat) oa.cat = *out_cat;
-  oa.Mb = Mb; oa.bias = bias; oa.y = y; oa.pool_y = pool_y; oa.code = code_out; oa.bits = relu_bits_out;
-  oa.K = pl.rows; oa.P = H; oa.Q = W; oa.TH = pl.TH; oa.TW = pl.TW; oa.relu = relu; oa.T = pl.T;
+  if (o.cat) oa.cat = *o.cat;
+  oa.Mb = Mb; oa.bias = o.bias; oa.y = o.y; oa.pool_y = o.pool_y; oa.code = o.code; oa.bits = o.bits; oa.gate = o.gate;
+  oa.K = pl.rows; oa.P = H; oa.Q = W; oa.TH = pl.TH; oa.TW = pl.TW; oa.relu = o.relu; oa.T = pl.T;
   dim3 og((unsigned)cdiv64(pl.T, 256), (unsigned)pl.rows);
-  {
-    FcdProfScope p3(FCD_K_WINO_XFORM, st, 0.0,
-                    (double)pl.m_bytes + (double)pl.m_bytes / pl.A2 * mm * (pool_y ? 0.3125 : 1.0),
-                    fcd_prof_tagf("out pool=%d K=%d img=%dx%dx%d", pool_y ? 1 : 0, pl.rows, N, H, W));
-    if (blk) {
-      oa.tblk = ga.c_tblk; oa.xs_blk = ga.c_batch;
-      const dim3 ogb((unsigned)cdiv64(pl.T, 256), (unsigned)cdiv(pl.rows, 4));
-      if (bn_part) {
-        oa.bn_part = bn_part; oa.bn_bpg = bn_bpg;
-        hipLaunchKernelGGL(wino_output_blk_bn_kernel, ogb, dim3(256), 0, st, oa);
-      } else {
-        hipLaunchKernelGGL(wino_output_blk_kernel, ogb, dim3(256), 0, st, oa);
-      }
-    } else if (pl.m == 2) hipLaunchKernelGGL(wino_output_kernel<2>, og, dim3(256), 0, st, oa);
-    else hipLaunchKernelGGL(wino_output_kernel<4>, og, dim3(256), 0, st, oa);
-  }
+  const double mm = pl.m * pl.m;
+  FcdProfScope p3(FCD_K_WINO_XFORM, st, 0.0,
+                  (double)pl.m_bytes + (double)pl.m_bytes / pl.A2 * mm * (o.pool_y ? 0.3125 : 1.0),
+                  fcd_prof_tagf("out pool=%d K=%d img=%dx%dx%d", o.pool_y ? 1 : 0, pl.rows, N, H, W));
+  if (ga.c_blk) {
+    oa.tblk = ga.c_tblk; oa.xs_blk = ga.c_batch;
+    const dim3 ogb((unsigned)cdiv64(pl.T, 256), (unsigned)cdiv(pl.rows, 4));
+    if (o.bn_part) {
+      oa.bn_part = o.bn_part; oa.bn_bpg = o.bn_bpg;
+      hipLaunchKernelGGL(wino_output_blk_bn_kernel, ogb, dim3(256), 0, st, oa);
+    } else {
+      hipLaunchKernelGGL(wino_output_blk_kernel, ogb, dim3(256), 0, st, oa);
+    }
+  } else if (pl.m == 2) hipLaunchKernelGGL(wino_output_kernel<2>, og, dim3(256), 0, st, oa);
+  else hipLaunchKernelGGL(wino_output_kernel<4>, og, dim3(256), 0, st, oa);
+}
+
+static int wino_run(const WinoPlan& pl, int N, int in_ch, int H, int W, const float* src, const float* mask,
+                    const unsigned char* code_in, int Hp, int Wp, const float* U, const float* bias, int relu, float* y,
+                    float* pool_y, unsigned char* code_out, void* ws, hipStream_t st,
+                    const WinoCat* in_cat = nullptr, const WinoCat* out_cat = nullptr, float* v_keep = nullptr,
+                    const unsigned short* mask_bits = nullptr, unsigned short* relu_bits_out = nullptr,
+                    double* bn_part = nullptr, int bn_bpg = 0) {
+  float* V = v_keep ? v_keep : (float*)ws;       // v_keep: the caller keeps the transformed input for the weight gradient
+  float* Mb = (float*)((char*)ws + ((pl.v_bytes + 255) & ~(size_t)255));
+  const WinoInSrc in = {src, mask, mask_bits, code_in, Hp, Wp, in_cat};
+  wino_stage_input(pl, N, in_ch, H, W, in, V, st);
+  const WinoGemmArgs ga = wino_stage_gemm(pl, U, V, Mb, N, H, W, st);
+  const WinoOutDst out = {bias, relu, y, pool_y, code_out, out_cat, relu_bits_out, nullptr, bn_part, bn_bpg};
+  wino_stage_output(pl, ga, Mb, N, H, W, out, st);
   return 0;
 }
 
@@ -2297,6 +2136,147 @@ extern "C" int fcd_conv2d_bwd_data_wino(const fcd_conv_desc* d, const float* dy,
   wino_run(pl, d->N, d->K, d->P, d->Q, dy, pool_code ? nullptr : relu_out, pool_code, d->P / 2, d->Q / 2, U, nullptr, 0,
            dx, nullptr, nullptr, ws, (hipStream_t)stream);
   FCD_LAUNCH_CHECK("conv2d_bwd_data_wino");
+  return FCD_OK;
+}
+
+// =============================================================================================
+// [r5] Runs of frozen 3x3 layers with only a ReLU between them (the VGG16 stack of the perception term, reference Loss.py:25-36:
+// conv + ReLU pairs between two max-pools, requires_grad = False): input transform -> GEMM -> [fused output -> input transform
+// (conv_wino_chain.hip) -> GEMM] x (n - 1) -> output transform.  The activations between the layers of a run are never written
+// as tensors; the backward run needs only their sign bits.  d[0 .. n) are the layers' descriptors in forward order.
+static bool wino_chain_plans(const fcd_conv_desc* d, int n, int mode, WinoPlan* pls) {
+  if (!d || n < 1 || n > 8) return false;
+  for (int i = 0; i < n; ++i) {
+    if (!wino_plan(&d[i], mode, &pls[i]) || pls[i].m != 4 || !wino_blk_path(pls[i])) return false;
+    if (d[i].N != d[0].N || d[i].H != d[0].H || d[i].W != d[0].W || d[i].P != d[0].H || d[i].Q != d[0].W) return false;
+    if (i > 0 && (d[i].C != d[i - 1].K || !wino_oi_ok(d[i].C, d[i].H, d[i].W))) return false;
+  }
+  return true;
+}
+// 1: the run d[0 .. n) can go through fcd_conv2d_fwd_wino_chain (mode 0) / fcd_conv2d_bwd_data_wino_chain (mode 1)
+extern "C" int fcd_conv_wino_chain_ok(const fcd_conv_desc* d, int n, int mode) {
+  WinoPlan pls[8];
+  return (mode == 0 || mode == 1) && wino_chain_plans(d, n, mode, pls) ? 1 : 0;
+}
+// bytes of relu_bits[i] of a run: 16 sign bits per (n, k, 4 x 4 output tile) of layer d (0: the layer's forward is not F(4x4))
+extern "C" size_t fcd_conv_wino_chain_bits_bytes(const fcd_conv_desc* d) {
+  WinoPlan pf;
+  if (!d || !wino_plan(d, 0, &pf) || pf.m != 4) return 0;
+  return (size_t)d->N * d->K * pf.TH * pf.TW * sizeof(unsigned short);
+}
+extern "C" size_t fcd_conv_wino_chain_ws_bytes(const fcd_conv_desc* d, int n, int mode) {
+  WinoPlan pls[8];
+  if (!(mode == 0 || mode == 1) || !wino_chain_plans(d, n, mode, pls)) return 0;
+  size_t v = 0, m = 0;
+  for (int i = 0; i < n; ++i) { v = std::max(v, pls[i].v_bytes); m = std::max(m, pls[i].m_bytes); }
+  return ((v + 255) & ~(size_t)255) + m + 256;
+}
+
+static void wino_stage_oi(const WinoPlan& prod, const WinoGemmArgs& ga, const float* Mb, const WinoPlan& cons, int N, int H, int W,
+                          const float* bias, int relu, unsigned short* bits_out, const unsigned short* gate, float* V, hipStream_t st) {
+  WinoOiArgs oa;
+  memset(&oa, 0, sizeof(oa));
+  oa.Mb = Mb; oa.xs_blk = ga.c_batch; oa.tblk = ga.c_tblk;
+  oa.bias = bias; oa.relu = relu; oa.bits_out = bits_out; oa.gate = gate; oa.V = V;
+  oa.N = N; oa.K = prod.rows; oa.H = H; oa.W = W; oa.TH = cons.TH; oa.TW = cons.TW; oa.Q = cons.Q; oa.T = cons.T;
+  FcdProfScope p(FCD_K_WINO_XFORM, st, 0.0, (double)prod.m_bytes + (double)cons.v_bytes + 2.0 * prod.rows * (double)cons.T,
+                 fcd_prof_tagf("oi gate=%d K=%d img=%dx%dx%d", gate ? 1 : 0, prod.rows, N, H, W));
+  wino_oi_launch(oa, st);
+}
+
+// y = relu(conv_{n-1}( ... relu(conv_0(x)) ... )), or pool_y / code = its 2 x 2 max-pool.  relu_bits[i] (may be NULL, and the
+// array itself may be NULL): sign bits of layer i's activation, fcd_conv_wino_chain_bits_bytes(&d[i]) bytes each; with pool_y the
+// last entry is ignored (the pool's argmax code carries the sign).
+extern "C" int fcd_conv2d_fwd_wino_chain(const fcd_conv_desc* d, int n, const float* x, const float* const* U,
+                                         const float* const* bias, float* y, float* pool_y, unsigned char* code,
+                                         unsigned short* const* relu_bits, void* ws, size_t ws_bytes, void* stream) {
+  WinoPlan pls[8];
+  FCD_CHECK_ARG(d && x && U && bias && (y || (pool_y && code)), "fcd_conv2d_fwd_wino_chain: null pointer");
+  FCD_CHECK_ARG(wino_chain_plans(d, n, 0, pls), "fcd_conv2d_fwd_wino_chain: fcd_conv_wino_chain_ok(d, n, 0) == 0 for this run");
+  const size_t need = fcd_conv_wino_chain_ws_bytes(d, n, 0);
+  if (!ws || ws_bytes < need) {
+    fcd_set_error("fcd_conv2d_fwd_wino_chain: workspace %zu < %zu bytes", ws_bytes, need);
+    return FCD_ERR_WORKSPACE;
+  }
+  size_t vmax = 0;
+  for (int i = 0; i < n; ++i) vmax = std::max(vmax, pls[i].v_bytes);
+  float* V = (float*)ws;
+  float* Mb = (float*)((char*)ws + ((vmax + 255) & ~(size_t)255));
+  hipStream_t st = (hipStream_t)stream;
+  const int N = d[0].N, H = d[0].H, W = d[0].W;
+  WinoGemmArgs ga;
+  for (int i = 0; i < n; ++i) {
+    FCD_CHECK_ARG(U[i], "fcd_conv2d_fwd_wino_chain: null filter pack");
+    const WinoPlan& pl = pls[i];
+    const double v = (double)pl.v_bytes, m = (double)pl.m_bytes;
+    // bytes of this layer's share of the run: its input side (x or the fused kernel: M of the previous layer -> V), the GEMM,
+    // and for the last layer the output transform
+    const double in_b = i == 0 ? 4.0 * N * d[0].C * H * W + v : (double)pls[i - 1].m_bytes + v;
+    const double out_b = i == n - 1 ? m + m / pl.A2 * 16.0 * (pool_y ? 0.3125 : 1.0) : 0.0;
+    FcdProfScope prof(FCD_K_WINO_FWD, st, conv_flops(&d[i]), in_b + v + m + out_b + 4.0 * pl.A2 * pl.rows * pl.Kc,
+                      fcd_prof_tag_desc("wino_fwd_chain", &d[i]));
+    if (i == 0) {
+      const WinoInSrc in = {x, nullptr, nullptr, nullptr, 0, 0, nullptr};
+      wino_stage_input(pl, N, d[0].C, H, W, in, V, st);
+    } else {
+      wino_stage_oi(pls[i - 1], ga, Mb, pl, N, H, W, bias[i - 1], 1, relu_bits ? relu_bits[i - 1] : nullptr, nullptr, V, st);
+    }
+    ga = wino_stage_gemm(pl, U[i], V, Mb, N, H, W, st);
+    if (i == n - 1) {
+      const WinoOutDst out = {bias[i], 1, pool_y ? nullptr : y, pool_y, code, nullptr,
+                              (!pool_y && relu_bits) ? relu_bits[i] : nullptr, nullptr, nullptr, 0};
+      wino_stage_output(pl, ga, Mb, N, H, W, out, st);
+    }
+  }
+  FCD_LAUNCH_CHECK("conv2d_fwd_wino_chain");
+  return FCD_OK;
+}
+
+// Data gradient of the run: dy is the gradient w.r.t. the run's output -- pooled (pool_code != NULL) or not, in which case it is
+// gated with relu_bits[n - 1] when that entry is not NULL.  relu_bits[i], i < n - 1: the sign bits the forward run wrote (all
+// needed).  gate_in (optional): sign bits of the run's INPUT tensor (the activation of the layer in front of the run): dx is
+// zeroed where that activation was <= 0, for a preceding layer whose own data-gradient kernel cannot gate by bits.
+// U1[i]: mode-1 filter packs.  dx: (N, C_0, H, W).
+extern "C" int fcd_conv2d_bwd_data_wino_chain(const fcd_conv_desc* d, int n, const float* dy, const unsigned char* pool_code,
+                                              const unsigned short* const* relu_bits, const unsigned short* gate_in,
+                                              const float* const* U1, float* dx, void* ws, size_t ws_bytes, void* stream) {
+  WinoPlan pls[8];
+  FCD_CHECK_ARG(d && dy && U1 && dx && (n == 1 || relu_bits), "fcd_conv2d_bwd_data_wino_chain: null pointer");
+  FCD_CHECK_ARG(wino_chain_plans(d, n, 1, pls), "fcd_conv2d_bwd_data_wino_chain: fcd_conv_wino_chain_ok(d, n, 1) == 0 for this run");
+  const size_t need = fcd_conv_wino_chain_ws_bytes(d, n, 1);
+  if (!ws || ws_bytes < need) {
+    fcd_set_error("fcd_conv2d_bwd_data_wino_chain: workspace %zu < %zu bytes", ws_bytes, need);
+    return FCD_ERR_WORKSPACE;
+  }
+  size_t vmax = 0;
+  for (int i = 0; i < n; ++i) vmax = std::max(vmax, pls[i].v_bytes);
+  float* V = (float*)ws;
+  float* Mb = (float*)((char*)ws + ((vmax + 255) & ~(size_t)255));
+  hipStream_t st = (hipStream_t)stream;
+  const int N = d[0].N, H = d[0].H, W = d[0].W;
+  WinoGemmArgs ga;
+  for (int i = n - 1; i >= 0; --i) {
+    FCD_CHECK_ARG(U1[i] && (i == 0 || relu_bits[i - 1]), "fcd_conv2d_bwd_data_wino_chain: null filter pack / sign bits");
+    const WinoPlan& pl = pls[i];       // rows = C_i, reduction = K_i
+    const double v = (double)pl.v_bytes, m = (double)pl.m_bytes;
+    const double in_b = i == n - 1 ? 4.0 * N * d[i].K * H * W * (pool_code ? 0.3125 : 1.03125) + v : (double)pls[i + 1].m_bytes + v;
+    const double out_b = i == 0 ? m + m / pl.A2 * 16.0 : 0.0;
+    FcdProfScope prof(FCD_K_WINO_DGRAD, st, conv_flops(&d[i]), in_b + v + m + out_b + 4.0 * pl.A2 * pl.rows * pl.Kc,
+                      fcd_prof_tag_desc("wino_dgrad_chain", &d[i]));
+    if (i == n - 1) {
+      const WinoInSrc in = {dy, nullptr, pool_code ? nullptr : (relu_bits ? relu_bits[i] : nullptr), pool_code, H / 2, W / 2, nullptr};
+      wino_stage_input(pl, N, d[i].K, H, W, in, V, st);
+    } else {
+      // products of layer i + 1's data gradient = gradient w.r.t. layer i's activation: gate with its sign bits
+      wino_stage_oi(pls[i + 1], ga, Mb, pl, N, H, W, nullptr, 0, nullptr, relu_bits[i], V, st);
+    }
+    ga = wino_stage_gemm(pl, U1[i], V, Mb, N, H, W, st);
+    if (i == 0) {
+      const WinoOutDst out = {nullptr, 0, dx, nullptr, nullptr, nullptr, nullptr, gate_in, nullptr, 0};
+      wino_stage_output(pl, ga, Mb, N, H, W, out, st);
+    }
+  }
+  FCD_LAUNCH_CHECK("conv2d_bwd_data_wino_chain");
   return FCD_OK;
 }
 

@@ -177,6 +177,27 @@ int fcd_conv2d_fwd_wino_relu_bits(const fcd_conv_desc* d, const float* x, const 
                                   unsigned short* relu_bits, void* ws, size_t ws_bytes, void* stream);
 int fcd_conv2d_bwd_data_wino_bits(const fcd_conv_desc* d, const float* dy, const unsigned short* relu_bits, const float* U,
                                   float* dx, void* ws, size_t ws_bytes, void* stream);
+/* ---- runs of FROZEN F(4x4) layers (round 5): the conv + ReLU pairs between two max-pools of the VGG16 stack (reference
+ * Loss.py:25-36; torchvision vgg16.features[5..8], [10..15], [17..22], [24..29]).  d[0 .. n) in forward order, same N, H, W,
+ * d[i].C == d[i-1].K.  Between two layers of a run ONE kernel turns the products of layer i into the transformed input of
+ * layer i + 1 (bias, ReLU, sign bits on the way; the gradient's ReLU gate on the way back): the activation between them is
+ * never written -- 4.5 instead of 6.5 tensor passes per layer boundary.  Results are bit-identical to the layer-by-layer calls.
+ * fcd_conv_wino_chain_ok(d, n, mode): 1 when the run qualifies (mode 0 forward, 1 data gradient); the data gradient of a run
+ * may cover a SUFFIX of the forward run (conv2_1's data gradient is a 64-row GEMM and runs on the fused F(2x2) kernel).
+ * relu_bits[i]: sign bits of layer i's activation, fcd_conv_wino_chain_bits_bytes(&d[i]) bytes, written by the forward run
+ * (entries / the array may be NULL when no backward pass follows; with pool_y the last entry is not used).
+ * Backward: dy = gradient of the run's output, pooled when pool_code != NULL, else gated with relu_bits[n-1] if given;
+ * gate_in (optional): sign bits of the run's INPUT activation -- dx is zeroed where it was <= 0 (for a producer whose own
+ * data-gradient kernel then runs ungated). */
+int fcd_conv_wino_chain_ok(const fcd_conv_desc* d, int n, int mode);
+size_t fcd_conv_wino_chain_ws_bytes(const fcd_conv_desc* d, int n, int mode);
+size_t fcd_conv_wino_chain_bits_bytes(const fcd_conv_desc* d);
+int fcd_conv2d_fwd_wino_chain(const fcd_conv_desc* d, int n, const float* x, const float* const* U, const float* const* bias,
+                              float* y, float* pool_y, unsigned char* code, unsigned short* const* relu_bits, void* ws,
+                              size_t ws_bytes, void* stream);
+int fcd_conv2d_bwd_data_wino_chain(const fcd_conv_desc* d, int n, const float* dy, const unsigned char* pool_code,
+                                   const unsigned short* const* relu_bits, const unsigned short* gate_in,
+                                   const float* const* U1, float* dx, void* ws, size_t ws_bytes, void* stream);
 /* dx from dy, dy * [relu_out > 0] (relu_out != NULL) or the pooled gradient routed by pool_code */
 int fcd_conv2d_bwd_data_wino(const fcd_conv_desc* d, const float* dy, const float* relu_out,
                              const unsigned char* pool_code, const float* U, float* dx, void* ws,
