@@ -563,12 +563,6 @@ def main():
             cands.sort(key=lambda e: -(e['share_of_step_time'] or 0.0))
             res['roofline'] = cands[0]
             res['roofline']['other_mfma_kernels'] = cands[1:]
-            if res['roofline']['kernel'].startswith('wino_gemm_split'):
-                # context, never the peak the fraction is priced against: what the vendor library's best bf16 GEMM reaches on this chip
-                res['roofline']['vendor_bf16_gemm'] = {
-                    'frac_of_peak': 0.548, 'tflops': 1370.1, 'what': 'hipBLASLt bf16 16384^3 through torch.matmul on one MI355X '
-                    '(tools/bench_vendor_gemm.py, profiles/r04_vendor_gemm.md); the vendor fp32 GEMM on the conv3_x / conv4_x shapes of this '
-                    'step takes 1.5 - 1.6x the split GEMM\'s time'}
             # HBM bytes per launch of the direct-conv family from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate
             # rocprofv3 passes over this very command: tools/pmc_bench.sh); bench.py cannot run the profiler on itself,
             # so it reports the committed measurement of the family it belongs to.
@@ -586,25 +580,34 @@ def main():
                     'note': 'bench.py cannot run rocprofv3 --pmc on itself: `traffic` is the committed PMC measurement of this very '
                             'command (tools/pmc_hbm.sh), reported ONLY while the HIP sources it was taken on are the ones built here; '
                             'otherwise traffic is null'}
-                alg = {'wino_gemm': wgemm['bytes'] / max(wgemm['launches'], 1),
-                       'wino_gemm_split': wsplit['bytes'] / max(wsplit['launches'], 1),
-                       'conv_wino2': (w2f['bytes'] + w2d['bytes']) / max(w2f['launches'] + w2d['launches'], 1),
-                       'conv_wgrad': (wg['bytes'] - wgw_['bytes']) / max(wg['launches'] - wgw_['launches'], 1),
-                       'conv_igemm': (fwd['bytes'] + dg['bytes']) / max(fwd['launches'] + dg['launches'], 1)}
+                # like for like: the report holds HBM bytes per STEP of every kernel that runs inside a family's
+                # calls (tools/kernel_families.py: one map for both tools); both figures below are per CALL as this run counts them
+                from tools.kernel_families import FAMILIES, calls_per_step
+                scopes = {k: dict(launches=v['launches'], bytes=v['bytes']) for k, v in prof.items()}
+
+                def alg_bytes_per_call(fam):
+                    _, add, sub = FAMILIES[fam]
+                    by = sum(scopes[s_]['bytes'] for s_ in add if s_ in scopes) - sum(scopes[s_]['bytes'] for s_ in sub if s_ in scopes)
+                    n = calls_per_step(fam, scopes, 1)
+                    return by / n if n > 0 else None
                 for e in cands:
                     key = ('wino_gemm_split' if e['kernel'].startswith('wino_gemm_split') else
                            'wino_gemm' if e['kernel'].startswith('wino_gemm') else
                            'conv_wino2' if e['kernel'].startswith('conv_wino2') else
                            'conv_wgrad' if e['kernel'].startswith('weight gradient') else
                            'conv_igemm' if e['kernel'].startswith('conv_igemm') else None)
-                    if key:
-                        e['algorithmic_bytes_per_launch'] = alg[key]
-                    if fresh and key and key in tj:
-                        e['traffic'] = tj[key]['hbm_bytes_per_launch']
-                        e['traffic_unit'] = ('HBM bytes per launch: PMC FETCH_SIZE x %.2f + WRITE_SIZE x %.2f (factors calibrated in the same '
-                                             'session on known 2 GiB streams in the kernel\'s access pattern, %s)'
-                                             % (tj[key]['fetch_factor'] or 1.0, tj[key]['write_factor'] or 1.0, os.path.relpath(tpath, ROOT)))
-                        e['traffic_over_algorithmic'] = e['traffic'] / alg[key] if alg[key] else None
+                    if not key:
+                        continue
+                    alg_b = alg_bytes_per_call(key)
+                    e['algorithmic_bytes_per_launch'] = alg_b
+                    if fresh and key in tj and 'hbm_bytes_per_step' in tj[key]:
+                        n_call = calls_per_step(key, scopes, psteps)
+                        e['traffic'] = tj[key]['hbm_bytes_per_step'] / n_call if n_call > 0 else None
+                        e['traffic_unit'] = ('HBM bytes per call (= per launch of this table): PMC FETCH_SIZE x %.2f + WRITE_SIZE x %.2f over every kernel '
+                                             'of the family, per step, / %.1f calls per step (factors calibrated in the same session on known '
+                                             '2 GiB streams in the kernel\'s access pattern, %s)'
+                                             % (tj[key]['fetch_factor'] or 1.0, tj[key]['write_factor'] or 1.0, n_call, os.path.relpath(tpath, ROOT)))
+                        e['traffic_over_algorithmic'] = e['traffic'] / alg_b if (alg_b and e['traffic']) else None
             if wf['launches'] + wd['launches'] > 0:
                 wms, wfl = wf['ms'] + wd['ms'], wf['flops'] + wd['flops']
                 from fcd_gan_pytorch_amd import _lib as _l

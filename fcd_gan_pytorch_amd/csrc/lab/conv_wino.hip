@@ -23,6 +23,9 @@
 // m = 4 transforms is ~1e-5 relative (tests/test_gpu_ops.py), m = 2 ~3e-7.
 #include "conv_wino.h"
 
+#ifndef FCD_NT_EXP
+#define FCD_NT_EXP 0  // experiments with non-temporal hints: 2 input-transform x loads, 4 B stream of the filter-resident GEMM, 8 blocked C stores
+#endif
 
 // --------------------------------------------------------------------------------------------
 // filter transform: U[xi][row][kc] = (G g G^T)[xi]
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(256) void wino_input_roll_kernel(WinoInArgs a, int 
         v[2] = __uint_as_float(cc);
       } else if (idx < 32 * RH * V4 && q * 32 + c < a.C && ih >= 0 && ih < a.H && iw < a.W) {
         const size_t off = img + (size_t)c * plane + (size_t)ih * a.W + iw;
-        v = *(const f32x4*)(xsrc + off);
+        v = (FCD_NT_EXP & 2) ? __builtin_nontemporal_load((const f32x4*)(xsrc + off)) : *(const f32x4*)(xsrc + off);
         if (SRC == 1) {
           // bit mask: keep the RAW tile word in the register (decoded in commit): arithmetic on it here would wait for the
           // load and serialise the strip's prefetch (measured: +2 ms per step with the decode at issue time)
@@ -448,6 +451,9 @@ __global__ __launch_bounds__(256) void wino_input_roll_kernel(WinoInArgs a, int 
 // is applied on the SOURCE address of the lane-linear DMA -- so the four ds_read_b128 with which a
 // lane fetches its 16 operands of the chunk are bank-conflict free without padding.  Two LDS stages
 // as distinct objects, chunk loop unrolled by two (see conv_igemm.hip for why).
+#ifndef FCD_GEXP
+#define FCD_GEXP 0   // diagnostic builds only (wrong results): 1 no DMA in the loop, 2 operands from registers, 4 no barrier
+#endif
 template <int WM, int WN>      // waves along M / N, each 64 x 64: block tile (64 WM) x (64 WN)
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void wino_gemm_kernel(WinoGemmArgs a) {
   constexpr int KC = 32;                   // reduction elements per pipeline stage
@@ -542,19 +548,19 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void wino_gem
   }
 #define WG_STEP(SA, SB, SAN, SBN)                                                                \
   {                                                                                              \
-    if (fb < nb) WG_DMA(SAN, SBN)                                                                 \
+    if (!(FCD_GEXP & 1)) if (fb < nb) WG_DMA(SAN, SBN)                                           \
     _Pragma("unroll") for (int j4 = 0; j4 < UH; ++j4) {                                          \
       f32x4 av[2], bv[2];                                                                        \
       _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                            \
-        av[i] = *(const f32x4*)((SA) + aoff[i] + uoff[j4]);                                          \
-        bv[i] = *(const f32x4*)((SB) + boff[i] + uoff[j4]);                                          \
+        av[i] = (FCD_GEXP & 2) ? f32x4{(float)lane, 1.f, 2.f, (float)j4} : *(const f32x4*)((SA) + aoff[i] + uoff[j4]); \
+        bv[i] = (FCD_GEXP & 2) ? f32x4{(float)i, 1.f, (float)lane, 3.f} : *(const f32x4*)((SB) + boff[i] + uoff[j4]); \
       }                                                                                          \
       _Pragma("unroll") for (int e = 0; e < 4; ++e)                                              \
         _Pragma("unroll") for (int i = 0; i < 2; ++i)                                            \
           _Pragma("unroll") for (int j = 0; j < 2; ++j)                                          \
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], bv[j][e], acc[i][j], 0, 0, 0); \
     }                                                                                            \
-    __syncthreads();                                                                             \
+    if (!(FCD_GEXP & 4)) __syncthreads();                                                        \
   }
 
   WG_DMA(sa0, sb0)
@@ -597,13 +603,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void wino_gem
 // the v_mfma_f32_32x32x2_f32 chain performs.  A (the transformed filters) is split once per weight version by the pack
 // kernel (three bf16 planes); B (the transformed activations V, fp32 in HBM and in LDS) is split in registers right
 // before the MFMAs.  Lane (row, half) owns reduction elements half*16 .. half*16+15 of the 32-chunk, 8 per MFMA step.
-// Where in a stage the LDS-DMA of the NEXT stage is issued (256-tile kernel): [r4] after the SECOND of the four MFMA groups instead of at
-// the top of the stage -- measured on conv3_x / conv4_x / conv3_1: 1.58 -> 1.485, 1.297 -> 1.257, 0.727 -> 0.699 ms (the requests no longer
-// sit in front of the stage's own LDS operand reads, and half a stage is still enough for them to land); after the first group 1.53 /
-// 1.285 / 0.706, after the third 1.51 / 1.264 / 0.709; s_setprio 2 over the MFMA part of a stage: no effect; the same move in the 128-tile
-// kernel: no gain.  [r5] The switches those A/B runs used (FCD_YEXP), the wrong-result diagnostic builds (FCD_SEXP / FCD_GEXP: no split,
-// one MFMA of six, no DMA, no barrier ...), the non-temporal-hint experiments and the two-group ping-pong variant of this tile live in
-// csrc/lab/conv_wino.hip (`make lab`: libfcdgan_hip_lab.so, not part of the product build or of its source stamp).
+// Where in a stage the LDS-DMA of the NEXT stage is issued (FCD_YEXP, results identical): [r4] after the SECOND of the four MFMA groups
+// (bit 4, the default) instead of at the top of the stage -- measured on conv3_x / conv4_x / conv3_1: 1.58 -> 1.485, 1.297 -> 1.257,
+// 0.727 -> 0.699 ms (the requests no longer sit in front of the stage's own LDS operand reads, and half a stage is still enough for
+// them to land); after the first group (bit 2) 1.53 / 1.285 / 0.706, after the third (bit 8) 1.51 / 1.264 / 0.709.  Bit 1 = s_setprio 2
+// over the MFMA part of a stage: no effect.  Bit 16 = the same move in the 128-tile kernel: no gain (9.73 - 9.86 vs 9.69 - 9.72 ms over the
+// 12 layer shapes of tools/bench_wino_gemm.py).
 // YG_TIME: attribution build of the 256-tile split GEMM (tools/gemm_segments.py): every wave stamps s_memtime at the segment borders
 // of its stage loop -- top of the stage, in front of the first MFMA group (after the stage's first LDS reads and the split of step 0),
 // behind the last MFMA group, behind the stage barrier -- and around the C store of a batch, and writes the per-segment cycle sums
@@ -611,6 +616,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void wino_gem
 // fences and wait for the wave's outstanding LDS reads.  Never defined in the product build.
 #ifndef YG_TIME
 #define YG_TIME 0
+#endif
+#ifndef YG_PLAINC
+#define YG_PLAINC 0     // experiment: the 256-tile kernel's C tile with plain instead of non-temporal stores
 #endif
 #if YG_TIME
 #define YG_T(var) __builtin_amdgcn_sched_barrier(0); const unsigned long long var = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0);
@@ -620,6 +628,13 @@ extern "C" void fcd_wino_gemm_time_buf(void* p) { g_yg_tbuf = (unsigned long lon
 #else
 #define YG_T(var)
 #define YG_TACC(slot, t1, t0)
+#endif
+#ifndef FCD_YEXP
+#define FCD_YEXP 4
+#endif
+#ifndef FCD_SEXP
+#define FCD_SEXP 0   // diagnostic builds only (wrong results): 1 no operand split, 2 one MFMA of the six, 4 no barrier, 8 no DMA,
+                     // 64 no A-operand DMA (128-tile kernel), 128 no C stores (128-tile kernel)
 #endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -732,9 +747,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void wino_gem
   {                                                                                              \
     const unsigned short* as_ = Ab + (size_t)fb * a.a_batch + (size_t)fq * KC;                   \
     const float* bs_ = BT ? Bb + (size_t)fb * a.b_batch : Bb + (size_t)fb * a.b_batch + (size_t)fq * a.b_adv; \
-    _Pragma("unroll") for (int j = 0; j < PPW_A; ++j)                                            \
+    if (!(FCD_SEXP & 64)) { _Pragma("unroll") for (int j = 0; j < PPW_A; ++j)                    \
       __builtin_amdgcn_global_load_lds((gbl_void_t*)(as_ + a_goff[j]),                           \
-                                       (lds_void_t*)((SA) + (wave + NW * j) * 512), 16, 0, 0);   \
+                                       (lds_void_t*)((SA) + (wave + NW * j) * 512), 16, 0, 0); } \
     _Pragma("unroll") for (int j = 0; j < PPW_B; ++j) {                                          \
       /* BT: tile (q_beg + fq) * 32 + t of the forward V, clamped to the last real tile (A is zero there) */ \
       const long long bo_ = BT ? (long long)b_goff[j] + min((long long)(q_beg + fq) * KC + bt_t[j], a.bt_T - 1) * 32 \
@@ -752,22 +767,28 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void wino_gem
 #define WS_SPLIT(X0, X1, H, M, L)                                                                \
   {                                                                                              \
     unsigned th[4], tm[4], tl[4];                                                                \
-    split_pair(X0[0], X0[1], th[0], tm[0], tl[0]);                                               \
-    split_pair(X0[2], X0[3], th[1], tm[1], tl[1]);                                               \
-    split_pair(X1[0], X1[1], th[2], tm[2], tl[2]);                                               \
-    split_pair(X1[2], X1[3], th[3], tm[3], tl[3]);                                               \
+    if (FCD_SEXP & 1) {                                                                          \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                            \
+        th[e] = __float_as_uint(X0[e]); tm[e] = __float_as_uint(X1[e]); tl[e] = th[e] ^ tm[e]; } \
+    } else {                                                                                     \
+      split_pair(X0[0], X0[1], th[0], tm[0], tl[0]);                                             \
+      split_pair(X0[2], X0[3], th[1], tm[1], tl[1]);                                             \
+      split_pair(X1[0], X1[1], th[2], tm[2], tl[2]);                                             \
+      split_pair(X1[2], X1[3], th[3], tm[3], tl[3]);                                             \
+    }                                                                                            \
     H = u32x4{th[0], th[1], th[2], th[3]};                                                       \
     M = u32x4{tm[0], tm[1], tm[2], tm[3]};                                                       \
     L = u32x4{tl[0], tl[1], tl[2], tl[3]};                                                       \
   }
 #define WS_SIX(AH, AM, AL, BH, BM_, BL)                                                          \
-  WS_MFMA(AL, BH) WS_MFMA(AH, BL) WS_MFMA(AM, BM_) WS_MFMA(AM, BH) WS_MFMA(AH, BM_) WS_MFMA(AH, BH)
+  if (!(FCD_SEXP & 2)) { WS_MFMA(AL, BH) WS_MFMA(AH, BL) WS_MFMA(AM, BM_) WS_MFMA(AM, BH) WS_MFMA(AH, BM_) } \
+  WS_MFMA(AH, BH)
 // One 32-element stage = two MFMA steps.  Program order = the software pipeline the scheduler is then pinned to with
 // sched_group_barrier: all LDS reads of the stage, the split of step 0, then the 24 MFMAs of step 0 with the split of
 // step 1 in their shadows (4 VALU per MFMA), then the 24 MFMAs of step 1.
 #define WS_STEP(SA, SB, SAN, SBN)                                                                \
   {                                                                                              \
-    if (fb < nb) WS_DMA(SAN, SBN)                                                                \
+    if (!(FCD_SEXP & 8) && !(FCD_YEXP & 16)) if (fb < nb) WS_DMA(SAN, SBN)                       \
     f32x4 xr[2][2][2];                                                                           \
     u32x4 ah[2][2], am[2][2], al[2][2], bh[2][2], bm[2][2], bl[2][2];                            \
     _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                \
@@ -777,22 +798,23 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void wino_gem
           xr[s][i][0] = f32x4{bp_[0], bp_[32], bp_[64], bp_[96]};                                \
           xr[s][i][1] = f32x4{bp_[128], bp_[160], bp_[192], bp_[224]};                           \
         } else {                                                                                 \
-        xr[s][i][0] = *(const f32x4*)((SB) + boff[i] + (((2 * s) ^ swb) * 4));     \
-        xr[s][i][1] = *(const f32x4*)((SB) + boff[i] + (((2 * s + 1) ^ swb) * 4)); \
+        xr[s][i][0] = (FCD_SEXP & 32) ? f32x4{(float)lane, 1.f, (float)s, 2.f} : *(const f32x4*)((SB) + boff[i] + (((2 * s) ^ swb) * 4));     \
+        xr[s][i][1] = (FCD_SEXP & 32) ? f32x4{(float)i, 3.f, (float)lane, 2.f} : *(const f32x4*)((SB) + boff[i] + (((2 * s + 1) ^ swb) * 4)); \
         }                                                                                        \
       }                                                                                          \
     _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                \
       _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                            \
         const unsigned short* ap = (SA) + aoff[i] + ((s ^ swa) * 8);                             \
-        ah[s][i] = *(const u32x4*)(ap);                        \
-        am[s][i] = *(const u32x4*)(ap + 2 * BM * 2 * 8);       \
-        al[s][i] = *(const u32x4*)(ap + 2 * (2 * BM * 2 * 8)); \
+        ah[s][i] = (FCD_SEXP & 32) ? u32x4{(unsigned)lane, 1u, (unsigned)s, 7u} : *(const u32x4*)(ap);                        \
+        am[s][i] = (FCD_SEXP & 32) ? u32x4{(unsigned)i, 1u, (unsigned)lane, 7u} : *(const u32x4*)(ap + 2 * BM * 2 * 8);       \
+        al[s][i] = (FCD_SEXP & 32) ? u32x4{(unsigned)lane, 3u, (unsigned)s, 9u} : *(const u32x4*)(ap + 2 * (2 * BM * 2 * 8)); \
       }                                                                                          \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) WS_SPLIT(xr[0][i][0], xr[0][i][1], bh[0][i], bm[0][i], bl[0][i]) \
     WS_SIX(ah[0], am[0], al[0], bh[0], bm[0], bl[0])                                             \
+    if ((FCD_YEXP & 16) && !(FCD_SEXP & 8)) if (fb < nb) WS_DMA(SAN, SBN)                        \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) WS_SPLIT(xr[1][i][0], xr[1][i][1], bh[1][i], bm[1][i], bl[1][i]) \
     WS_SIX(ah[1], am[1], al[1], bh[1], bm[1], bl[1])                                             \
-    {                                                                                            \
+    if (!(FCD_SEXP & 16)) {                                                                      \
       __builtin_amdgcn_sched_group_barrier(0x100, BT ? 44 : 20, 0);                              \
       __builtin_amdgcn_sched_group_barrier(0x002, 88, 0);                                        \
       _Pragma("unroll") for (int k = 0; k < 22; ++k) {                                           \
@@ -802,7 +824,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void wino_gem
       __builtin_amdgcn_sched_group_barrier(0x008, 26, 0);                                        \
     }                                                                                            \
     __builtin_amdgcn_sched_barrier(0);                                                           \
-    __syncthreads();                                                                             \
+    if (!(FCD_SEXP & 4)) __syncthreads();                                                        \
   }
 
   WS_DMA(sa0, sb0)
@@ -825,7 +847,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void wino_gem
 #pragma unroll
             for (int g = 0; g < 4; ++g)
               { const f32x4 cv_ = f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                *(f32x4*)(blk + g * 128) = cv_; }
+                if (FCD_NT_EXP & 8) __builtin_nontemporal_store(cv_, (f32x4*)(blk + g * 128)); else *(f32x4*)(blk + g * 128) = cv_; }
           }
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
@@ -843,7 +865,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void wino_gem
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int n = n0 + wn * 64 + j * 32 + l31;
-          if (m < a.M && n < ldc) Cb[(size_t)m * ldc + n] = acc[i][j][r];
+          if (m < a.M && n < ldc && (!(FCD_SEXP & 128) || acc[i][j][r] == 12345.f)) Cb[(size_t)m * ldc + n] = acc[i][j][r];
           acc[i][j][r] = 0.f;
         }
       }
@@ -928,7 +950,7 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split_res_kernel(WinoGemmArg
     const int n0f = fnt * BN;                                                                    \
     _Pragma("unroll") for (int j = 0; j < PPW_B; ++j)                                            \
       __builtin_amdgcn_global_load_lds((gbl_void_t*)(bs_ + (size_t)min(n0f + b_row[j], a.N - 1) * a.b_ld + b_in[j]), \
-                                       (lds_void_t*)((SB) + (wave + NW * j) * 256), 16, 0, 0);   \
+                                       (lds_void_t*)((SB) + (wave + NW * j) * 256), 16, 0, (FCD_NT_EXP & 4) ? 2 : 0);   \
     if (++fq == Q) { fq = 0; ++fnt; }                                                            \
   }
 #define R_MFMA(AV, BV)                                                                           \
@@ -985,7 +1007,7 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split_res_kernel(WinoGemmArg
           float* blk = Cb + ((size_t)mb * a.c_tblk + tb) * 1024 + (half * 4 * 32 + l31) * 4;     \
           _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                        \
             const f32x4 cv_ = f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]}; \
-            *(f32x4*)(blk + g * 128) = cv_;                                                      \
+            if (FCD_NT_EXP & 8) __builtin_nontemporal_store(cv_, (f32x4*)(blk + g * 128)); else *(f32x4*)(blk + g * 128) = cv_; \
           }                                                                                      \
         }                                                                                        \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;                       \
@@ -1103,9 +1125,9 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split256_kernel(WinoGemmArgs
 #define Y_LOADA(SA, S, IH, AH, AM, AL)                                                           \
   _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                \
     const unsigned short* ap = (SA) + aoff[2 * (IH) + i] + (((S) ^ swa) * 8);                    \
-    AH[i] = *(const u32x4*)(ap);                        \
-    AM[i] = *(const u32x4*)(ap + 2 * BM * 2 * 8);         \
-    AL[i] = *(const u32x4*)(ap + 2 * (2 * BM * 2 * 8)); \
+    AH[i] = (FCD_SEXP & 32) ? u32x4{(unsigned)lane, 1u, (unsigned)(S), 7u} : *(const u32x4*)(ap);                        \
+    AM[i] = (FCD_SEXP & 32) ? u32x4{(unsigned)i, 1u, (unsigned)lane, 7u} : *(const u32x4*)(ap + 2 * BM * 2 * 8);         \
+    AL[i] = (FCD_SEXP & 32) ? u32x4{(unsigned)lane, 3u, (unsigned)(IH), 9u} : *(const u32x4*)(ap + 2 * (2 * BM * 2 * 8)); \
   }
 #define Y_MFMA(IH, AV, BV)                                                                       \
   _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                  \
@@ -1117,27 +1139,31 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split256_kernel(WinoGemmArgs
 #define Y_STEP(SA, SB, SAN, SBN)                                                                 \
   {                                                                                              \
     YG_T(ys0)                                                                                    \
+    if (!(FCD_SEXP & 8) && !(FCD_YEXP & 14)) if (fb < nb) Y_DMA(SAN, SBN)                         \
     f32x4 xa[2][2];                                                                              \
     u32x4 pah[2], pam[2], pal[2], qah[2], qam[2], qal[2];                                        \
     u32x4 bh0[2], bm0[2], bl0[2], bh1[2], bm1[2], bl1[2];                                        \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                              \
-      xa[j][0] = *(const f32x4*)((SB) + boff[j] + ((0 ^ swb) * 4)); \
-      xa[j][1] = *(const f32x4*)((SB) + boff[j] + ((1 ^ swb) * 4)); \
+      xa[j][0] = (FCD_SEXP & 32) ? f32x4{(float)lane, 1.f, 0.f, 2.f} : *(const f32x4*)((SB) + boff[j] + ((0 ^ swb) * 4)); \
+      xa[j][1] = (FCD_SEXP & 32) ? f32x4{(float)j, 3.f, (float)lane, 2.f} : *(const f32x4*)((SB) + boff[j] + ((1 ^ swb) * 4)); \
     }                                                                                            \
     Y_LOADA(SA, 0, 0, pah, pam, pal)                                                             \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) WS_SPLIT(xa[j][0], xa[j][1], bh0[j], bm0[j], bl0[j]) \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                              \
-      xa[j][0] = *(const f32x4*)((SB) + boff[j] + ((2 ^ swb) * 4)); \
-      xa[j][1] = *(const f32x4*)((SB) + boff[j] + ((3 ^ swb) * 4)); \
+      xa[j][0] = (FCD_SEXP & 32) ? f32x4{(float)lane, 1.f, 2.f, 2.f} : *(const f32x4*)((SB) + boff[j] + ((2 ^ swb) * 4)); \
+      xa[j][1] = (FCD_SEXP & 32) ? f32x4{(float)j, 3.f, (float)lane, 2.f} : *(const f32x4*)((SB) + boff[j] + ((3 ^ swb) * 4)); \
     }                                                                                            \
+    if (FCD_YEXP & 1) __builtin_amdgcn_s_setprio(2);                                             \
     YG_T(ys1)                                                                                    \
     Y_SIX(0, pah, pam, pal, bh0, bm0, bl0)                                                       \
+    if ((FCD_YEXP & 2) && !(FCD_SEXP & 8)) if (fb < nb) Y_DMA(SAN, SBN)                          \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) WS_SPLIT(xa[j][0], xa[j][1], bh1[j], bm1[j], bl1[j]) \
     Y_LOADA(SA, 0, 1, qah, qam, qal)                                                             \
     Y_SIX(1, qah, qam, qal, bh0, bm0, bl0)                                                       \
-    if (fb < nb) Y_DMA(SAN, SBN)      /* the NEXT stage's LDS-DMA: behind the second MFMA group (see above) */ \
+    if ((FCD_YEXP & 4) && !(FCD_SEXP & 8)) if (fb < nb) Y_DMA(SAN, SBN)                          \
     Y_LOADA(SA, 1, 0, pah, pam, pal)                                                             \
     Y_SIX(0, pah, pam, pal, bh1, bm1, bl1)                                                       \
+    if ((FCD_YEXP & 8) && !(FCD_SEXP & 8)) if (fb < nb) Y_DMA(SAN, SBN)                          \
     Y_LOADA(SA, 1, 1, qah, qam, qal)                                                             \
     Y_SIX(1, qah, qam, qal, bh1, bm1, bl1)                                                       \
     __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);     /* B raw step 0, A (0, 0) */         \
@@ -1165,6 +1191,7 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split256_kernel(WinoGemmArgs
     }                                                                                            \
     __builtin_amdgcn_sched_group_barrier(0x008, 36, 0);                                          \
     __builtin_amdgcn_sched_barrier(0);                                                           \
+    if (FCD_YEXP & 1) __builtin_amdgcn_s_setprio(0);                                             \
     YG_T(ys2)                                                                                    \
     if (YG_TIME) __builtin_amdgcn_s_waitcnt(0x0F70);        /* vmcnt(0): the wave's share of the next stage's LDS-DMA has landed */ \
     YG_T(ys2b)                                                                                   \
@@ -1194,7 +1221,7 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split256_kernel(WinoGemmArgs
 #pragma unroll
             for (int g = 0; g < 4; ++g)
               { const f32x4 cv_ = f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                __builtin_nontemporal_store(cv_, (f32x4*)(blk + g * 128)); }      /* M is consumed once, by the output transform: measured -2 ... -4 % on the 256-row launches and their output transforms; the 128-row kernels lose with the same hint */
+                if (YG_PLAINC) *(f32x4*)(blk + g * 128) = cv_; else __builtin_nontemporal_store(cv_, (f32x4*)(blk + g * 128)); }      /* M is consumed once, by the output transform: measured -2 ... -4 % on the 256-row launches and their output transforms; the 128-row kernels lose with the same hint */
           }
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
@@ -1235,6 +1262,180 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split256_kernel(WinoGemmArgs
 #undef Y_MFMA
 #undef Y_LOADA
 #undef Y_DMA
+}
+
+// The same 256 x 256 tile as a two-group ping-pong (MI355X_MICROARCH.md, "Two waves per SIMD"): waves 0-3 (upper 128
+// rows, group A) and their SIMD partners 4-7 (lower 128 rows, group B) run the same stage loop ONE barrier interval
+// apart, so that in every interval each SIMD has one wave in its compute segment (48 MFMAs of a 16-element reduction
+// step, the second half's A fragments read from LDS in their shadow) beside one in its load segment (B fragments and the
+// first A fragments LDS -> registers, exact bf16 split of B, then the wave's 5 of the 40 LDS-DMA wave-instructions of
+// the stage two ahead).  The matrix pipe never waits for a split or an LDS round trip of its own wave.  Ring of four
+// 40-KB LDS stages = the whole LDS:
+//   interval 2n  : A load(n), A's half of DMA(n+2)    | B compute(n-1)
+//   interval 2n+1: A compute(n)                        | B load(n), B's half of DMA(n+2)
+// Slot (n+2) % 4 held stage n-2, last read in B's compute(n-2) = interval 2n-2; stage n+2 is first read in interval
+// 2n+4, after each group waited for its own half (vmcnt) before a barrier that precedes it.
+template <int DUMMY>
+__global__ __launch_bounds__(512, 1) void wino_gemm_split_pp_kernel(WinoGemmArgs a) {
+  constexpr int BM = 256, BN = 256;
+  constexpr int A_UNITS = 3 * 2 * BM;              // [plane][half][row] x 16 B (8 bf16)
+  constexpr int B_UNITS = 2 * BN * 2;              // [half][row][2 units of 4 fp32]
+    __shared__ __attribute__((aligned(16))) unsigned short sa0[A_UNITS * 8];
+  __shared__ __attribute__((aligned(16))) unsigned short sa1[A_UNITS * 8];
+  __shared__ __attribute__((aligned(16))) unsigned short sa2[A_UNITS * 8];
+  __shared__ __attribute__((aligned(16))) unsigned short sa3[A_UNITS * 8];
+  __shared__ __attribute__((aligned(16))) float sb0[B_UNITS * 4];
+  __shared__ __attribute__((aligned(16))) float sb1[B_UNITS * 4];
+  __shared__ __attribute__((aligned(16))) float sb2[B_UNITS * 4];
+  __shared__ __attribute__((aligned(16))) float sb3[B_UNITS * 4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wm = wave >> 2, wn = wave & 3;
+  unsigned v;
+  {
+    const unsigned total = gridDim.x, b = blockIdx.x;
+    if (a.xcd_remap) {
+      const unsigned q8 = total >> 3, r8 = total & 7u, xcd = b & 7u;
+      v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
+    } else {
+      v = b;
+    }
+  }
+  const int mt = (int)(v % (unsigned)a.m_tiles), nt = (int)(v / (unsigned)a.m_tiles);
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int Q = a.Kc / 16;                         // stages per batch (even)
+  const int b_first = (int)blockIdx.y * a.xb;
+  const int nb = min(a.xb, a.batches - b_first);
+  const int S = nb * Q;
+  const unsigned short* Ab = a.As + (size_t)b_first * a.a_batch + (size_t)m0 * a.a_ld;
+  const float* Bb = a.B + (size_t)b_first * a.b_batch + (size_t)n0 * a.b_ld;
+
+  // DMA (group B only; wave-instruction p of wave wn covers units (wn + 4 p) * 64 + lane).  A: 512 units per plane,
+  // so instruction p lies in plane p / 2.
+  // every wave issues 5 of the 40 wave-instructions of a stage: its group's half of each A plane and of the B slab
+  int a_goff[1], b_goff[2];
+  {
+    const int rem = (wn + 4 * wm) * 64 + lane;     // unit inside the plane: half * 256 + row
+    const int h = rem / BM, row = rem % BM;
+    a_goff[0] = (int)(min(row, a.M - 1 - m0) * a.a_ld) + h * 8;
+  }
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int u = (wn + 4 * (2 * p + wm)) * 64 + lane;
+    const int h = u / (BN * 2), row = (u >> 1) % BN, pj = u & 1;
+    const int jl = pj ^ ((row >> 4) & 1);          // 32-B row pitch: rows 16..31 of a block take the other unit parity
+    b_goff[p] = (int)(min(row, a.N - 1 - n0) * a.b_ld) + h * 8 + jl * 4;
+  }
+  int aoff[4], boff[2];
+  const int swb = (l31 >> 4) & 1;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) aoff[i] = (half * BM + wm * 128 + i * 32 + l31) * 8;        // bf16 elements, plane 0
+#pragma unroll
+  for (int j = 0; j < 2; ++j) boff[j] = (half * BN + wn * 64 + j * 32 + l31) * 8;         // floats, unit 0
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  int fq = 0, fb = 0;        // stage / batch of the next slab pair to fetch (group B)
+  int cq = 0, cb = 0;        // stage / batch being multiplied
+#define P_DMA(SA, SB)                                                                            \
+  {                                                                                              \
+    const unsigned short* as_ = Ab + (size_t)fb * a.a_batch + (size_t)fq * 16;                   \
+    const float* bs_ = Bb + (size_t)fb * a.b_batch + (size_t)(fq >> 1) * a.b_adv + (fq & 1) * 16; \
+    _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)       /* half `wm` of plane pl */             \
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(as_ + (size_t)pl * a.as_plane + a_goff[0]),  \
+                                       (lds_void_t*)((SA) + (pl * 8 + wn + 4 * wm) * 512), 16, 0, 0); \
+    _Pragma("unroll") for (int p = 0; p < 2; ++p)                                                \
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(bs_ + b_goff[p]),                           \
+                                       (lds_void_t*)((SB) + (wn + 4 * (2 * p + wm)) * 256), 16, 0, 0); \
+    /* past the last stage the last slabs are fetched again into a slot nobody reads any more: the number of DMA */ \
+    /* instructions of this wave in flight behind the stage being waited for is 5 on every path                              */ \
+    if (!(fb == nb - 1 && fq == Q - 1)) { if (++fq == Q) { fq = 0; ++fb; } }                     \
+  }
+#define P_LOADA(SA, IH, AH, AM, AL)                                                              \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                \
+    const unsigned short* ap = (SA) + aoff[2 * (IH) + i];                                        \
+    AH[i] = *(const u32x4*)(ap);                                                                 \
+    AM[i] = *(const u32x4*)(ap + 2 * BM * 8);                                                    \
+    AL[i] = *(const u32x4*)(ap + 2 * (2 * BM * 8));                                              \
+  }
+#define P_MFMA(IH, AV, BV)                                                                       \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                  \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                \
+      acc[2 * (IH) + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                            \
+          __builtin_bit_cast(bf16x8, AV[i]), __builtin_bit_cast(bf16x8, BV[j]), acc[2 * (IH) + i][j], 0, 0, 0);
+#define P_SIX(IH, AH, AM, AL)                                                                    \
+  P_MFMA(IH, AL, bh) P_MFMA(IH, AH, bl) P_MFMA(IH, AM, bm) P_MFMA(IH, AM, bh) P_MFMA(IH, AH, bm) P_MFMA(IH, AH, bh)
+// one stage of one wave: load segment, barrier, compute segment, barrier
+#define P_STAGE(SA, SB, FA, FB)                                                                  \
+  {                                                                                              \
+    u32x4 bh[2], bm[2], bl[2], pah[2], pam[2], pal[2], qah[2], qam[2], qal[2];                   \
+    {                                                                                            \
+      f32x4 xa[2][2];                                                                            \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                            \
+        xa[j][0] = *(const f32x4*)((SB) + boff[j] + ((0 ^ swb) * 4));                            \
+        xa[j][1] = *(const f32x4*)((SB) + boff[j] + ((1 ^ swb) * 4));                            \
+      }                                                                                          \
+      P_LOADA(SA, 0, pah, pam, pal)                                                              \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) WS_SPLIT(xa[j][0], xa[j][1], bh[j], bm[j], bl[j]) \
+    }                                                                                            \
+    if (!(FCD_SEXP & 8)) {                                                                       \
+      P_DMA(FA, FB)                                                                              \
+      __builtin_amdgcn_s_waitcnt(0x0F75);                                /* vmcnt(5) */          \
+    }                                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    __builtin_amdgcn_s_barrier();                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    P_LOADA(SA, 1, qah, qam, qal)                                                                \
+    P_SIX(0, pah, pam, pal)                                                                      \
+    P_SIX(1, qah, qam, qal)                                                                      \
+    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);                                           \
+    __builtin_amdgcn_sched_group_barrier(0x008, 48, 0);                                          \
+    if (++cq == Q) {                                                                             \
+      cq = 0;                                                                                    \
+      int ldc = a.N;                                                                             \
+      asm volatile("" : "+s"(ldc));                                                              \
+      float* Cb = a.C + (size_t)(b_first + cb) * a.M * ldc;                                      \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                              \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                         \
+          const int m = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;              \
+          _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                        \
+            const int n = n0 + wn * 64 + j * 32 + l31;                                           \
+            if (m < a.M && n < ldc) Cb[(size_t)m * ldc + n] = acc[i][j][r];                      \
+            acc[i][j][r] = 0.f;                                                                  \
+          }                                                                                      \
+        }                                                                                        \
+      ++cb;                                                                                      \
+    }                                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    __builtin_amdgcn_s_barrier();                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+  }
+
+  P_DMA(sa0, sb0)
+  P_DMA(sa1, sb1)              // (S >= 2: reductions of >= 32 elements only)
+  __builtin_amdgcn_s_waitcnt(0x0F75);            // vmcnt(5): this wave's part of stage 0 has landed
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();     // group B runs one interval behind
+#pragma unroll 1
+  for (int g = 0; g < S; g += 4) {
+    P_STAGE(sa0, sb0, sa2, sb2)
+    if (g + 1 < S) P_STAGE(sa1, sb1, sa3, sb3)
+    if (g + 2 < S) P_STAGE(sa2, sb2, sa0, sb0)
+    if (g + 3 < S) P_STAGE(sa3, sb3, sa1, sb1)
+  }
+  if (wm == 0) __builtin_amdgcn_s_barrier();     // ... and group A waits for it at the end
+  __builtin_amdgcn_s_waitcnt(0x0F70);            // the surplus prefetches must land before the LDS allocation is released
+#undef P_STAGE
+#undef P_SIX
+#undef P_MFMA
+#undef P_LOADA
+#undef P_DMA
 }
 
 static int wino_gemm_cfg() {     // FCD_WINO_TILE: 0 = 128x128 (4 waves), 1 = 256x128 (8 waves), 2 = 256x256 (16 waves)
@@ -1308,18 +1509,22 @@ static void wino_gemm_launch(WinoGemmArgs ga, int batches, int splits, hipStream
       return;
     }
     // FCD_WINO_SPLIT_BIG: 0 = 128 x 128 tiles only; 1 (default) = 256 x 256 two-stage kernel for GEMMs with >= 256
-    // rows and enough tiles to fill the chip; 2 = ... for every GEMM with >= 256 rows (tests)
+    // rows and enough tiles to fill the chip; 2 = ... for every GEMM with >= 256 rows (tests); 4 / 5 = the same two
+    // policies with the ping-pong kernel (measured slower: DESIGN.md)
     static int big = -1;
     if (big < 0) { const char* e = getenv("FCD_WINO_SPLIT_BIG"); big = e ? atoi(e) : 1; }
-    const bool force = big == 2 || wino_split() == 2;
+    const bool force = big == 2 || big == 5 || wino_split() == 2;
     if (big && ga.M >= 256 && (force || (long long)cdiv(ga.M, 256) * cdiv(ga.N, 256) * batches >= 1024)) {
       ga.m_tiles = cdiv(ga.M, 256); ga.n_tiles = cdiv(ga.N, 256);
       ga.xb = wino_gemm_xb((long long)ga.m_tiles * ga.n_tiles * 2, batches, 1, ga.Kc / 32);
       const dim3 grid((unsigned)(ga.m_tiles * ga.n_tiles), (unsigned)cdiv(batches, ga.xb));
+      if (big >= 4) hipLaunchKernelGGL((wino_gemm_split_pp_kernel<0>), grid, dim3(512), 0, st, ga);
+      else {
 #if YG_TIME
-      ga.tbuf = g_yg_tbuf;
+        ga.tbuf = g_yg_tbuf;
 #endif
-      hipLaunchKernelGGL((wino_gemm_split256_kernel<0>), grid, dim3(512), 0, st, ga);
+        hipLaunchKernelGGL((wino_gemm_split256_kernel<0>), grid, dim3(512), 0, st, ga);
+      }
       return;
     }
     ga.m_tiles = cdiv(ga.M, 128); ga.n_tiles = cdiv(ga.N, 128);
@@ -1699,7 +1904,8 @@ static bool wino_blk_path(const WinoPlan& pl) {
   static int cblk_on = -1;
   if (cblk_on < 0) {
     const char* e = getenv("FCD_WINO_CBLK");
-    cblk_on = (e && e[0] == '0') ? 0 : 1;
+    const char* e2 = getenv("FCD_WINO_SPLIT_BIG");
+    cblk_on = ((e && e[0] == '0') || (e2 && atoi(e2) >= 4)) ? 0 : 1;      // (the ping-pong experiment kernel writes row-major)
   }
   return cblk_on && pl.m == 4 && pl.rows > 64 && wino_split() && (pl.rows & 3) == 0;
 }

@@ -33,8 +33,18 @@ typedef __attribute__((address_space(1))) const void gbl_void_t;
 
 int fcd_wino_mode_now();   // conv_wino.hip: 0 = direct kernels only (tests' A/B switch), 2 / 4 otherwise
 
-// [r5] The wrong-result diagnostic switches (W2_EXP: no memory instruction in the loop, no barrier, operands from registers, one
-// patch buffer ...) and the W2_LATE / W2_DEEP A/B switches live in csrc/lab/conv_wino2.hip (`make lab`), not in this source.
+// W2_EXP: diagnostic builds only (WRONG results): 1 = no filter DMA / patch loads / LDS stores in the loop, 2 = no barrier in the
+// loop, 4 = operands from registers instead of LDS, 8 = no transform adds, 64 = ONE patch buffer (racy; LDS 68 KB: is a
+// second resident workgroup per CU worth a second barrier per stage?)
+#ifndef W2_EXP
+#define W2_EXP 0
+#endif
+#ifndef W2_DEEP
+#define W2_DEEP 1
+#endif
+#ifndef W2_LATE
+#define W2_LATE 0     // 1: the next stage's filter LDS-DMA is issued after the first 4-channel group of the stage instead of at its top
+#endif
 // W2_TIME: attribution build (tools/w2_segments.py): every wave stamps s_memtime at the segment borders of its
 // stage loop and writes the per-segment cycle sums {prologue, issue (filter DMA + patch loads), operands + transforms + MFMA issue,
 // LDS commit of the next patch (waits for its global loads), barrier, epilogue, total} to a debug buffer.  Results stay correct;
@@ -70,7 +80,7 @@ constexpr int W2_RP = 72;                   // pair-row pitch (floats): 34 colum
 //   fetch and 1.5x halo rows; kept for the record
 //   4 waves x 4 tile rows each, 8 x 32 pixels (FCD_WINO2_WAVES=1: one wave per SIMD, 256 VGPRs + 256 AGPRs): 8.9 ms as
 //   the compiler schedules it -- a single wave per SIMD needs a hand-pipelined operand prefetch to hide its LDS reads
-// Where the 6.2 ms go (diagnostic builds, lab/conv_wino2.hip): pure MFMA floor 2.85 ms; MFMA + transforms + per-workgroup prologue /
+// Where the 6.2 ms go (diagnostic builds, W2_EXP): pure MFMA floor 2.85 ms; MFMA + transforms + per-workgroup prologue /
 // epilogue with NO memory instruction in the loop 4.0 ms (one workgroup per CU: nothing hides the prologue's memory
 // round trip and the epilogue's stores); + LDS operand reads 0.9, + filter DMA / patch loads / LDS stores 0.9, + barrier
 // 0.3.  PMC: 47 % MFMA-busy, 32 % of wave cycles parked at s_waitcnt / s_barrier (profiles/r02_pmc_wino2.md).
@@ -145,7 +155,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wino2_kernel(Wino2Args a) {
   constexpr int U_PER_W = (U_INSTR + NW - 1) / NW;
   __shared__ __attribute__((aligned(16))) float su0[U_STAGE];
   __shared__ __attribute__((aligned(16))) float su1[U_STAGE];
-  __shared__ __attribute__((aligned(16))) float sx[2 * XS_SZ];
+  __shared__ __attribute__((aligned(16))) float sx[((W2_EXP & 64) ? 1 : 2) * XS_SZ];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = wave & 3, hrow = wave >> 2;
@@ -196,7 +206,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wino2_kernel(Wino2Args a) {
   constexpr int P_ELEMS = W2_CB * PPH * PPW;
   constexpr int L_PER_T = (SRC == 2) ? (P_ELEMS + NT - 1) / NT : X_PER_T;
   constexpr int L_ELEMS = (SRC == 2) ? P_ELEMS : X_ELEMS;
-  constexpr bool DEEP = (SRC == 0 || SRC == 2);
+  constexpr bool DEEP = (SRC == 0 || SRC == 2) && (W2_DEEP != 0);
   float xr[L_PER_T], xr2[DEEP ? L_PER_T : 1], mr[SRC == 1 ? L_PER_T : 1];
   unsigned xr_c[SRC == 2 ? L_PER_T : 1], xr2_c[SRC == 2 ? L_PER_T : 1], x_boff[L_PER_T];
   // per staged element: byte offset in the source chunk + ONE packed word.  Patch-position staging: {LDS offset of the .x copy
@@ -290,23 +300,24 @@ __global__ __launch_bounds__(64 * NW) void conv_wino2_kernel(Wino2Args a) {
   {                                                                                                  \
     const int cch = (CH);                                                                             \
     const bool have_next = cch + 1 < a.nchunks;                                                       \
-    const int xb = cch & 1;                                                                           \
+    const int xb = (W2_EXP & 64) ? 0 : (cch & 1);                                                     \
     W2_T(ts0)                                                                                         \
-    if (have_next) {                                                                                 \
-      W2_DMA(cch + 1, UNXT)                                                                           \
+    if (have_next && !(W2_EXP & 1)) {                                                                \
+      if (!W2_LATE) W2_DMA(cch + 1, UNXT)                                                             \
       if (!DEEP) W2_LOAD_X(cch + 1, XNEXT)                                                            \
     }                                                                                                \
     if (DEEP && cch + 2 < a.nchunks) W2_LOAD_X(cch + 2, XFAR)                                         \
     W2_T(ts1)                                                                                         \
     const float* xl = sx + xb * XS_SZ;                                                               \
     _Pragma("unroll") for (int ks = 0; ks < W2_KS; ++ks) {                                           \
+    if (W2_LATE && ks == 1 && have_next && !(W2_EXP & 1)) W2_DMA(cch + 1, UNXT)                      \
     if (W2_KS == 3 && ks > 0 && cch * W2_CB + ks * 4 >= a.C) continue;   /* 12-channel stages: the last one may hold 4 or 8 */ \
     float av[16];                                                                                    \
     {                                                                                                \
       const float* up = (UCUR) + ks * W2_SLAB + aoff;                                                \
-      const f32x4 r0 = *(const f32x4*)up;    \
-      const f32x4 r1 = *(const f32x4*)(up + 4);     \
-      const f32x4 r2 = *(const f32x4*)(up + 8);     \
+      const f32x4 r0 = (W2_EXP & 4) ? f32x4{(float)lane, 1.f, 2.f, (float)ks} : *(const f32x4*)up;    \
+      const f32x4 r1 = (W2_EXP & 4) ? f32x4{3.f, (float)lane, 2.f, 1.f} : *(const f32x4*)(up + 4);     \
+      const f32x4 r2 = (W2_EXP & 4) ? f32x4{1.f, 1.f, (float)lane, 4.f} : *(const f32x4*)(up + 8);     \
       const float tt[12] = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3], r2[0], r2[1], r2[2], r2[3]}; \
       _Pragma("unroll") for (int ar = 0; ar < 4; ++ar) {   /* (G g) G^T: u0 = x0, u1 = m + h, u2 = m - h, u3 = x2 */ \
         const float x0 = tt[3 * ar], hh = tt[3 * ar + 1], x2 = tt[3 * ar + 2];                       \
@@ -321,8 +332,8 @@ __global__ __launch_bounds__(64 * NW) void conv_wino2_kernel(Wino2Args a) {
       const float* xp = xl + ks * 4 * W2_PL + boff[pg];                                               \
       f32x2 d[4][4];                                                                                 \
       _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                \
-        const f32x4 q0 = *(const f32x4*)(xp + i * W2_RP);      \
-        const f32x4 q1 = *(const f32x4*)(xp + i * W2_RP + 4);  \
+        const f32x4 q0 = (W2_EXP & 4) ? f32x4{(float)lane, (float)i, 1.f, 2.f} : *(const f32x4*)(xp + i * W2_RP);      \
+        const f32x4 q1 = (W2_EXP & 4) ? f32x4{1.f, (float)lane, (float)i, 3.f} : *(const f32x4*)(xp + i * W2_RP + 4);  \
         d[i][0] = __builtin_shufflevector(q0, q0, 0, 1); d[i][1] = __builtin_shufflevector(q0, q0, 2, 3); \
         d[i][2] = __builtin_shufflevector(q1, q1, 0, 1); d[i][3] = __builtin_shufflevector(q1, q1, 2, 3); \
       }                                                                                              \
@@ -352,9 +363,9 @@ __global__ __launch_bounds__(64 * NW) void conv_wino2_kernel(Wino2Args a) {
     }                                                                                                \
     }                                                                                                \
     W2_T(ts2)                                                                                         \
-    if (have_next) W2_STORE_X(xb ^ 1, cch + 1, XNEXT)                                                 \
+    if (have_next && !(W2_EXP & 1)) W2_STORE_X(((W2_EXP & 64) ? 0 : (xb ^ 1)), cch + 1, XNEXT)        \
     W2_T(ts3)                                                                                         \
-    __syncthreads();     /* (a hand-written `s_waitcnt vmcnt(X_PER_T)` + s_barrier that keeps the DEEP loads in flight makes LLVM's waitcnt pass put a vmcnt(0) right behind the next stage's loads: measured on the ISA, not kept) */ \
+    if (!(W2_EXP & 2)) __syncthreads();     /* (a hand-written `s_waitcnt vmcnt(X_PER_T)` + s_barrier that keeps the DEEP loads in flight makes LLVM's waitcnt pass put a vmcnt(0) right behind the next stage's loads: measured on the ISA, not kept) */ \
     W2_T(ts4)                                                                                         \
     W2_TACC(1, ts1, ts0) W2_TACC(2, ts2, ts1) W2_TACC(3, ts3, ts2) W2_TACC(4, ts4, ts3)               \
   }

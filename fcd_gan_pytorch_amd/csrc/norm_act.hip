@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
   __shared__ double red[16];
   const int c = blockIdx.x, g = blockIdx.y, sp = blockIdx.z;
   double s1 = 0.0, s2 = 0.0;
-  if ((HW & 3) == 0) {
+  if ((HW & 3) == 0 && ((size_t)x & 15) == 0) {
     const int hw4 = HW >> 2;
     const long long total = (long long)Ng * hw4;
     const long long chunk = (total + split - 1) / split;
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void bn_act_apply_kernel(const float* __restri
   const float slope = slope_ptr ? slope_ptr[0] : slope_imm;
   const float* xp = x + (size_t)plane * HW;
   float* yp = y + (size_t)plane * HW;
-  if ((HW & 3) == 0) {
+  if ((HW & 3) == 0 && ((((size_t)x | (size_t)y)) & 15) == 0) {
     const int hw4 = HW >> 2;
     for (int i = blockIdx.y * 256 + threadIdx.x; i < hw4; i += gridDim.y * 256) {
       float4 v = reinterpret_cast<const float4*>(xp)[i];
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     s2 += (double)dyv * (double)((xv - mu) * is);
     if (act == FCD_ACT_PRELU && yv <= 0.f) s3 += (double)dzv * (double)yv;
   };
-  if ((HW & 3) == 0) {
+  if ((HW & 3) == 0 && ((((size_t)x | (size_t)dz)) & 15) == 0) {
     // [r4] 16-B accesses, two units of each stream requested before the first is consumed (the scalar loop had one 4-B load per
     // stream in flight per thread and a 64-bit division per element: 4.2 TB/s where a two-stream read reaches > 5.5)
     const int hw4 = HW >> 2;
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     if (training) return sc * (dyv - k1 - (xv - mu) * is * k2);
     return dyv * sc;
   };
-  if ((HW & 3) == 0) {
+  if ((HW & 3) == 0 && ((((size_t)x | (size_t)dz | (size_t)dx)) & 15) == 0) {
     const int hw4 = HW >> 2;
     for (int i = blockIdx.y * 256 + threadIdx.x; i < hw4; i += gridDim.y * 256) {
       const float4 xv = reinterpret_cast<const float4*>(xp)[i], dv = reinterpret_cast<const float4*>(dp)[i];

@@ -475,7 +475,7 @@ __global__ void pair_gap_diff_fwd_kernel(const float* __restrict__ f, float* __r
   const float* fx = f + ((size_t)((2 * i) * n + s) * C + c) * HW;
   const float* fy = f + ((size_t)((2 * i + 1) * n + s) * C + c) * HW;
   double acc = 0.0;
-  if ((HW & 3) == 0) {
+  if ((HW & 3) == 0 && ((size_t)f & 15) == 0) {      // 16-B loads need an aligned base too (a view with a storage offset is contiguous, not aligned)
     for (int p = 4 * lane; p < HW; p += 256) {
       const float4 a = *reinterpret_cast<const float4*>(fx + p), b = *reinterpret_cast<const float4*>(fy + p);
       acc += (double)(a.x - b.x) + (double)(a.y - b.y) + (double)(a.z - b.z) + (double)(a.w - b.w);
@@ -614,7 +614,8 @@ extern "C" int fcd_masked_stack_fwd(const float* s0, const float* s1, const floa
   const double elems = (double)k * N * C * HW;
   FcdProfScope prof(FCD_K_POOL, (hipStream_t)stream, 0.0, 4.0 * 2.0 * elems);
   const int block = 256;
-  if ((HW & 3) == 0) {
+  const size_t al_f = (size_t)s0 | (size_t)s1 | (size_t)s2 | (size_t)s3 | (size_t)cmask | (size_t)z;      // (NULL sources: 0)
+  if ((HW & 3) == 0 && (al_f & 15) == 0) {
     const long long blocks = std::min<long long>(cdiv64((long long)(elems / 4), block), 256 * 32);
     hipLaunchKernelGGL(masked_stack_fwd_kernel<4>, dim3((unsigned)blocks), dim3(block), 0, (hipStream_t)stream, s0, s1, s2, s3, k, cmask, z, N, C, HW);
   } else {
@@ -634,7 +635,9 @@ extern "C" int fcd_masked_stack_bwd(const float* dz, const float* s0, const floa
   const double elems = (double)k * N * C * HW;
   FcdProfScope prof(FCD_K_POOL, (hipStream_t)stream, 0.0, 4.0 * 2.0 * elems);
   const int block = 128;
-  if ((HW & 3) == 0) {
+  const size_t al_b = (size_t)dz | (size_t)s0 | (size_t)s1 | (size_t)s2 | (size_t)s3 | (size_t)cmask | (size_t)dcmask | (size_t)d0 |
+                      (size_t)d1 | (size_t)d2 | (size_t)d3;
+  if ((HW & 3) == 0 && (al_b & 15) == 0) {
     hipLaunchKernelGGL(masked_stack_bwd_kernel<4>, dim3((unsigned)cdiv64((long long)N * (HW / 4), block)), dim3(block), 0, (hipStream_t)stream,
                        dz, s0, s1, s2, s3, k, cmask, dcmask, d0, d1, d2, d3, N, C, HW);
   } else {

@@ -31,7 +31,9 @@ replayed step is not faster either (same box, 90.8 / 91.3 ms replayed vs 90.4 / 
 workload; the step is kernel-bound, its ~950 launches cost the host 10 - 12 ms, and ``hipGraphLaunch`` spends as long enqueuing
 the nodes) -- the wrapper is for hosts that ARE launch-bound (fewer cores per rank, smaller tiles).
 
-Rules: tensors in the returned dict are the graph's own buffers -- valid until the next call; a call whose tensor shapes or
+Rules: tensors in the returned dict are the graph's own buffers -- valid until the next call; tensor arguments may be passed
+positionally or by keyword (both are copied into the graph's input buffers before a replay); a step function that calls one
+optimizer's ``step()`` twice is not captured (``self.refused_multistep``); a call whose tensor shapes or
 keyword arguments differ from every captured signature is captured separately (``max_graphs``) or runs eagerly; the first
 ``warmup`` calls run eagerly (kernel modules, allocator pools and packed frozen filters settle).  Anything the graph reads
 that lives outside it (frozen VGG / Generator filters and their packed forms) is kept alive by the wrapper and its version is
@@ -43,11 +45,17 @@ from . import _ops as ops
 from . import dp as _dp
 
 
+def _tsig(a):
+    return (tuple(a.shape), str(a.dtype), str(a.device))
+
+
 def _sig(args, kw):
-    out = []
-    for a in args:
-        out.append((tuple(a.shape), str(a.dtype), str(a.device)) if torch.is_tensor(a) else ('obj', id(a)))
-    return tuple(out), tuple(sorted((k, v) for k, v in kw.items() if not torch.is_tensor(v)))
+    """Signature a captured graph is valid for: shapes / dtypes / devices of every tensor -- positional AND keyword (a tensor
+    passed as ``region=...`` is an input like any other: it gets a static buffer and is refreshed before every replay) -- plus the
+    identity of the other positional arguments and the values of the other keyword arguments."""
+    out = [(_tsig(a) if torch.is_tensor(a) else ('obj', id(a))) for a in args]
+    kws = tuple(sorted((k, (('tensor',) + _tsig(v)) if torch.is_tensor(v) else ('value', v)) for k, v in kw.items()))
+    return tuple(out), kws
 
 
 class GraphedStep:
@@ -60,6 +68,7 @@ class GraphedStep:
         self.eager_calls = 0
         self.enabled = True
         self.refused_dp = False
+        self.refused_multistep = False     # the step function calls one optimizer's step() more than once: not captured (see _capture)
         self._side = None
 
     # -------------------------------------------------------------------------------------------------
@@ -84,6 +93,7 @@ class GraphedStep:
     def _capture(self, args, kw):
         dev = next(a for a in args if torch.is_tensor(a)).device
         static = [a.clone() if torch.is_tensor(a) else a for a in args]
+        static_kw = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in kw.items()}
         counts = {}
         for o in self.optimizers:                      # count the step() calls of each optimizer inside one fn call
             o.use_device_hyper()
@@ -104,14 +114,18 @@ class GraphedStep:
         g = torch.cuda.CUDAGraph()
         try:
             with torch.cuda.graph(g, stream=self._side):
-                out = self._detached(self.fn(*static, **kw))
+                out = self._detached(self.fn(*static, **static_kw))
         finally:
             for o in self.optimizers:
                 del o._after_step                        # back to the class's method
         watch, keep = self._frozen_state()
         # BatchNorm buffers of nets in train() mode are moved by captured kernels (their versions change with every replay):
         # only tensors nothing in the graph writes are watched
-        entry = dict(graph=g, static=static, out=out, counts=counts, keep=keep,
+        if any(n > 1 for n in counts.values()):
+            # write_hyper() holds ONE set of scalars (learning rate, Adam bias corrections) per optimizer and replay: a second
+            # captured step() of the same optimizer would be replayed with the first one's bias correction.  Not captured.
+            return None
+        entry = dict(graph=g, static=static, static_kw=static_kw, out=out, counts=counts, keep=keep,
                      watch=[(t, t._version) for t in watch if not self._written_in_graph(t)])
         return entry
 
@@ -170,8 +184,16 @@ class GraphedStep:
         if entry is None:
             if len(self._graphs) >= self.max_graphs:      # e.g. the ragged last batch of an epoch: not worth a graph of its own
                 return self._eager(main, args, kw)        # (optimizers in device-hyper mode refresh their scalars themselves)
-            entry = self._graphs[key] = self._capture(args, kw)
+            entry = self._capture(args, kw)
+            if entry is None:                             # capture recorded launches only (nothing ran): run this call eagerly,
+                self.enabled, self.refused_multistep = False, True      # and every later one launch by launch
+                return self._eager(main, args, kw)
+            self._graphs[key] = entry
         for s, a in zip(entry['static'], args):
+            if torch.is_tensor(a) and s.data_ptr() != a.data_ptr():
+                s.copy_(a, non_blocking=True)
+        for k, a in kw.items():
+            s = entry['static_kw'][k]
             if torch.is_tensor(a) and s.data_ptr() != a.data_ptr():
                 s.copy_(a, non_blocking=True)
         for o in self.optimizers:

@@ -308,8 +308,14 @@ def _crit(p, name, C, per_band, sdV):
     return crit.to(DEV)
 
 
-def test_rsss_iteration_gradients_full_size(conv_path):
-    """configs[2]: Demo_RSSS.py:285-332 at 13 bands 256x256, 2 tile pairs (S and D stepped, RMSprop 5e-5)."""
+@pytest.mark.parametrize('literal', [False, True], ids=['minimal', 'literal'])
+def test_rsss_iteration_gradients_full_size(conv_path, literal):
+    """configs[2]: Demo_RSSS.py:285-332 at 13 bands 256x256, 2 tile pairs (S and D stepped, RMSprop 5e-5).  ``literal``: the
+    reference's own call order -- Discriminator step through the un-detached change map with retain_graph, second Discriminator
+    forward, Generator forward with a graph (steps.py) -- against the same oracle gradients (the literal order was only
+    compared at fixture size)."""
+    if literal and conv_path != 'winograd':
+        pytest.skip('the literal order is checked on the default plan')
     p = pkg()
     C, N, H = 13, 2, 256
     sdG = seeded_state(onets.generator_spec(C), 11)
@@ -340,7 +346,7 @@ def test_rsss_iteration_gradients_full_size(conv_path):
     store = {}
     oS.pre_step_hooks.append(_hook(store, 'S'))
     oD.pre_step_hooks.append(_hook(store, 'D'))
-    r = p.steps.rsss_adversarial_step(netS, netD, netG, crit, oS, oD, x.to(DEV), y.to(DEV), region.to(DEV))
+    r = p.steps.rsss_adversarial_step(netS, netD, netG, crit, oS, oD, x.to(DEV), y.to(DEV), region.to(DEV), literal=literal)
     # values: every logged loss, the change-density map (1e-4, north_star) and the thresholded map
     got = [float(r[k]) for k in ('d_loss', 's_loss', 's_d_loss', 'g_loss', 'l1_loss', 'r_loss', 'generator_loss', 'ssim_loss', 'perception_loss')]
     ref = [float(ro[k]) for k in ('d_loss', 's_loss', 's_d_loss', 'g_loss', 'l1_loss', 'r_loss', 'gen', 'ssim', 'perc')]
@@ -350,7 +356,7 @@ def test_rsss_iteration_gradients_full_size(conv_path):
     assert err <= 1e-4, 'density map L_inf %.2e' % err
     safe = (cmo - 0.5).abs() > 2e-4
     assert torch.equal((cm > 0.5)[safe], (cmo > 0.5)[safe])
-    tag = 'rsss_13x256_' + conv_path
+    tag = 'rsss_13x256_' + conv_path + ('_literal' if literal else '')
     own = _d_own_truths(d_truth, g64, r['cmap'].detach().cpu(), ro['cmap'].detach(), dcache)
     bad = check_net(tag, 'D', netD, 'rmsprop', 5e-5, store, n.capture['D'], n.D, g64['D'], conv_path, limD, truth_own=own)
     bad += check_net(tag, 'S', netS, 'rmsprop', 5e-5, store, n.capture['S'], n.S, g64['S'], conv_path, limS)

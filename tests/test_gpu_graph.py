@@ -30,7 +30,7 @@ def _setup(p):
     return netG, netS, netD, crit
 
 
-def _run_rsss(graphed, iters=6):
+def _run_rsss(graphed, iters=6, kw_region=False):
     import fcd_gan_pytorch_amd as p
     netG, netS, netD, crit = _setup(p)
     netS.train(); netD.train(); netG.eval()
@@ -43,7 +43,11 @@ def _run_rsss(graphed, iters=6):
             for o in (oS, oD):
                 o.param_groups[0]['lr'] = 2e-5
         x, y, region = (t.to(DEV) for t in seeded_tiles(500 + it, N, C, H, H))      # fresh tiles every iteration
-        r = gs(netS, netD, netG, crit, oS, oD, x, y, region) if graphed else fn(netS, netD, netG, crit, oS, oD, x, y, region)
+        if kw_region:       # a tensor passed BY KEYWORD is an input like any other (it used to be captured by address)
+            r = gs(netS, netD, netG, crit, oS, oD, x, y, region=region) if graphed else fn(netS, netD, netG, crit, oS, oD, x, y, region=region)
+            del region          # the caller drops it: a replay must not read the first call's tensor
+        else:
+            r = gs(netS, netD, netG, crit, oS, oD, x, y, region) if graphed else fn(netS, netD, netG, crit, oS, oD, x, y, region)
         losses.append([float(r[k]) for k in ('d_loss', 's_loss', 'g_loss', 'perception_loss', 'ssim_loss')])
     torch.cuda.synchronize()
     out = dict(pS=oS.flat_p.cpu().numpy(), pD=oD.flat_p.cpu().numpy(), sqS=oS.square_avg.cpu().numpy(), losses=np.array(losses),
@@ -68,6 +72,44 @@ def test_graphed_rsss_step_equals_eager_steps():
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)
     for k in a['bn']:
         np.testing.assert_array_equal(a['bn'][k], b['bn'][k], err_msg=k)
+
+
+def test_graphed_step_refreshes_tensor_keyword_arguments():
+    a, b = _run_rsss(False, iters=5, kw_region=True), _run_rsss(True, iters=5, kw_region=True)
+    assert b['replays'] == 3 and b['eager'] == 2
+    np.testing.assert_array_equal(a['losses'], b['losses'])
+    for k in ('pS', 'pD'):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+
+
+def test_graphed_step_refuses_two_steps_of_one_optimizer():
+    """One set of device-side optimizer scalars per replay: a step function that steps the same optimizer twice is run launch by
+    launch, with the same results as without the wrapper."""
+    import fcd_gan_pytorch_amd as p
+
+    def run(graphed):
+        netG, _, _, _ = _setup(p)
+        netG.train()
+        opt = p.optim.Adam(netG.parameters(), lr=1e-4, betas=(0.9, 0.99))
+
+        def fn(net, o, x, y):
+            for _ in range(2):
+                o.zero_grad()
+                loss = ((net(x) - y) ** 2).mean()
+                loss.backward()
+                o.step()
+            return dict(loss=loss)
+        gs = p.graph.GraphedStep(fn, nets=(netG,), optimizers=(opt,), warmup=1) if graphed else None
+        for it in range(3):
+            x, y, _ = (t.to(DEV) for t in seeded_tiles(900 + it, N, C, 64, 64))
+            r = gs(netG, opt, x, y) if graphed else fn(netG, opt, x, y)
+        torch.cuda.synchronize()
+        return opt.flat_p.cpu().numpy(), float(r['loss']), opt.steps, gs
+    pa, la, sa, _ = run(False)
+    pb, lb, sb, gs = run(True)
+    assert gs.refused_multistep and gs.replays == 0 and not gs.enabled
+    assert sa == sb == 6 and la == lb
+    np.testing.assert_array_equal(pa, pb)
 
 
 def _run_usss_adam(graphed, iters=5):

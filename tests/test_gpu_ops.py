@@ -990,3 +990,57 @@ def test_masked_stack(case):
     assert_close(t1.grad, (g[:N].double() * (1 - cm.double())), tol=1e-6, what='dsrc only')
     with pytest.raises(ValueError):
         ops.masked_stack([ts[0].cuda(), ts[0].cuda()[:, :1]], cm.cuda())
+
+
+def _misaligned(t):
+    """The same values as a CONTIGUOUS view whose storage starts 4 bytes past a 16-B boundary."""
+    buf = torch.empty(t.numel() + 1, dtype=t.dtype, device=t.device)
+    v = buf[1:].view(t.shape)
+    v.copy_(t)
+    assert v.is_contiguous() and v.data_ptr() % 16 == 4
+    return v
+
+
+def test_vector_paths_fall_back_on_misaligned_views():
+    """the float4 paths of masked_stack / pair_gap_diff / BatchNorm were chosen from HW % 4 == 0 alone; a contiguous
+    view with a storage offset is not 16-B aligned.  Same results from aligned tensors and from views one float off."""
+    ops = _ops()
+    N, C, H, W = 2, 8, 16, 16
+    x = rnd(N, C, H, W, seed=1).cuda()
+    y = rnd(N, C, H, W, seed=2).cuda()
+    cm = torch.sigmoid(rnd(N, 1, H, W, seed=3)).cuda()
+    g = rnd(2 * N, C, H, W, seed=4).cuda()
+
+    def stack(xx, yy, mm, gg):
+        xx, yy, mm = xx.detach().requires_grad_(True), yy.detach().requires_grad_(True), mm.detach().requires_grad_(True)
+        z = ops.masked_stack([xx, yy], mm)
+        z.backward(gg)
+        return z.detach(), xx.grad, yy.grad, mm.grad
+    for u, v in zip(stack(x, y, cm, g), stack(_misaligned(x), _misaligned(y), _misaligned(cm), _misaligned(g))):
+        assert torch.equal(u, v)
+
+    f = rnd(4 * N, C, H, W, seed=5).cuda()
+    gd = rnd(2 * N, C, 1, 1, seed=6).cuda()
+
+    def gap(ff):
+        ff = ff.detach().requires_grad_(True)
+        d = ops.pair_gap_diff(ff, 2)
+        d.backward(gd)
+        return d.detach(), ff.grad
+    for u, v in zip(gap(f), gap(_misaligned(f))):
+        assert torch.equal(u, v)
+
+    bn = torch.nn.BatchNorm2d(C).cuda().train()
+
+    def bnrun(xx, gg):
+        bn.running_mean.zero_(); bn.running_var.fill_(1.0)
+        xx = xx.detach().requires_grad_(True)
+        z = ops.bn_act(xx, bn, ops.ACT_RELU)
+        z.backward(gg)
+        return z.detach(), xx.grad, bn.weight.grad.clone(), bn.running_var.clone()
+    ga = g[:N].contiguous()
+    a = bnrun(x, ga)
+    bn.weight.grad = None; bn.bias.grad = None
+    b = bnrun(_misaligned(x), _misaligned(ga))
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)

@@ -38,30 +38,35 @@ for pat in ('calib_copy_b128', 'calib_copy_b32', 'calib_read_b128', 'calib_copy_
 F_B128, F_B32, F_DMA = cal['calib_copy_b128']['fetch_factor'], cal['calib_copy_b32']['fetch_factor'], cal['calib_copy_lds_dma']['fetch_factor']
 W_B128, W_B32 = cal['calib_copy_b128']['write_factor'], cal['calib_copy_b32']['write_factor']
 
-FAM = {
-    # family: (kernel-name substring(s), fetch factor, write factor, what the streams are)
-    'wino_gemm': (['wino_gemm_kernel'], F_DMA, W_B32, 'both operands by global_load_lds 16 B/lane; C tile by dword stores (128 B per 32 lanes)'),
-    'wino_gemm_split': (['wino_gemm_split'], F_DMA, W_B128, 'bf16 planes of U and fp32 V by global_load_lds 16 B/lane; C tile by dword stores'),
-    'wino_input_transform': (['wino_input_kernel', 'wino_input_roll_kernel', 'wino_wg_input_kernel', 'wino_wg_dy_kernel'], F_B128, W_B32, 'float4 row reads; V rows as 128 B dword-store segments'),
-    'wino_output_transform': (['wino_output_kernel', 'wino_output_blk_kernel'], F_B32, W_B128, 'coalesced dword reads of M; float4 row stores'),
-    'conv_wino2': (['conv_wino2_kernel'], F_B32, W_B32, 'fused F(2x2) kernel: dword patch loads (8 x 32 pixel blocks + halo), filter slabs by LDS-DMA (L2-resident), '
+from tools.kernel_families import FAMILIES, family_of      # noqa: E402  (one kernel -> family map for this report and bench.py)
+
+# calibration pattern per family: (fetch factor, write factor, what the streams are)
+PATTERN = {
+    'wino_gemm': (F_DMA, W_B32, 'both operands by global_load_lds 16 B/lane; C tile by dword stores (128 B per 32 lanes)'),
+    'wino_gemm_split': (F_DMA, W_B128, 'bf16 planes of U and fp32 V by global_load_lds 16 B/lane; C tile in 32 x 32 blocks by dwordx4 stores'),
+    'wino_transform': (F_B128, W_B32, 'input side: float4 row reads, V rows as 128-B dword-store segments; output side / fused output -> input '
+                       'kernel: 8- / 16-B reads of M, float4 row stores / V rows'),
+    'conv_wino2': (F_B32, W_B32, 'fused F(2x2) kernel: dword patch loads (8 x 32 pixel blocks + halo), filter slabs by LDS-DMA (L2-resident), '
                    'dword / 8-B output stores'),
-    'conv_wgrad': (['conv_wgrad_kernel', 'conv_wgrad_roll_kernel', 'conv_wgrad_thin_kernel', 'nchw_to_nhwc', 'wgrad_reduce'], F_DMA, W_B32,
-                   'direct weight-gradient kernels incl. their re-layout and split-K reduce passes'),
-    'conv_igemm': (['conv_igemm_kernel', 'conv_igemm_glds_kernel', 'conv3x3_fwd_thin', 'conv3x3_dgrad_thin'], F_B32, W_B32, 'dword patch loads (+ small L2-resident filter slabs by LDS-DMA); dword stores'),
+    'conv_wgrad': (F_DMA, W_B32, 'direct weight-gradient calls: re-layout passes, GEMM kernel (operands by LDS-DMA), split-K reduce / finish kernels'),
+    'conv_igemm': (F_B32, W_B32, 'direct forward / data-gradient calls: dword patch loads (+ small L2-resident filter slabs by LDS-DMA), dword stores'),
 }
+STEPS = int(os.environ.get('PMC_BENCH_STEPS', '3'))      # tools/pmc_hbm.sh: bench.py --steps 2 --warmup 1
 out = {'source': 'tools/pmc_hbm.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over tools/hbm_calib.bin '
                  '(2 GiB known streams) and over `python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof` (3 steps in total)',
        'kernel_source_hash': kernel_source_hash(),
        'counter_unit': 'KiB', 'calibration': cal, 'families': {}}
-for fam, (keys, ff, wf, what) in FAM.items():
-    fsum = sum(v['FETCH_SIZE'] for k, v in bf.items() if any(s in k for s in keys)) * unit
-    wsum = sum(v['WRITE_SIZE'] for k, v in bw.items() if any(s in k for s in keys)) * unit
-    nd = sum(v['dispatches'] for k, v in bf.items() if any(s in k for s in keys))
+out['steps_profiled'] = STEPS
+out['note'] = ('bytes are per STEP (all dispatches of the family\'s kernels / steps profiled); bench.py divides by ITS calls per step, so that '
+               'traffic and algorithmic bytes are both per call (tools/kernel_families.py)')
+for fam, (ff, wf, what) in PATTERN.items():
+    fsum = sum(v['FETCH_SIZE'] for k, v in bf.items() if family_of(k) == fam) * unit
+    wsum = sum(v['WRITE_SIZE'] for k, v in bw.items() if family_of(k) == fam) * unit
+    nd = sum(v['dispatches'] for k, v in bf.items() if family_of(k) == fam)
     if not nd:
         continue
-    out['families'][fam] = {'dispatches': nd, 'streams': what, 'raw_fetch_bytes_per_launch': fsum / nd, 'raw_write_bytes_per_launch': wsum / nd,
+    out['families'][fam] = {'kernels': sorted(k for k in bf if family_of(k) == fam), 'dispatches_per_step': nd / float(STEPS), 'streams': what,
                             'fetch_factor': ff, 'write_factor': wf,
-                            'hbm_bytes_per_launch': (fsum * (ff or 1.0) + wsum * (wf or 1.0)) / nd,
-                            'hbm_fetch_bytes_per_launch': fsum * (ff or 1.0) / nd, 'hbm_write_bytes_per_launch': wsum * (wf or 1.0) / nd}
+                            'hbm_bytes_per_step': (fsum * (ff or 1.0) + wsum * (wf or 1.0)) / STEPS,
+                            'hbm_fetch_bytes_per_step': fsum * (ff or 1.0) / STEPS, 'hbm_write_bytes_per_step': wsum * (wf or 1.0) / STEPS}
 print(json.dumps(out, indent=1))
