@@ -9,7 +9,7 @@ divides by ITS number of calls per step -- like for like (tests/test_kernel_fami
 
 # family -> (kernel-name substrings, bench.py profile scopes whose launches are the family's calls [added], [subtracted])
 FAMILIES = {
-    'wino_gemm_split': (['wino_gemm_split_kernel', 'wino_gemm_split256_kernel', 'wino_gemm_split_res_kernel', 'wino_gemm_split_pp_kernel'],
+    'wino_gemm_split': (['wino_gemm_split_kernel', 'wino_gemm_split256_kernel', 'wino_gemm_split_res_kernel'],
                         ['wino_gemm_bf16x6'], []),
     'wino_gemm': (['wino_gemm_kernel'], ['wino_gemm'], []),
     'conv_wino2': (['conv_wino2_kernel'], ['conv_wino2_fwd', 'conv_wino2_dgrad'], []),
