@@ -120,6 +120,42 @@ struct WinoGemmArgs {
   unsigned long long* tbuf;   // YG_TIME builds: [workgroup][wave][8] cycle sums
 };
 
+// Workgroup -> (tile v, transform-position group by, reduction split bz) of the split GEMM kernels (WinoGemmArgs.xcd_remap):
+//   0  the launch geometry as it is;
+//   1  many tiles per position group: each XCD (own L2; workgroups go to the 8 XCDs round-robin in launch order) walks a CONTIGUOUS
+//      range of the tiles of a group, so the workgroups resident on it share their operand panels' neighbours;
+//   2  [r5] few tiles per group (the Segmentor's deep layers: 8 tiles, filters of 450 MB; every split-K weight-gradient GEMM: 1 - 8 tiles):
+//      ALL tiles of a group go to ONE XCD -- groups are dealt to the XCDs eight at a time, the tiles of a group sit 8 apart in launch
+//      order -- so that the operand panels the tiles share (A: one per row tile, read by every column tile and vice versa) come
+//      from HBM once per group instead of once per tile: with 4 x 2 tiles that is 0.6 instead of 1.5 GB for the 2048 -> 1024 layer.
+__device__ __forceinline__ void wino_gemm_block(int mode, unsigned& v, unsigned& by, unsigned& bz) {
+  const unsigned gx = gridDim.x, gy = gridDim.y;
+  if (mode == 2) {
+    const unsigned L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned P = gy * gridDim.z, P8 = P & ~7u;
+    unsigned p, t;
+    if (L < P8 * gx) {
+      const unsigned r = L >> 3;
+      t = r % gx;
+      p = (r / gx) * 8 + (L & 7u);
+    } else {                      // the last P % 8 groups: plain order
+      const unsigned Lt = L - P8 * gx, rem = P - P8;
+      p = P8 + Lt % rem;
+      t = Lt / rem;
+    }
+    v = t; by = p % gy; bz = p / gy;
+    return;
+  }
+  by = blockIdx.y; bz = blockIdx.z;
+  const unsigned b = blockIdx.x;
+  if (mode == 1) {
+    const unsigned q8 = gx >> 3, r8 = gx & 7u, xcd = b & 7u;
+    v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
+  } else {
+    v = b;
+  }
+}
+
 struct WinoOutArgs {
   const float* Mb;      // [xi][K][T]
   const float* bias;

@@ -661,22 +661,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void wino_gem
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int wm = wave / WN, wn = wave % WN;
-  unsigned v;
-  {
-    const unsigned total = gridDim.x, b = blockIdx.x;
-    if (a.xcd_remap) {
-      const unsigned q8 = total >> 3, r8 = total & 7u, xcd = b & 7u;
-      v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
-    } else {
-      v = b;
-    }
-  }
+  unsigned v, by_, bz_;
+  wino_gemm_block(a.xcd_remap, v, by_, bz_);
   const int mt = (int)(v % (unsigned)a.m_tiles), nt = (int)(v / (unsigned)a.m_tiles);
   const int m0 = mt * BM, n0 = nt * BN;
   const int q_all = a.Kc / KC;
-  const int q_beg = (int)blockIdx.z * a.stages_per_split;      // split of the reduction (weight gradient)
+  const int q_beg = (int)bz_ * a.stages_per_split;      // split of the reduction (weight gradient)
   const int Q = min(a.stages_per_split, q_all - q_beg);
-  const int b_first = (int)blockIdx.y * a.xb;
+  const int b_first = (int)by_ * a.xb;
   const int nb = min(a.xb, a.batches - b_first);
   const unsigned short* Ab = a.As + (size_t)b_first * a.a_batch + (size_t)q_beg * KC + (size_t)m0 * a.a_ld;
   const float* Bb = BT ? a.B + (size_t)b_first * a.b_batch
@@ -834,7 +826,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void wino_gem
     }
     int ldc = a.N;
     asm volatile("" : "+s"(ldc));
-    float* Cb = a.C + ((size_t)blockIdx.z * a.batches + (b_first + cb)) * a.M * ldc;
+    float* Cb = a.C + ((size_t)bz_ * a.batches + (b_first + cb)) * a.M * ldc;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1034,20 +1026,12 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split256_kernel(WinoGemmArgs
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int wm = wave >> 2, wn = wave & 3;
-  unsigned v;
-  {
-    const unsigned total = gridDim.x, b = blockIdx.x;
-    if (a.xcd_remap) {
-      const unsigned q8 = total >> 3, r8 = total & 7u, xcd = b & 7u;
-      v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
-    } else {
-      v = b;
-    }
-  }
+  unsigned v, by_, bz_;
+  wino_gemm_block(a.xcd_remap, v, by_, bz_);
   const int mt = (int)(v % (unsigned)a.m_tiles), nt = (int)(v / (unsigned)a.m_tiles);
   const int m0 = mt * BM, n0 = nt * BN;
   const int Q = a.Kc / KC;
-  const int b_first = (int)blockIdx.y * a.xb;
+  const int b_first = (int)by_ * a.xb;
   const int nb = min(a.xb, a.batches - b_first);
   const unsigned short* Ab = a.As + (size_t)b_first * a.a_batch + (size_t)m0 * a.a_ld;
   const float* Bb = a.B + (size_t)b_first * a.b_batch + (size_t)n0 * a.b_ld;
@@ -1283,6 +1267,15 @@ extern "C" int fcd_conv_wino_split_set(int on) {
   return old;
 }
 
+static int wino_xcd();
+// few tiles per transform position: all tiles of a position group on one XCD (wino_gemm_block mode 2; FCD_WINO_XCD2=0: off)
+static int wino_xcd_mode(int tiles, int groups) {
+  static int max_tiles = -1;      // FCD_WINO_XCD2=<n>: largest tile count per group that takes mode 2 (0: never)
+  if (max_tiles < 0) { const char* e = getenv("FCD_WINO_XCD2"); max_tiles = e ? atoi(e) : 128; }
+  if (!wino_xcd()) return 0;
+  return (tiles <= max_tiles && groups >= 8) ? 2 : 1;
+}
+
 static void wino_gemm_launch(WinoGemmArgs ga, int batches, int splits, hipStream_t st) {
   int cfg = wino_gemm_cfg();
   if (ga.As && ga.M > 64 && wino_split()) {
@@ -1290,6 +1283,7 @@ static void wino_gemm_launch(WinoGemmArgs ga, int batches, int splits, hipStream
     if (splits > 1 || ga.bt) {          // weight gradient: split reduction, one transform position per workgroup
       ga.m_tiles = cdiv(ga.M, 128); ga.n_tiles = cdiv(ga.N, 128);
       ga.xb = 1;
+      ga.xcd_remap = wino_xcd_mode(ga.m_tiles * ga.n_tiles, batches * splits) == 2 ? 2 : 0;      // (mode 1 was never on for these launches)
       const dim3 grid((unsigned)(ga.m_tiles * ga.n_tiles), (unsigned)batches, (unsigned)splits);
       if (ga.bt) hipLaunchKernelGGL((wino_gemm_split_kernel<2, 2, true>), grid, dim3(256), 0, st, ga);
       else hipLaunchKernelGGL((wino_gemm_split_kernel<2, 2>), grid, dim3(256), 0, st, ga);
@@ -1315,6 +1309,7 @@ static void wino_gemm_launch(WinoGemmArgs ga, int batches, int splits, hipStream
     if (big && ga.M >= 256 && (force || (long long)cdiv(ga.M, 256) * cdiv(ga.N, 256) * batches >= 1024)) {
       ga.m_tiles = cdiv(ga.M, 256); ga.n_tiles = cdiv(ga.N, 256);
       ga.xb = wino_gemm_xb((long long)ga.m_tiles * ga.n_tiles * 2, batches, 1, ga.Kc / 32);
+      ga.xcd_remap = wino_xcd_mode(ga.m_tiles * ga.n_tiles, cdiv(batches, ga.xb));
       const dim3 grid((unsigned)(ga.m_tiles * ga.n_tiles), (unsigned)cdiv(batches, ga.xb));
 #if YG_TIME
       ga.tbuf = g_yg_tbuf;
@@ -1324,6 +1319,7 @@ static void wino_gemm_launch(WinoGemmArgs ga, int batches, int splits, hipStream
     }
     ga.m_tiles = cdiv(ga.M, 128); ga.n_tiles = cdiv(ga.N, 128);
     ga.xb = wino_gemm_xb((long long)ga.m_tiles * ga.n_tiles, batches, 1, ga.Kc / 32);
+    ga.xcd_remap = wino_xcd_mode(ga.m_tiles * ga.n_tiles, cdiv(batches, ga.xb));
     hipLaunchKernelGGL((wino_gemm_split_kernel<2, 2>), dim3((unsigned)(ga.m_tiles * ga.n_tiles), (unsigned)cdiv(batches, ga.xb)),
                        dim3(256), 0, st, ga);
     return;
