@@ -23,9 +23,9 @@
 // VW = channels per thread in the output phase: 4 (one 16-B word of the GEMM's blocks per position; BW + 2 tile columns incl. the
 // halo candidates) or 2 (8-B halves: lanes (tile, pair) still cover 256 contiguous bytes, every thread of the workgroup has an
 // item and holds 72 instead of 144 prefetch registers; bands that span the image only -- no halo column).
-template <int BW, int TRS, int CHB, int MINB, int VW, int NT, int UNR = 1>
+template <int BW, int TRS, int VW, int NT, int MINB>
 __global__ __launch_bounds__(NT, MINB) void wino_oi_kernel(WinoOiArgs a) {
-  constexpr int A = 6;
+  constexpr int A = 6, CHB = 32;           // one 32-channel chunk of V per workgroup: whole 128-B V rows (16-channel workgroups, 64-B rows: 3.7 vs 4.5 TB/s)
   constexpr int RR = 4 * TRS + 5;          // ring rows
   constexpr int CW = 4 * BW + 2;           // ring columns: left halo, band, right halo
   constexpr int PL = (RR * CW) | 1;        // odd channel pitch: the input phase reads with lanes = channels
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(NT, MINB) void wino_oi_kernel(WinoOiArgs a) {
     if (s + 1 < steps) issue(s + 1);
     __syncthreads();
     // input phase: tile rows s TRS - 1 .. s TRS + TRS - 2
-#pragma unroll UNR
+#pragma unroll 1
     for (int it = tid; it < TRS * BW * CHB; it += NT) {
       const int c = it % CHB, tl = it / CHB;
       const int tc = tl % BW, r = s * TRS - 1 + tl / BW;
@@ -175,25 +175,14 @@ int wino_oi_ok(int K, int H, int W) {
 }
 
 void wino_oi_launch(const WinoOiArgs& a, hipStream_t st) {
-  static int vw = -1;
-  if (vw < 0) { const char* e = getenv("FCD_WINO_OI_VW"); vw = (e && atoi(e) == 4) ? 4 : 2; }
+  // measured on MI355X (208 band images; bytes = M read + V written): 16 / 8 / 4 tiles wide, channel pairs per thread, two workgroups per
+  // CU: 4.8 - 5.1 / 5.2 - 5.5 / 5.2 - 5.5 TB/s (quads: 4.5 / 4.9 / 4.2; one workgroup per CU: 4.1 / 4.3 / 3.3); 32 tiles wide as ONE
+  // 8-wave workgroup per CU over the whole row: 4.5 - 4.7 TB/s (two 16-tile bands: 3.6 -- the one halo tile column of a band costs a
+  // whole 128-B line per position and row); unrolling the input phase by two: no change
   const dim3 grid((unsigned)cdiv(a.TW, a.TW >= 16 ? 16 : a.TW), (unsigned)(a.K / 32), (unsigned)a.N);
-  static int unr = -1;
-  if (unr < 0) { const char* e = getenv("FCD_WINO_OI_UNR"); unr = e ? atoi(e) : 1; }
-#define OI_LAUNCH(BW_, TRS_, VW_)                                                                                          \
-  {                                                                                                                        \
-    if (unr == 2 && VW_ == 2) hipLaunchKernelGGL((wino_oi_kernel<BW_, TRS_, 32, 2, 2, 256, 2>), grid, dim3(256), 0, st, a); \
-    else hipLaunchKernelGGL((wino_oi_kernel<BW_, TRS_, 32, 2, VW_, 256>), grid, dim3(256), 0, st, a);                       \
-  }
-  static int wide = -1;
-  if (wide < 0) { const char* e = getenv("FCD_WINO_OI_WIDE"); wide = e ? atoi(e) : 1; }
-  if (a.TW == 32 && wide) {       // the whole 128-pixel row in one 8-wave workgroup per CU (150 KB ring): no band halo, whose one tile column costs a 128-B line per position
-    hipLaunchKernelGGL((wino_oi_kernel<32, 1, 32, 1, 2, 512>), dim3(1, (unsigned)(a.K / 32), (unsigned)a.N), dim3(512), 0, st, a);
-    return;
-  }
-  if (a.TW > 16) OI_LAUNCH(16, 1, 4)             // bands: the neighbouring tile columns are recomputed
-  else if (a.TW == 16) { if (vw == 4) OI_LAUNCH(16, 1, 4) else OI_LAUNCH(16, 1, 2) }
-  else if (a.TW == 8) { if (vw == 4) OI_LAUNCH(8, 2, 4) else OI_LAUNCH(8, 2, 2) }
-  else { if (vw == 4) OI_LAUNCH(4, 4, 4) else OI_LAUNCH(4, 4, 2) }
-#undef OI_LAUNCH
+  if (a.TW == 32) hipLaunchKernelGGL((wino_oi_kernel<32, 1, 2, 512, 1>), dim3(1, (unsigned)(a.K / 32), (unsigned)a.N), dim3(512), 0, st, a);
+  else if (a.TW > 16) hipLaunchKernelGGL((wino_oi_kernel<16, 1, 4, 256, 2>), grid, dim3(256), 0, st, a);      // bands, neighbouring tile columns recomputed
+  else if (a.TW == 16) hipLaunchKernelGGL((wino_oi_kernel<16, 1, 2, 256, 2>), grid, dim3(256), 0, st, a);
+  else if (a.TW == 8) hipLaunchKernelGGL((wino_oi_kernel<8, 2, 2, 256, 2>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((wino_oi_kernel<4, 4, 2, 256, 2>), grid, dim3(256), 0, st, a);
 }

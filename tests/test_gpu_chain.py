@@ -46,9 +46,10 @@ CHAIN_CASES = [
     (2, (128, 256, 256, 256), 32, 32, True),    # conv3 block at 8 tiles wide (two tile rows per step)
     (2, (128, 256, 256, 256), 32, 32, False),
     (3, (256, 512, 512), 16, 16, False),        # conv5 geometry: 4 x 4 tiles, whole image in one step
-    (2, (128, 128, 128), 128, 128, False),      # 32 tiles wide: two bands, neighbouring tile column recomputed
+    (2, (128, 128, 128), 128, 128, False),      # 32 tiles wide: the whole row in one 8-wave workgroup
     (1, (128, 128, 256), 32, 64, True),         # non-square, 16 tiles wide, 8 tile rows
     (2, (256, 256, 128, 128), 16, 32, False),   # TW = 8 with TH = 4; shrinking channels
+    (1, (128, 128, 128), 32, 256, True),        # 64 tiles wide: four 16-tile bands, the neighbouring tile column of a band recomputed
 ]
 
 

@@ -59,7 +59,7 @@ def test_names_as_the_profilers_print_them():
     assert kf.family_of('void conv3x3_dgrad_c1_mfma_kernel<true>(float const*, unsigned char const*)') == 'conv_igemm'
     assert kf.family_of('nchw_to_nhwc_v4_kernel(float const*, float const*, float*, int, int, int, float*)') == 'conv_wgrad'
     assert kf.family_of('wgrad_reduce_wide_kernel(float const*, float*, long long, int, long long, int)') == 'conv_wgrad'
-    assert kf.family_of('void wino_oi_kernel<16, 1, 32, 2, 2, 256, 1>(WinoOiArgs)') == 'wino_transform'
+    assert kf.family_of('void wino_oi_kernel<16, 1, 2, 256, 2>(WinoOiArgs)') == 'wino_transform'
     assert kf.family_of('wino_output_blk_kernel(WinoOutArgs)') == 'wino_transform'
     assert kf.family_of('bn_act_apply_kernel(float const*, float*)') is None
     # the aggregation key of tools/pmc_hbm.sh: namespace stripped, cut at the first '('
