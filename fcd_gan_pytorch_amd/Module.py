@@ -191,8 +191,9 @@ class Segmentor(nn.Module):
 
     def forward(self, x1, x2):
         n = x1.shape[0]
-        f = self.inc(torch.cat([x1, x2], dim=0), groups=2)      # both temporal branches in one batch
-        return self._after_inc(f, n)
+        with ops.batched_bn_counters():                              # the 18 num_batches_tracked increments as one launch
+            f = self.inc(torch.cat([x1, x2], dim=0), groups=2)      # both temporal branches in one batch
+            return self._after_inc(f, n)
 
     @torch.no_grad()
     def forward_raw(self, x1_raw, x2_raw, valid, stats):
@@ -332,12 +333,13 @@ class Generator(nn.Module):
     def forward(self, x):
         if not self.training and not torch.is_grad_enabled():
             return self._infer(x)
-        b1 = ops.bn_act(_conv(self.block1[0], x), None, ops.ACT_PRELU, slope=self.block1[1].weight)
-        h = b1
-        for blk in (self.block2, self.block3, self.block4, self.block5, self.block6):
-            h = blk(h)
-        h = ops.bn_act(_conv(self.block7[0], h), self.block7[1], ops.ACT_NONE)
-        return _conv(self.block8, b1 + h)
+        with ops.batched_bn_counters():
+            b1 = ops.bn_act(_conv(self.block1[0], x), None, ops.ACT_PRELU, slope=self.block1[1].weight)
+            h = b1
+            for blk in (self.block2, self.block3, self.block4, self.block5, self.block6):
+                h = blk(h)
+            h = ops.bn_act(_conv(self.block7[0], h), self.block7[1], ops.ACT_NONE)
+            return _conv(self.block8, b1 + h)
 
 
 class Discriminator_SRGAN_simple(nn.Module):
@@ -393,7 +395,8 @@ class Discriminator_SRGAN_simple(nn.Module):
         return [self.classify(f[(2 * i) * n:(2 * i + 1) * n] - f[(2 * i + 1) * n:(2 * i + 2) * n]) for i in range(npairs)]
 
     def forward(self, x, y):
-        return self._classify_pairs(self.features(torch.cat([x, y], dim=0), groups=2), 1)[0]
+        with ops.batched_bn_counters():
+            return self._classify_pairs(self.features(torch.cat([x, y], dim=0), groups=2), 1)[0]
 
     def forward_pairs(self, pairs):
         """Evaluate several (x, y) pairs in one batched pass; equivalent to calling
@@ -405,4 +408,5 @@ class Discriminator_SRGAN_simple(nn.Module):
         ``ops.masked_stack`` writes): a list of ``npairs`` outputs."""
         if z.shape[0] % (2 * npairs):
             raise ValueError('forward_stacked: %d samples are not %d (x, y) pairs' % (z.shape[0], npairs))
-        return self._classify_pairs(self.features(z, groups=2 * npairs), npairs)
+        with ops.batched_bn_counters():
+            return self._classify_pairs(self.features(z, groups=2 * npairs), npairs)

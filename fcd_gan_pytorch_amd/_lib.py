@@ -98,6 +98,8 @@ _SIGS = {
     'fcd_conv2d_bwd_weight_bias_v': (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, c_size_t, P]),
     'fcd_conv_wino_filter_elems': (c_int64, [c_int, c_int, c_int, c_int]),
     'fcd_conv_wino_pack': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    'fcd_conv_wino_pack_blocks': (c_int, [c_int, c_int, c_int]),
+    'fcd_conv_wino_pack_multi': (c_int, [P, c_int, c_int, c_double, P]),
     'fcd_conv2d_fwd_wino': (c_int, [POINTER(ConvDesc), P, P, P, P, c_int, P, P, P, c_size_t, P]),
     'fcd_conv2d_bwd_data_wino': (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, c_size_t, P]),
     'fcd_conv_s2_dgrad_plan': (c_int, [POINTER(ConvDesc)]),

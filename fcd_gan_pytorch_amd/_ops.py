@@ -218,6 +218,53 @@ def invalidate_packs(params):
         p.__dict__.pop('_fcd_pack', None)
 
 
+_PACK_TABLES = {}
+
+
+def refresh_packs(params):
+    """After an update of ``params`` (versions already bumped): every F(4x4) filter pack they held is re-packed IN PLACE by ONE launch
+    (``fcd_conv_wino_pack_multi``: the Segmentor's 18 wide layers x {forward, data gradient} were 36 launches per step), every other
+    pack is dropped as :func:`invalidate_packs` does.  With a second stream in play (``MULTI_STREAM``) nothing is re-used in place."""
+    if MULTI_STREAM or os.environ.get('FCD_PACK_MULTI') == '0':
+        return invalidate_packs(params)
+    split_now = lib.fcd_conv_wino_split_set(-1) != 0
+    items = []
+    for p in params:
+        cache = p.__dict__.get('_fcd_pack')
+        if not cache:
+            continue
+        keep = {}
+        if p.is_cuda and p.dim() == 4 and p.is_contiguous():
+            for key, (ver, buf) in cache.items():
+                if isinstance(key, tuple) and key[0] == 'wino' and key[2] == 4 and key[3] == split_now and buf.device == p.device:
+                    items.append((p, key[1], buf))
+                    keep[key] = (p._version, buf)
+        if keep:
+            p.__dict__['_fcd_pack'] = keep
+        else:
+            p.__dict__.pop('_fcd_pack', None)
+    if not items:
+        return
+    sig = tuple((p.data_ptr(), mode, buf.data_ptr()) for p, mode, buf in items) + (split_now,)
+    hit = _PACK_TABLES.get(sig)
+    if hit is None:
+        rows, first, elems = [], 0, 0.0
+        for p, mode, buf in items:
+            K, C = p.shape[:2]
+            nb = lib.fcd_conv_wino_pack_blocks(K, C, mode)
+            r = K if mode == 0 else C
+            kc = ((C if mode == 0 else K) + 31) // 32 * 32
+            rows.append([p.data_ptr(), buf.data_ptr(), K, C, mode, first, nb, 1 if (split_now and r > 64) else 0])
+            first += nb
+            elems += float(r) * kc
+        if len(_PACK_TABLES) > 16:
+            _PACK_TABLES.clear()
+        hit = _PACK_TABLES[sig] = (torch.tensor(rows, dtype=torch.int64).to(items[0][0].device), len(rows), first, elems)
+    table, n, total, elems = hit
+    # (the parameters are contiguous slices of their optimizer's flat buffer: w is read where it lives)
+    check(lib.fcd_conv_wino_pack_multi(_p(table), n, total, elems, _stream()), 'fcd_conv_wino_pack_multi')
+
+
 def _channel_sum(t, mask, N, C, HW):
     out = torch.empty(C, dtype=torch.float32, device=t.device)
     ws = _ws(lib.fcd_channel_sum_ws_bytes(C), t.device)
@@ -726,6 +773,46 @@ class _BnAct(torch.autograd.Function):
         return dx, dgamma, dbeta, dslope, None, None, None, None, None, None, None, None
 
 
+_COUNTERS = None
+
+
+class batched_bn_counters:
+    """``num_batches_tracked += 1`` of every BatchNorm a net runs in train mode is an 8-byte ATen launch of its own (24 per Demo_RSSS
+    step); inside this context the increments are collected and applied as ONE ``torch._foreach_add_`` when the outermost context
+    exits -- the nets' ``forward`` wrap themselves in it.  The buffers hold the same values as before once ``forward`` returns."""
+
+    def __enter__(self):
+        global _COUNTERS
+        self.outer = _COUNTERS is not None
+        if not self.outer:
+            _COUNTERS = []
+        return self
+
+    def __exit__(self, *exc):
+        global _COUNTERS
+        if self.outer:
+            return False
+        todo, _COUNTERS = _COUNTERS, None
+        by_step = {}
+        for t, g in todo:
+            by_step.setdefault(int(g), []).append(t)
+        for g, ts in by_step.items():
+            uniq, seen = [], {}
+            for t in ts:                     # the same counter may be hit twice in one forward (shared modules): add it up
+                k = id(t)
+                if k in seen:
+                    seen[k][1] += g
+                else:
+                    seen[k] = [t, g]
+            same = [v[0] for v in seen.values() if v[1] == g]
+            if same:
+                torch._foreach_add_(same, g)
+            for t, tot in seen.values():
+                if tot != g:
+                    t += tot
+        return False
+
+
 def bn_act(x, bn=None, act=ACT_NONE, slope=None, slope_imm=0.0, groups=1):
     """y = act(BatchNorm(x)).  ``bn``: an nn.BatchNorm2d-like holder (weight, bias,
     running_mean, running_var, momentum, eps, training, num_batches_tracked) or
@@ -734,7 +821,10 @@ def bn_act(x, bn=None, act=ACT_NONE, slope=None, slope_imm=0.0, groups=1):
         return _BnAct.apply(x, None, None, slope, None, None, False, 0.0, 0.0, groups, act, slope_imm)
     training = bn.training or bn.running_mean is None
     if training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked += groups
+        if _COUNTERS is not None:
+            _COUNTERS.append((bn.num_batches_tracked, groups))      # one multi-tensor add at the end of the net's forward
+        else:
+            bn.num_batches_tracked += groups
     return _BnAct.apply(x, bn.weight, bn.bias, slope, bn.running_mean, bn.running_var, training,
                         bn.momentum if bn.momentum is not None else 0.1, bn.eps, groups, act, slope_imm)
 

@@ -36,15 +36,14 @@ __device__ __forceinline__ unsigned short bf16_rn_bits(float x) {
 }
 
 template <int MM>
-__global__ void wino_filter_kernel(const float* __restrict__ w, float* __restrict__ U, int K, int C, int rows, int Kc,
-                                   int mode, unsigned short* __restrict__ planes) {
+__device__ __forceinline__ void wino_filter_items(const float* __restrict__ w, float* __restrict__ U, int K, int C, int rows, int Kc,
+                                                  int mode, unsigned short* __restrict__ planes, long long i0, long long istep) {
   // one thread = TWO adjacent reduction channels (Kc is a multiple of 32): the bf16 planes are written as 4-byte pairs
   // and the fp32 U as float2 -- the pack is store-bound (40 B written per filter tap read), 2-byte stores halve its rate
   constexpr int A = WinoMat<MM>::A;
   const long long total = (long long)rows * Kc;
   const long long pairs = total >> 1;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < pairs;
-       i += (long long)gridDim.x * blockDim.x) {
+  for (long long i = i0; i < pairs; i += istep) {
     const int kc0 = (int)((2 * i) % Kc), row = (int)((2 * i) / Kc);
     float g[2][3][3];
 #pragma unroll
@@ -98,6 +97,31 @@ __global__ void wino_filter_kernel(const float* __restrict__ w, float* __restric
         }
       }
   }
+}
+
+template <int MM>
+__global__ void wino_filter_kernel(const float* __restrict__ w, float* __restrict__ U, int K, int C, int rows, int Kc,
+                                   int mode, unsigned short* __restrict__ planes) {
+  wino_filter_items<MM>(w, U, K, C, rows, Kc, mode, planes, (long long)blockIdx.x * blockDim.x + threadIdx.x,
+                        (long long)gridDim.x * blockDim.x);
+}
+
+// [r5] Every F(4x4) filter pack of a net in ONE launch (fcd_conv_wino_pack_multi): after an optimizer step the Segmentor's 18 wide
+// layers need their forward AND data-gradient packs again -- 36 launches of 8 - 170 us, most of them too small to fill the chip.
+// items (device memory, 8 x int64 each): {w, U, K, C, mode, first block, blocks, split}.
+__global__ void wino_filter_multi_kernel(const long long* __restrict__ items, int n) {
+  int e = 0;
+  while (e + 1 < n && (long long)blockIdx.x >= items[(e + 1) * 8 + 5]) ++e;
+  const long long* it = items + e * 8;
+  const float* w = (const float*)it[0];
+  float* U = (float*)it[1];
+  const int K = (int)it[2], C = (int)it[3], mode = (int)it[4];
+  const long long first = it[5], blocks = it[6];
+  const int rows = mode == 0 ? K : C, Kc = ((mode == 0 ? C : K) + 31) / 32 * 32;
+  unsigned short* planes = (unsigned short*)(U + 36LL * rows * Kc);
+  const bool split = it[7] != 0;
+  wino_filter_items<4>(w, split ? nullptr : U, K, C, rows, Kc, mode, split ? planes : nullptr,
+                       ((long long)blockIdx.x - first) * blockDim.x + threadIdx.x, blocks * blockDim.x);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -316,7 +340,7 @@ __global__ __launch_bounds__(256) void wino_input_roll_kernel(WinoInArgs a, int 
           if (wq + 1 < a.Wp) {
             const f32x2 g2 = *(const f32x2*)(a.x + off);
             v[0] = g2[0]; v[1] = g2[1];
-            cc = (unsigned)a.code[off] | ((unsigned)a.code[off + 1] << 8);
+            cc = *(const unsigned short*)(a.code + off);      // both codes in one load (off is even: wq is, and the rolling kernel takes even Wp only)
           } else {
             v[0] = a.x[off];
             cc = (unsigned)a.code[off];
@@ -1630,6 +1654,21 @@ extern "C" int fcd_conv_wino_pack(const float* w, float* U, int K, int C, int mo
   else
     hipLaunchKernelGGL(wino_filter_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, Uw, K, C, rows, Kc, mode, planes);
   FCD_LAUNCH_CHECK("wino_pack");
+  return FCD_OK;
+}
+
+// items_dev: n x 8 int64 in device memory {w, U, K, C, mode, first block, blocks, split}, blocks = min(cdiv(rows * Kc / 2, 256), 4096)
+// per item, first block = running sum; total_blocks = their sum.  The packs are what fcd_conv_wino_pack(w, U, K, C, mode, 4) writes
+// (split != 0: the three bf16 planes, else the fp32 U) -- bit-identical, one launch.  fcd_conv_wino_pack_blocks gives `blocks`.
+extern "C" int fcd_conv_wino_pack_blocks(int K, int C, int mode) {
+  const int rows = mode == 0 ? K : C, Kc = round_up(mode == 0 ? C : K, 32);
+  return (int)std::min<long long>(cdiv64((long long)rows * Kc / 2, 256), 4096);
+}
+extern "C" int fcd_conv_wino_pack_multi(const long long* items_dev, int n, int total_blocks, double total_elems, void* stream) {
+  FCD_CHECK_ARG(items_dev && n > 0 && total_blocks > 0, "fcd_conv_wino_pack_multi: bad arguments");
+  FcdProfScope prof(FCD_K_PACK, (hipStream_t)stream, 0.0, 4.0 * total_elems * (9 + 1.5 * 36));
+  hipLaunchKernelGGL(wino_filter_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, items_dev, n);
+  FCD_LAUNCH_CHECK("wino_pack_multi");
   return FCD_OK;
 }
 

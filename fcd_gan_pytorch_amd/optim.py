@@ -235,7 +235,7 @@ class _FlatOptimizer:
         # saved the old weights now raises, as it would after torch.optim's in-place update) and drop the
         # packed / transformed filter copies
         torch._C._increment_version(self.params)
-        ops.invalidate_packs(self.params)
+        ops.refresh_packs(self.params)          # F(4x4) packs re-packed in place by one launch, the others dropped
 
     @property
     def lr(self):

@@ -115,6 +115,14 @@ int fcd_conv_wino_split_set(int on);
 size_t fcd_conv_wino_ws_bytes(const fcd_conv_desc* d, int mode);
 int64_t fcd_conv_wino_filter_elems(int K, int C, int mode, int m);
 int fcd_conv_wino_pack(const float* w, float* U, int K, int C, int mode, int m, void* stream);
+/* (round 5) every F(4x4) pack of a net in ONE launch, e.g. right after an optimizer step (the Segmentor: 18 layers x {forward, data
+ * gradient} = 36 launches otherwise).  items_dev: n x 8 int64 in DEVICE memory {w, U, K, C, mode, first block, blocks, split}: w / U as
+ * fcd_conv_wino_pack takes them (U: fcd_conv_wino_filter_elems(K, C, mode, 4) floats), blocks = fcd_conv_wino_pack_blocks(K, C, mode),
+ * first block = sum of the previous items' blocks, split = fcd_conv_wino_split_set(-1) != 0 && rows > 64 (the pack then holds the
+ * three bf16 planes, else the fp32 U); total_blocks = sum of blocks; total_elems = sum of rows x Kc (profiling only).  Bit-identical to
+ * the single calls. */
+int fcd_conv_wino_pack_blocks(int K, int C, int mode);
+int fcd_conv_wino_pack_multi(const long long* items_dev, int n, int total_blocks, double total_elems, void* stream);
 /* y = [relu](conv + bias); with pool_y != NULL instead pool_y / code = maxpool2(relu(conv + bias)) */
 int fcd_conv2d_fwd_wino(const fcd_conv_desc* d, const float* x, const float* U, const float* bias, float* y,
                         int fuse_relu, float* pool_y, unsigned char* code, void* ws, size_t ws_bytes,

@@ -1044,3 +1044,51 @@ def test_vector_paths_fall_back_on_misaligned_views():
     b = bnrun(_misaligned(x), _misaligned(ga))
     for u, v in zip(a, b):
         assert torch.equal(u, v)
+
+
+def test_wino_packs_refreshed_in_one_launch_are_bit_identical():
+    """ops.refresh_packs: after an optimizer step every F(4x4) filter pack of the stepped parameters is re-packed in place by ONE
+    launch (fcd_conv_wino_pack_multi) -- same bytes as the per-layer fcd_conv_wino_pack calls, cache current, other packs dropped."""
+    import fcd_gan_pytorch_amd as p
+    ops = _ops()
+    convs = [torch.nn.Conv2d(128, 256, 3, padding=1), torch.nn.Conv2d(256, 128, 3, padding=1), torch.nn.Conv2d(64, 64, 3, padding=1),
+             torch.nn.Conv2d(128, 128, 3, padding=1)]
+    net = torch.nn.Sequential(*convs).cuda()
+    opt = p.optim.RMSprop(net.parameters(), lr=1e-3)
+    x = rnd(2, 128, 32, 32, seed=1).cuda()
+
+    def packs():
+        out = {}
+        for i, c in enumerate(convs):
+            for key, (ver, buf) in c.weight.__dict__.get('_fcd_pack', {}).items():
+                out[(i, key)] = (ver, buf.data_ptr(), buf.clone())
+        return out
+
+    def fwd_bwd():
+        h = ops.conv2d(x, convs[0].weight, convs[0].bias, 1, 1, relu=False)
+        h = ops.conv2d(h, convs[1].weight, convs[1].bias, 1, 1, relu=False)
+        g = ops.conv2d(h[:, :64].contiguous(), convs[2].weight, convs[2].bias, 1, 1)      # 64 rows: fused F(2x2), its own pack kind
+        h = ops.conv2d(h, convs[3].weight, convs[3].bias, 1, 1)
+        (h.square().mean() + g.square().mean()).backward()
+    opt.zero_grad(); fwd_bwd()
+    before = packs()
+    wino_keys = [k for k in before if isinstance(k[1], tuple) and k[1][0] == 'wino']
+    assert len(wino_keys) >= 5                     # forward + data-gradient packs of the wide layers (layer 0 needs no data gradient)
+    opt.step()                                      # -> refresh_packs
+    after = packs()
+    assert set(after) == set(wino_keys), 'only the F(4x4) packs are kept'
+    for k in wino_keys:
+        assert after[k][1] == before[k][1], 're-packed in place'
+        assert after[k][0] == convs[k[0]].weight._version
+        assert not torch.equal(after[k][2], before[k][2]), 'the update changed the filters'
+        K, C = convs[k[0]].weight.shape[:2]
+        ref = torch.empty_like(after[k][2])
+        ops.check(ops.lib.fcd_conv_wino_pack(ops._p(convs[k[0]].weight.detach().contiguous()), ops._p(ref), K, C, k[1][1], 4, ops._stream()))
+        n_planes_from = 36 * (K if k[1][1] == 0 else C) * (((C if k[1][1] == 0 else K) + 31) // 32 * 32)
+        # the single call writes the same region (the bf16 planes behind the fp32 area for these > 64-row layers)
+        assert torch.equal(after[k][2][n_planes_from:], ref[n_planes_from:])
+    # and the next step runs on the refreshed packs without packing anything again
+    opt.zero_grad(); fwd_bwd()
+    again = packs()
+    for k in wino_keys:
+        assert again[k][1] == before[k][1] and torch.equal(again[k][2], after[k][2])
