@@ -2454,7 +2454,9 @@ static int wino_wgrad_run_impl(const fcd_conv_desc* d, const float* x, const Win
                                const float* relu_out, float* dw, float* db, void* ws, hipStream_t st, const float* v_fwd) {
   WinoWgPlan pl;
   if (!fcd_wino_wgrad_plan(d, &pl)) return 1;
-  FcdProfScope pw(FCD_K_WGRAD_WINO, st, 2.0 * d->N * d->K * (double)d->P * d->Q * d->C * 9, 0.0,
+  // (same algorithmic bytes as the enclosing weight-gradient scope: bench.py subtracts this family from conv_wgrad to price the DIRECT calls)
+  FcdProfScope pw(FCD_K_WGRAD_WINO, st, 2.0 * d->N * d->K * (double)d->P * d->Q * d->C * 9,
+                  4.0 * ((v_fwd ? 2.25 : 1.0) * d->N * d->C * (double)d->H * d->W + (double)d->N * d->K * d->P * d->Q + (double)d->K * d->C * 9),
                   fcd_prof_tag_desc("wgrad_wino", d));
   char* wsp = (char*)ws;
   float* Wb = (float*)wsp; wsp += (pl.w_bytes + 255) & ~(size_t)255;
