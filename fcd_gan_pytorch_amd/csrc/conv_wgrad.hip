@@ -137,6 +137,9 @@ struct WgradArgs {
   int tiles_q, total_tiles, tiles_per_split;
   int c_tiles;
   long long split_stride;
+  const float* x;     // [r5] NCHW-direct rolling kernel: the operands as they are (no channel-minor copy)
+  const float* dy;
+  float* db_part;     //      [split][Kp] partial bias gradients (null: none wanted)
   int tkc;                      // [r4] split partials as [tap][K][C] (lanes along C: 128-B runs) instead of dw's [K][C][tap], where the 64 lanes
                                 //      of a store hit 64 different 36-B filters; the split reduction writes dw's layout
   unsigned long long* tbuf;     // WG_TIME builds
@@ -439,6 +442,175 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_roll_kernel(WgradArgs a) {
 #endif
 }
 
+// ---------------------------------------------------------------------------
+// [r5] The rolling 3x3 kernel on the NCHW operands themselves (W % 32 == 0, no ReLU mask): the channel-minor copies of x and dy in
+// front of the kernel above are a second read and a write of both tensors -- a third of the 64 -> 64 call (profiles/r04_wgrad_segments.md),
+// 3x the algorithmic HBM bytes of the family (profiles/r05_hbm_traffic.json).  Here the ring slots hold [64 c][44 pixels] (image columns
+// q0 - 4 .. q0 + 39: whole 16-B groups, so a row of a channel is one 176-B run of the LDS-DMA) and the dY slab [64 k][36]; the 11- / 9-unit
+// channel pitch is odd in 16-B units, so a lane reads ITS channel's pixels with conflict-free ds_read_b128.  The two reduction
+// indices of a 32x32x2 MFMA are pixels t and t + 16 of the tile (lane half = which half of the tile row), so every lane holds a
+// contiguous, 16-B aligned window of its row -- 16 + 2 halo pixels of x, 16 of dY -- and the operand of tap s at step t is
+// register t + s + 3 of that window: 18 + 4 LDS instructions per 144 MFMAs instead of 160.  The bias gradient is the sum of the
+// dY windows (workgroups of channel tile 0), per split, finished by channel_psum_fin_kernel.
+// Measured (MI355X, whole call incl. split reduction): 16 x 64 x 256^2 -> 64: 0.86 -> 0.73 ms, 16 x 64 x 128^2 -> 128: 0.40 -> 0.34, 8 x 64 x 256^2: 0.42 -> 0.33
+// (116 TF = 0.74 of the fp32 MFMA peak).  Splits ordered strip-fastest (concurrent workgroups covering whole image rows of a channel between
+// them) changed nothing: the 128-B row pieces are not what bounds it.
+__global__ __launch_bounds__(256, 2) void conv_wgrad_roll_nchw_kernel(WgradArgs a) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  constexpr int TW = 32, XG = 11, XP = 4 * XG, DG = 9, DP = 4 * DG;
+  constexpr int SLOT = 64 * XP, DYS = 64 * DP;
+  __shared__ __attribute__((aligned(16))) float smem[4 * SLOT + 2 * DYS];
+  float* ring = smem;
+  float* dybuf = smem + 4 * SLOT;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wm = wave >> 1, wc = wave & 1;
+  const int ko0 = (blockIdx.x / a.c_tiles) * 64;
+  const int c0 = (blockIdx.x % a.c_tiles) * 64;
+  const int split = blockIdx.y;
+  const float* zsrc = a.zeros + (lane & 15) * 4;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float dbacc = 0.f;
+  const bool want_db = a.db_part != nullptr && c0 == 0 && wc == 0;
+
+  // loop-invariant part of the DMA addresses: unit u = instruction * 64 + lane -> (channel, 16-B group) of the slot image
+  int x_off[3], x_iw[3], dy_off[3];
+  bool x_cok[3], dy_ok[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int u = (wave + 4 * j) * 64 + lane;
+    const int xc = u / XG, xg = u % XG;
+    x_off[j] = (c0 + xc) * a.H * a.W + 4 * xg - 4;
+    x_iw[j] = 4 * xg - 4;
+    x_cok[j] = (wave + 4 * j) < XG && c0 + xc < a.C;
+    const int dk = u / DG, dg = u % DG;
+    dy_off[j] = (ko0 + dk) * a.P * a.Q + 4 * dg;
+    dy_ok[j] = (wave + 4 * j) < DG && ko0 + dk < a.K && dg < DG - 1;       // the ninth group pads the pitch, never read
+  }
+
+  const int tile_beg = split * a.tiles_per_split;
+  const int tile_end = min(tile_beg + a.tiles_per_split, a.total_tiles);
+
+#define FCD_RN_DECODE(T, N_, TQ_, P_) \
+  const int P_ = (T) % a.P;             \
+  const int TQ_ = ((T) / a.P) % a.tiles_q; \
+  const int N_ = (T) / (a.P * a.tiles_q);
+#define FCD_RN_LOAD_ROW(N_, TQ_, IH)                                                                  \
+  {                                                                                                   \
+    const int ih_ = (IH);                                                                             \
+    float* dst = ring + ((ih_ + 1) & 3) * SLOT;                                                       \
+    const bool rowok = ih_ >= 0 && ih_ < a.H;                                                         \
+    const float* base = a.x + ((size_t)(N_) * a.C * a.H + (rowok ? ih_ : 0)) * a.W + (TQ_) * TW;     \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                                   \
+      const int ins = wave + 4 * j;                                                                   \
+      if (ins < XG) {                                                                                 \
+        const int iw = (TQ_) * TW + x_iw[j];                                                          \
+        const bool ok = rowok && x_cok[j] && iw >= 0 && iw < a.W;                                     \
+        const float* src = ok ? base + x_off[j] : zsrc;                                               \
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(dst + ins * 256), 16, 0, 0); \
+      }                                                                                               \
+    }                                                                                                 \
+  }
+#define FCD_RN_LOAD_DY(N_, TQ_, P_, BUF)                                                              \
+  {                                                                                                   \
+    float* dst = dybuf + (BUF) * DYS;                                                                 \
+    const float* base = a.dy + ((size_t)(N_) * a.K * a.P + (P_)) * a.Q + (TQ_) * TW;                 \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                                   \
+      const int ins = wave + 4 * j;                                                                   \
+      if (ins < DG) {                                                                                 \
+        const float* src = dy_ok[j] ? base + dy_off[j] : zsrc;                                        \
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(dst + ins * 256), 16, 0, 0); \
+      }                                                                                               \
+    }                                                                                                 \
+  }
+
+  if (tile_beg < tile_end) {
+    FCD_RN_DECODE(tile_beg, n0, tq0, p0)
+    FCD_RN_LOAD_ROW(n0, tq0, p0 - 1)
+    FCD_RN_LOAD_ROW(n0, tq0, p0)
+    FCD_RN_LOAD_ROW(n0, tq0, p0 + 1)
+    FCD_RN_LOAD_DY(n0, tq0, p0, 0)
+  }
+  __syncthreads();
+  int buf = 0;
+  const int a_lane = (wm * 32 + l31) * DP + 16 * half;
+  const int b_lane = (wc * 32 + l31) * XP + 16 * half;
+  for (int tile = tile_beg; tile < tile_end; ++tile) {
+    FCD_RN_DECODE(tile, n, tq, p)
+    const bool have_next = tile + 1 < tile_end;
+    const bool same_strip = have_next && (p + 1 < a.P);
+    if (have_next) {
+      FCD_RN_DECODE(tile + 1, nn, tqn, pn)
+      FCD_RN_LOAD_DY(nn, tqn, pn, buf ^ 1)
+      if (same_strip) FCD_RN_LOAD_ROW(n, tq, p + 2)       // the one new row of the next tile
+    }
+    float av[16];
+    {
+      const float* ap = dybuf + buf * DYS + a_lane;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const f32x4 q = *(const f32x4*)(ap + 4 * v);
+        av[4 * v] = q[0]; av[4 * v + 1] = q[1]; av[4 * v + 2] = q[2]; av[4 * v + 3] = q[3];
+      }
+    }
+    if (want_db) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) dbacc += av[t];
+    }
+#pragma unroll
+    for (int rl = 0; rl < 3; ++rl) {
+      const float* bp = ring + ((p + rl) & 3) * SLOT + b_lane;      // input row p - 1 + rl
+      float w[24];
+#pragma unroll
+      for (int v = 0; v < 6; ++v) {
+        const f32x4 q = *(const f32x4*)(bp + 4 * v);
+        w[4 * v] = q[0]; w[4 * v + 1] = q[1]; w[4 * v + 2] = q[2]; w[4 * v + 3] = q[3];
+      }
+#pragma unroll
+      for (int t = 0; t < 16; ++t)
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+          acc[rl * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], w[t + s + 3], acc[rl * 3 + s], 0, 0, 0);
+    }
+    __syncthreads();
+    if (have_next && !same_strip) {      // strip change: (re)load the three rows of the new strip
+      FCD_RN_DECODE(tile + 1, nn, tqn, pn)
+      FCD_RN_LOAD_ROW(nn, tqn, pn - 1)
+      FCD_RN_LOAD_ROW(nn, tqn, pn)
+      FCD_RN_LOAD_ROW(nn, tqn, pn + 1)
+      __syncthreads();
+    }
+    buf ^= 1;
+  }
+#undef FCD_RN_DECODE
+#undef FCD_RN_LOAD_ROW
+#undef FCD_RN_LOAD_DY
+
+  if (want_db) {
+    const float v = dbacc + __shfl_xor(dbacc, 32, 64);
+    const int ko = ko0 + wm * 32 + l31;
+    if (half == 0) a.db_part[(size_t)split * a.Kp + ko] = ko < a.K ? v : 0.f;
+  }
+  float* out = a.out + (size_t)split * a.split_stride;
+  const int c = c0 + wc * 32 + l31;
+  if (c < a.C) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int ko = ko0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+        if (ko < a.K) out[a.tkc ? ((size_t)t * a.K + ko) * a.C + c : (((size_t)ko * a.C + c) * 3 + t / 3) * 3 + t % 3] = acc[t][reg];
+      }
+    }
+  }
+}
+
 // dw = sum over split-K partials (fixed order => deterministic).  float4 streams, four independent
 // loads in flight per partial; n4 = n / 4 vectors, the (n % 4) tail is handled by the last threads.
 // (kc > 0: the partials are laid out [tap][K][C], kc = K * C, rs = taps: element e goes to dw[(e % kc) * rs + e / kc])
@@ -610,8 +782,9 @@ static bool wgrad_plan(const fcd_conv_desc* d, WgradPlan* pl) {
   pl->zero_bytes = 1024;
   // bias gradient: per-block channel partials of the dy re-layout (float4 path), else the
   // two-stage channel_sum workspace
-  pl->psum_bytes = std::max((size_t)d->N * cdiv(d->P * d->Q, 64) * pl->Kp * sizeof(float),
-                            (size_t)d->K * 64 * sizeof(double));
+  pl->psum_bytes = std::max(std::max((size_t)d->N * cdiv(d->P * d->Q, 64) * pl->Kp * sizeof(float),
+                                     (size_t)d->K * 64 * sizeof(double)),
+                            (size_t)pl->splits * pl->Kp * sizeof(float));      // [r5] NCHW-direct kernel: [split][Kp]
   return true;
 }
 
@@ -655,6 +828,15 @@ static int wgrad_roll() {
     v = (e && e[0] == '0') ? 0 : 1;
   }
   return v;
+}
+
+// FCD_WGRAD_NCHW=0: channel-minor copies + conv_wgrad_roll_kernel for every 3x3 / stride-1 layer (rounds 1-4).  Read per call (tests switch it).
+static bool wgrad_nchw_ok(const fcd_conv_desc* d, const WgradPlan& pl, const float* x, const float* dy, const float* relu_out) {
+  const char* e = getenv("FCD_WGRAD_NCHW");
+  if (e && e[0] == '0') return false;
+  return d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1 && pl.TW == 32 && (d->W % 32) == 0 && relu_out == nullptr &&
+         ((((size_t)x) | ((size_t)dy)) & 15) == 0 && (long long)pl.Cp * d->H * d->W < (1LL << 31) &&
+         (long long)pl.Kp * d->P * d->Q < (1LL << 31);
 }
 
 template <int R, int S, int RB, int STRIDE, int TW>
@@ -723,7 +905,8 @@ extern "C" int fcd_conv2d_bwd_weight_bias(const fcd_conv_desc* d, const float* x
     fcd_set_error("fcd_conv2d_bwd_weight: memset failed");
     return FCD_ERR_LAUNCH;
   }
-  {
+  const bool nchw = wgrad_roll() && wgrad_nchw_ok(d, pl, x, dy, relu_out);
+  if (!nchw) {
     const int HW = d->H * d->W;
     launch_transpose(x, nullptr, xt, d->N, d->C, HW, pl.Cp, st);
     const int PQ = d->P * d->Q;
@@ -753,7 +936,12 @@ extern "C" int fcd_conv2d_bwd_weight_bias(const fcd_conv_desc* d, const float* x
   a.tkc = (pl.splits > 1 && wgrad_tkc()) ? 1 : 0;
   const int R = d->R, S = d->S, sd = d->stride;
   const bool narrow = pl.TW == 16;
-  if (R == 3 && S == 3 && sd == 1 && d->pad == 1 && wgrad_roll()) {
+  if (nchw) {
+    a.x = x; a.dy = dy; a.db_part = db ? psum : nullptr;
+    dim3 grid((unsigned)(pl.k_tiles * pl.c_tiles), (unsigned)pl.splits, 1);
+    hipLaunchKernelGGL(conv_wgrad_roll_nchw_kernel, grid, dim3(256), 0, st, a);
+    if (db) hipLaunchKernelGGL(channel_psum_fin_kernel, dim3(d->K), dim3(256), 0, st, (const float*)psum, db, d->K, pl.Kp, pl.splits);
+  } else if (R == 3 && S == 3 && sd == 1 && d->pad == 1 && wgrad_roll()) {
     // p-fastest tile order + rolling 4-row ring (see conv_wgrad_roll_kernel)
     dim3 grid((unsigned)(pl.k_tiles * pl.c_tiles), (unsigned)pl.splits, 1);
 #if WG_TIME

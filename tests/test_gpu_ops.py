@@ -922,6 +922,36 @@ def test_weight_gradient_from_the_forward_v_equals_the_one_from_x(case):
     assert_close(out['v'][1], dy.cpu().double().sum(dim=(0, 2, 3)), tol=2e-5, what='db')
 
 
+@pytest.mark.parametrize('case', [(2, 64, 40, 64, 64), (3, 64, 17, 96, 128), (2, 128, 24, 32, 64), (1, 40, 20, 64, 72), (5, 64, 9, 128, 64)],
+                         ids=lambda c: 'x'.join(map(str, c)))
+def test_weight_gradient_on_nchw_operands(case, monkeypatch):
+    """The rolling 3x3 weight-gradient kernel that reads x and dy as they are (``conv_wgrad_roll_nchw_kernel``, W % 32 == 0, no ReLU
+    mask; reference: autograd of nn.Conv2d, Module.py:25-31,177-181) against the round-1..4 route (channel-minor copies of both operands +
+    ``conv_wgrad_roll_kernel``, FCD_WGRAD_NCHW=0) and against the fp64 gradient: several column strips, an odd row count, two filter
+    tiles, two channel tiles, ragged channel / filter counts (zero page), more samples than splits."""
+    import ctypes
+    ops = _ops()
+    lib = ops.lib
+    N, C, H, W, K = case
+    d = ops._desc((N, C, H, W), (K, C, 3, 3), 1, 1)
+    x, dy = rnd(N, C, H, W, seed=171).cuda(), rnd(N, K, H, W, seed=174).cuda()
+    out = {}
+    for tag in ('nchw', 'copies'):
+        monkeypatch.setenv('FCD_WGRAD_NCHW', '1' if tag == 'nchw' else '0')
+        dw, db = torch.full((K, C, 3, 3), float('nan'), device='cuda'), torch.full((K,), float('nan'), device='cuda')
+        ws = ops._ws(lib.fcd_conv2d_bwd_weight_ws_bytes(ctypes.byref(d)), x.device)
+        ops.check(lib.fcd_conv2d_bwd_weight_bias(ctypes.byref(d), ops._p(x), ops._p(dy), None, ops._p(dw), ops._p(db), ops._p(ws),
+                                                 ws.numel(), ops._stream()), 'bwd_weight_bias')
+        out[tag] = (dw.cpu().double(), db.cpu().double())
+    xr, wr = x.cpu().double(), torch.zeros(K, C, 3, 3, dtype=torch.double, requires_grad=True)
+    F.conv2d(xr, wr, None, padding=1).backward(dy.cpu().double())
+    for tag in out:
+        assert_close(out[tag][0], wr.grad, tol=2e-5, what='dw (%s)' % tag)
+        assert_close(out[tag][1], dy.cpu().double().sum(dim=(0, 2, 3)), tol=2e-5, what='db (%s)' % tag)
+    scale = wr.grad.abs().max().item()
+    assert (out['nchw'][0] - out['copies'][0]).abs().max().item() <= 4e-6 * scale      # same products, another summation order
+
+
 @pytest.mark.parametrize('shape', [(2, 2, 512, 16, 16), (1, 3, 40, 7, 5), (2, 1, 64, 13, 13)], ids=lambda c: 'x'.join(map(str, c)))
 def test_pair_gap_diff(shape):
     """AdaptiveAvgPool2d(1)(net(x) - net(y)) of the Discriminator (reference Module.py:211,222-223) on the batched feature

@@ -14,7 +14,7 @@ FAMILIES = {
     'wino_gemm': (['wino_gemm_kernel'], ['wino_gemm'], []),
     'conv_wino2': (['conv_wino2_kernel'], ['conv_wino2_fwd', 'conv_wino2_dgrad'], []),
     # direct weight gradients incl. the 1x1 head: every kernel a fcd_conv2d_bwd_weight* / fcd_conv1x1_head_bwd call launches
-    'conv_wgrad': (['conv_wgrad_kernel', 'conv_wgrad_roll_kernel', 'conv_wgrad_thin_kernel', 'conv_wgrad_thin_finish_kernel',
+    'conv_wgrad': (['conv_wgrad_kernel', 'conv_wgrad_roll_kernel', 'conv_wgrad_roll_nchw_kernel', 'conv_wgrad_thin_kernel', 'conv_wgrad_thin_finish_kernel',
                     'conv_wgrad_thin9_kernel', 'conv_wgrad_thin9_finish_kernel', 'thin9_bias_part_kernel', 'thin9_bias_fin_kernel',
                     'nchw_to_nhwc_kernel', 'nchw_to_nhwc_v4_kernel', 'wgrad_reduce_kernel', 'wgrad_reduce_wide_kernel',
                     'head_wgrad_kernel', 'head_wgrad_final_kernel'],
