@@ -455,6 +455,28 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_roll_kernel(WgradArgs a) {
 // Measured (MI355X, whole call incl. split reduction): 16 x 64 x 256^2 -> 64: 0.86 -> 0.73 ms, 16 x 64 x 128^2 -> 128: 0.40 -> 0.34, 8 x 64 x 256^2: 0.42 -> 0.33
 // (116 TF = 0.74 of the fp32 MFMA peak).  Splits ordered strip-fastest (concurrent workgroups covering whole image rows of a channel between
 // them) changed nothing: the 128-B row pieces are not what bounds it.
+typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wg_bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned wg_u32x4 __attribute__((ext_vector_type(4)));
+// (x0, x1) -> three packed bf16 pairs h, m, l with x = h + m + l exactly (both residuals are exact in fp32, the last one fits 8 bits): the
+// split of conv_wino.hip's GEMM (11 VALU per pair)
+__device__ __forceinline__ void wg_split_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  const wg_bf16x2 hp = {(__bf16)x0, (__bf16)x1};
+  h = __builtin_bit_cast(unsigned, hp);
+  const float r0 = x0 - __uint_as_float(__builtin_amdgcn_perm(h, 0u, 0x05040c0cu)), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+  const wg_bf16x2 mp = {(__bf16)r0, (__bf16)r1};
+  m = __builtin_bit_cast(unsigned, mp);
+  const float q0 = r0 - __uint_as_float(__builtin_amdgcn_perm(m, 0u, 0x05040c0cu)), q1 = r1 - __uint_as_float(m & 0xffff0000u);
+  const wg_bf16x2 lp = {(__bf16)q0, (__bf16)q1};
+  l = __builtin_bit_cast(unsigned, lp);
+}
+
+// SPLIT: the same kernel on the bf16 matrix pipe -- every fp32 operand split exactly into three bf16 parts, six partial products per multiply
+// accumulated in fp32 (fp32-equivalent results, as in the Winograd GEMM): 108 v_mfma_f32_32x32x16_bf16 of 8 passes instead of 144 32x32x2 of 16 per
+// tile = 0.375x the matrix-pipe time, for ~480 VALU per tile and wave.  A 16-pixel reduction step j pairs pixel u with pixel u + 8 in one packed
+// register (lane half h, register m: pixels 16 j + 4 h + m and + 8), so the operand of tap s is four CONSECUTIVE packed registers P[s .. s + 3] of the
+// six pairs P[i] = (x[16 j + 4 h + i - 1], x[.. + 8]) -- the three taps of a row share one split, nothing is re-packed.
+template <bool SPLIT>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_roll_nchw_kernel(WgradArgs a) {
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   constexpr int TW = 32, XG = 11, XP = 4 * XG, DG = 9, DP = 4 * DG;
@@ -539,8 +561,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_roll_nchw_kernel(WgradArgs 
   }
   __syncthreads();
   int buf = 0;
-  const int a_lane = (wm * 32 + l31) * DP + 16 * half;
-  const int b_lane = (wc * 32 + l31) * XP + 16 * half;
+  const int a_lane = (wm * 32 + l31) * DP + (SPLIT ? 4 : 16) * half;
+  const int b_lane = (wc * 32 + l31) * XP + (SPLIT ? 4 : 16) * half;
   for (int tile = tile_beg; tile < tile_end; ++tile) {
     FCD_RN_DECODE(tile, n, tq, p)
     const bool have_next = tile + 1 < tile_end;
@@ -550,6 +572,52 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_roll_nchw_kernel(WgradArgs 
       FCD_RN_LOAD_DY(nn, tqn, pn, buf ^ 1)
       if (same_strip) FCD_RN_LOAD_ROW(n, tq, p + 2)       // the one new row of the next tile
     }
+    if (SPLIT) {
+      // dY: pixels 4 h + 8 g + (0..3), g = 0..3; step j pairs group 2 j with group 2 j + 1
+      wg_u32x4 ah[2], am[2], al[2];
+      {
+        const float* ap = dybuf + buf * DYS + a_lane;
+        f32x4 gq[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gq[g] = *(const f32x4*)(ap + 8 * g);
+        if (want_db) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) dbacc += (gq[g][0] + gq[g][1]) + (gq[g][2] + gq[g][3]);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            unsigned h_, m_, l_;
+            wg_split_pair(gq[2 * j][m], gq[2 * j + 1][m], h_, m_, l_);
+            ah[j][m] = h_; am[j][m] = m_; al[j][m] = l_;
+          }
+      }
+#pragma unroll
+      for (int rl = 0; rl < 3; ++rl) {
+        const float* bp = ring + ((p + rl) & 3) * SLOT + b_lane;      // input row p - 1 + rl; w[t] = slot column 4 h + t
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          float w[20];
+#pragma unroll
+          for (int v = 0; v < 5; ++v) {
+            const f32x4 q = *(const f32x4*)(bp + 16 * j + 4 * v);
+            w[4 * v] = q[0]; w[4 * v + 1] = q[1]; w[4 * v + 2] = q[2]; w[4 * v + 3] = q[3];
+          }
+          unsigned ph[6], pm[6], pl[6];
+#pragma unroll
+          for (int i = 0; i < 6; ++i) wg_split_pair(w[i + 3], w[i + 11], ph[i], pm[i], pl[i]);
+#pragma unroll
+          for (int s = 0; s < 3; ++s) {
+            const wg_u32x4 bh = {ph[s], ph[s + 1], ph[s + 2], ph[s + 3]}, bm = {pm[s], pm[s + 1], pm[s + 2], pm[s + 3]},
+                           bl = {pl[s], pl[s + 1], pl[s + 2], pl[s + 3]};
+#define FCD_WG_MF(AV, BV) acc[rl * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wg_bf16x8, AV), __builtin_bit_cast(wg_bf16x8, BV), acc[rl * 3 + s], 0, 0, 0);
+            FCD_WG_MF(al[j], bh) FCD_WG_MF(ah[j], bl) FCD_WG_MF(am[j], bm) FCD_WG_MF(am[j], bh) FCD_WG_MF(ah[j], bm) FCD_WG_MF(ah[j], bh)
+#undef FCD_WG_MF
+          }
+        }
+      }
+    } else {
     float av[16];
     {
       const float* ap = dybuf + buf * DYS + a_lane;
@@ -577,6 +645,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_roll_nchw_kernel(WgradArgs 
 #pragma unroll
         for (int s = 0; s < 3; ++s)
           acc[rl * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], w[t + s + 3], acc[rl * 3 + s], 0, 0, 0);
+    }
     }
     __syncthreads();
     if (have_next && !same_strip) {      // strip change: (re)load the three rows of the new strip
@@ -939,7 +1008,9 @@ extern "C" int fcd_conv2d_bwd_weight_bias(const fcd_conv_desc* d, const float* x
   if (nchw) {
     a.x = x; a.dy = dy; a.db_part = db ? psum : nullptr;
     dim3 grid((unsigned)(pl.k_tiles * pl.c_tiles), (unsigned)pl.splits, 1);
-    hipLaunchKernelGGL(conv_wgrad_roll_nchw_kernel, grid, dim3(256), 0, st, a);
+    const char* e = getenv("FCD_WGRAD_SPLIT");        // =0: the fp32 matrix pipe (A/B, tests)
+    if (e && e[0] == '0') hipLaunchKernelGGL(conv_wgrad_roll_nchw_kernel<false>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(conv_wgrad_roll_nchw_kernel<true>, grid, dim3(256), 0, st, a);
     if (db) hipLaunchKernelGGL(channel_psum_fin_kernel, dim3(d->K), dim3(256), 0, st, (const float*)psum, db, d->K, pl.Kp, pl.splits);
   } else if (R == 3 && S == 3 && sd == 1 && d->pad == 1 && wgrad_roll()) {
     // p-fastest tile order + rolling 4-row ring (see conv_wgrad_roll_kernel)

@@ -936,8 +936,9 @@ def test_weight_gradient_on_nchw_operands(case, monkeypatch):
     d = ops._desc((N, C, H, W), (K, C, 3, 3), 1, 1)
     x, dy = rnd(N, C, H, W, seed=171).cuda(), rnd(N, K, H, W, seed=174).cuda()
     out = {}
-    for tag in ('nchw', 'copies'):
-        monkeypatch.setenv('FCD_WGRAD_NCHW', '1' if tag == 'nchw' else '0')
+    for tag in ('nchw', 'nchw_fp32_pipe', 'copies'):
+        monkeypatch.setenv('FCD_WGRAD_NCHW', '0' if tag == 'copies' else '1')
+        monkeypatch.setenv('FCD_WGRAD_SPLIT', '0' if tag == 'nchw_fp32_pipe' else '1')     # default: bf16 pipe, operands split exactly in three
         dw, db = torch.full((K, C, 3, 3), float('nan'), device='cuda'), torch.full((K,), float('nan'), device='cuda')
         ws = ops._ws(lib.fcd_conv2d_bwd_weight_ws_bytes(ctypes.byref(d)), x.device)
         ops.check(lib.fcd_conv2d_bwd_weight_bias(ctypes.byref(d), ops._p(x), ops._p(dy), None, ops._p(dw), ops._p(db), ops._p(ws),
@@ -949,7 +950,8 @@ def test_weight_gradient_on_nchw_operands(case, monkeypatch):
         assert_close(out[tag][0], wr.grad, tol=2e-5, what='dw (%s)' % tag)
         assert_close(out[tag][1], dy.cpu().double().sum(dim=(0, 2, 3)), tol=2e-5, what='db (%s)' % tag)
     scale = wr.grad.abs().max().item()
-    assert (out['nchw'][0] - out['copies'][0]).abs().max().item() <= 4e-6 * scale      # same products, another summation order
+    for tag in ('nchw', 'nchw_fp32_pipe'):
+        assert (out[tag][0] - out['copies'][0]).abs().max().item() <= 4e-6 * scale, tag      # same products (the split ones: up to 2^-24 each), another summation order
 
 
 @pytest.mark.parametrize('shape', [(2, 2, 512, 16, 16), (1, 3, 40, 7, 5), (2, 1, 64, 13, 13)], ids=lambda c: 'x'.join(map(str, c)))
