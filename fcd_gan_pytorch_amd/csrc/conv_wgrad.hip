@@ -476,14 +476,22 @@ __device__ __forceinline__ void wg_split_pair(float x0, float x1, unsigned& h, u
 // tile = 0.375x the matrix-pipe time, for ~480 VALU per tile and wave.  A 16-pixel reduction step j pairs pixel u with pixel u + 8 in one packed
 // register (lane half h, register m: pixels 16 j + 4 h + m and + 8), so the operand of tap s is four CONSECUTIVE packed registers P[s .. s + 3] of the
 // six pairs P[i] = (x[16 j + 4 h + i - 1], x[.. + 8]) -- the three taps of a row share one split, nothing is re-packed.
-template <bool SPLIT>
+// STRIDE 2 (the Discriminator's 3x3 / stride-2 layers, SPLIT only): a tile is 16 output pixels of one output row = ONE reduction step; output pixel t
+// under tap s reads input column 2 t + s - 1, so with the slot starting at column 2 q0 - 4 the pair of register m is slot columns 8 h + 2 m + s + 3 and
+// + 16: nine pairs P[0 .. 8] per row, tap s takes P[s], P[s + 2], P[s + 4], P[s + 6].  Output row p needs input rows 2 p - 1 .. 2 p + 1: two new rows
+// per tile, five ring slots (three in use, two in flight).
+template <bool SPLIT, int STRIDE>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_roll_nchw_kernel(WgradArgs a) {
   typedef float f32x4 __attribute__((ext_vector_type(4)));
-  constexpr int TW = 32, XG = 11, XP = 4 * XG, DG = 9, DP = 4 * DG;
+  static_assert(STRIDE == 1 || (STRIDE == 2 && SPLIT), "stride 2 exists on the bf16 pipe only");
+  constexpr int TW = STRIDE == 1 ? 32 : 16;
+  constexpr int XG = STRIDE == 1 ? 11 : 9, XP = 4 * XG, DG = STRIDE == 1 ? 9 : 5, DP = 4 * DG;
+  constexpr int NSLOT = STRIDE == 1 ? 4 : 5;
   constexpr int SLOT = 64 * XP, DYS = 64 * DP;
-  __shared__ __attribute__((aligned(16))) float smem[4 * SLOT + 2 * DYS];
+  __shared__ __attribute__((aligned(16))) float smem[NSLOT * SLOT + 2 * DYS];
   float* ring = smem;
-  float* dybuf = smem + 4 * SLOT;
+  float* dybuf = smem + NSLOT * SLOT;
+  auto slot_of = [](int ih) { return STRIDE == 1 ? ((ih + 1) & 3) : ((ih + 1) % 5); };      // ih >= -1
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
@@ -502,7 +510,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_roll_nchw_kernel(WgradArgs 
   const bool want_db = a.db_part != nullptr && c0 == 0 && wc == 0;
 
   // loop-invariant part of the DMA addresses: unit u = instruction * 64 + lane -> (channel, 16-B group) of the slot image
-  int x_off[3], x_iw[3], dy_off[3];
+  int x_off[3], x_iw[3], dy_off[3], dy_q[3];
   bool x_cok[3], dy_ok[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
@@ -513,7 +521,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_roll_nchw_kernel(WgradArgs 
     x_cok[j] = (wave + 4 * j) < XG && c0 + xc < a.C;
     const int dk = u / DG, dg = u % DG;
     dy_off[j] = (ko0 + dk) * a.P * a.Q + 4 * dg;
-    dy_ok[j] = (wave + 4 * j) < DG && ko0 + dk < a.K && dg < DG - 1;       // the ninth group pads the pitch, never read
+    dy_q[j] = 4 * dg;
+    dy_ok[j] = (wave + 4 * j) < DG && ko0 + dk < a.K && dg < DG - 1;       // the last group pads the pitch, never read
   }
 
   const int tile_beg = split * a.tiles_per_split;
@@ -526,13 +535,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_roll_nchw_kernel(WgradArgs 
 #define FCD_RN_LOAD_ROW(N_, TQ_, IH)                                                                  \
   {                                                                                                   \
     const int ih_ = (IH);                                                                             \
-    float* dst = ring + ((ih_ + 1) & 3) * SLOT;                                                       \
+    float* dst = ring + slot_of(ih_) * SLOT;                                                          \
     const bool rowok = ih_ >= 0 && ih_ < a.H;                                                         \
-    const float* base = a.x + ((size_t)(N_) * a.C * a.H + (rowok ? ih_ : 0)) * a.W + (TQ_) * TW;     \
+    const float* base = a.x + ((size_t)(N_) * a.C * a.H + (rowok ? ih_ : 0)) * a.W + (TQ_) * (TW * STRIDE); \
     _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                                   \
       const int ins = wave + 4 * j;                                                                   \
       if (ins < XG) {                                                                                 \
-        const int iw = (TQ_) * TW + x_iw[j];                                                          \
+        const int iw = (TQ_) * (TW * STRIDE) + x_iw[j];                                               \
         const bool ok = rowok && x_cok[j] && iw >= 0 && iw < a.W;                                     \
         const float* src = ok ? base + x_off[j] : zsrc;                                               \
         __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(dst + ins * 256), 16, 0, 0); \
@@ -546,7 +555,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_roll_nchw_kernel(WgradArgs 
     _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                                   \
       const int ins = wave + 4 * j;                                                                   \
       if (ins < DG) {                                                                                 \
-        const float* src = dy_ok[j] ? base + dy_off[j] : zsrc;                                        \
+        const float* src = (dy_ok[j] && (TQ_) * TW + dy_q[j] < a.Q) ? base + dy_off[j] : zsrc;        \
         __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(dst + ins * 256), 16, 0, 0); \
       }                                                                                               \
     }                                                                                                 \
@@ -554,15 +563,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_roll_nchw_kernel(WgradArgs 
 
   if (tile_beg < tile_end) {
     FCD_RN_DECODE(tile_beg, n0, tq0, p0)
-    FCD_RN_LOAD_ROW(n0, tq0, p0 - 1)
-    FCD_RN_LOAD_ROW(n0, tq0, p0)
-    FCD_RN_LOAD_ROW(n0, tq0, p0 + 1)
+    FCD_RN_LOAD_ROW(n0, tq0, p0 * STRIDE - 1)
+    FCD_RN_LOAD_ROW(n0, tq0, p0 * STRIDE)
+    FCD_RN_LOAD_ROW(n0, tq0, p0 * STRIDE + 1)
     FCD_RN_LOAD_DY(n0, tq0, p0, 0)
   }
   __syncthreads();
   int buf = 0;
   const int a_lane = (wm * 32 + l31) * DP + (SPLIT ? 4 : 16) * half;
-  const int b_lane = (wc * 32 + l31) * XP + (SPLIT ? 4 : 16) * half;
+  const int b_lane = (wc * 32 + l31) * XP + (SPLIT ? 4 * STRIDE : 16) * half;
   for (int tile = tile_beg; tile < tile_end; ++tile) {
     FCD_RN_DECODE(tile, n, tq, p)
     const bool have_next = tile + 1 < tile_end;
@@ -570,22 +579,26 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_roll_nchw_kernel(WgradArgs 
     if (have_next) {
       FCD_RN_DECODE(tile + 1, nn, tqn, pn)
       FCD_RN_LOAD_DY(nn, tqn, pn, buf ^ 1)
-      if (same_strip) FCD_RN_LOAD_ROW(n, tq, p + 2)       // the one new row of the next tile
+      if (same_strip) {                                     // the new row(s) of the next tile
+        FCD_RN_LOAD_ROW(n, tq, (p + 1) * STRIDE + 1)
+        if (STRIDE == 2) FCD_RN_LOAD_ROW(n, tq, (p + 1) * STRIDE)
+      }
     }
     if (SPLIT) {
-      // dY: pixels 4 h + 8 g + (0..3), g = 0..3; step j pairs group 2 j with group 2 j + 1
-      wg_u32x4 ah[2], am[2], al[2];
+      constexpr int NJ = STRIDE == 1 ? 2 : 1;               // 16-pixel reduction steps per tile
+      // dY: step j pairs pixels 16 j + 4 h + m and + 8
+      wg_u32x4 ah[NJ], am[NJ], al[NJ];
       {
         const float* ap = dybuf + buf * DYS + a_lane;
-        f32x4 gq[4];
+        f32x4 gq[2 * NJ];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) gq[g] = *(const f32x4*)(ap + 8 * g);
+        for (int g = 0; g < 2 * NJ; ++g) gq[g] = *(const f32x4*)(ap + 8 * g);
         if (want_db) {
 #pragma unroll
-          for (int g = 0; g < 4; ++g) dbacc += (gq[g][0] + gq[g][1]) + (gq[g][2] + gq[g][3]);
+          for (int g = 0; g < 2 * NJ; ++g) dbacc += (gq[g][0] + gq[g][1]) + (gq[g][2] + gq[g][3]);
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
           for (int m = 0; m < 4; ++m) {
             unsigned h_, m_, l_;
@@ -595,22 +608,24 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_roll_nchw_kernel(WgradArgs 
       }
 #pragma unroll
       for (int rl = 0; rl < 3; ++rl) {
-        const float* bp = ring + ((p + rl) & 3) * SLOT + b_lane;      // input row p - 1 + rl; w[t] = slot column 4 h + t
+        const float* bp = ring + slot_of(p * STRIDE - 1 + rl) * SLOT + b_lane;      // input row p * STRIDE - 1 + rl; w[t] = slot column 4 STRIDE h + t
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          float w[20];
+        for (int j = 0; j < NJ; ++j) {
+          constexpr int NWF = STRIDE == 1 ? 20 : 28, NP = STRIDE == 1 ? 6 : 9, HI = STRIDE == 1 ? 8 : 16;
+          float w[NWF];
 #pragma unroll
-          for (int v = 0; v < 5; ++v) {
+          for (int v = 0; v < NWF / 4; ++v) {
             const f32x4 q = *(const f32x4*)(bp + 16 * j + 4 * v);
             w[4 * v] = q[0]; w[4 * v + 1] = q[1]; w[4 * v + 2] = q[2]; w[4 * v + 3] = q[3];
           }
-          unsigned ph[6], pm[6], pl[6];
+          unsigned ph[NP], pm[NP], pl[NP];
 #pragma unroll
-          for (int i = 0; i < 6; ++i) wg_split_pair(w[i + 3], w[i + 11], ph[i], pm[i], pl[i]);
+          for (int i = 0; i < NP; ++i) wg_split_pair(w[i + 3], w[i + 3 + HI], ph[i], pm[i], pl[i]);
 #pragma unroll
           for (int s = 0; s < 3; ++s) {
-            const wg_u32x4 bh = {ph[s], ph[s + 1], ph[s + 2], ph[s + 3]}, bm = {pm[s], pm[s + 1], pm[s + 2], pm[s + 3]},
-                           bl = {pl[s], pl[s + 1], pl[s + 2], pl[s + 3]};
+            const wg_u32x4 bh = {ph[s], ph[s + STRIDE], ph[s + 2 * STRIDE], ph[s + 3 * STRIDE]},
+                           bm = {pm[s], pm[s + STRIDE], pm[s + 2 * STRIDE], pm[s + 3 * STRIDE]},
+                           bl = {pl[s], pl[s + STRIDE], pl[s + 2 * STRIDE], pl[s + 3 * STRIDE]};
 #define FCD_WG_MF(AV, BV) acc[rl * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wg_bf16x8, AV), __builtin_bit_cast(wg_bf16x8, BV), acc[rl * 3 + s], 0, 0, 0);
             FCD_WG_MF(al[j], bh) FCD_WG_MF(ah[j], bl) FCD_WG_MF(am[j], bm) FCD_WG_MF(am[j], bh) FCD_WG_MF(ah[j], bm) FCD_WG_MF(ah[j], bh)
 #undef FCD_WG_MF
@@ -618,41 +633,41 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_roll_nchw_kernel(WgradArgs 
         }
       }
     } else {
-    float av[16];
-    {
-      const float* ap = dybuf + buf * DYS + a_lane;
+      float av[16];
+      {
+        const float* ap = dybuf + buf * DYS + a_lane;
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const f32x4 q = *(const f32x4*)(ap + 4 * v);
-        av[4 * v] = q[0]; av[4 * v + 1] = q[1]; av[4 * v + 2] = q[2]; av[4 * v + 3] = q[3];
+        for (int v = 0; v < 4; ++v) {
+          const f32x4 q = *(const f32x4*)(ap + 4 * v);
+          av[4 * v] = q[0]; av[4 * v + 1] = q[1]; av[4 * v + 2] = q[2]; av[4 * v + 3] = q[3];
+        }
       }
-    }
-    if (want_db) {
+      if (want_db) {
 #pragma unroll
-      for (int t = 0; t < 16; ++t) dbacc += av[t];
-    }
-#pragma unroll
-    for (int rl = 0; rl < 3; ++rl) {
-      const float* bp = ring + ((p + rl) & 3) * SLOT + b_lane;      // input row p - 1 + rl
-      float w[24];
-#pragma unroll
-      for (int v = 0; v < 6; ++v) {
-        const f32x4 q = *(const f32x4*)(bp + 4 * v);
-        w[4 * v] = q[0]; w[4 * v + 1] = q[1]; w[4 * v + 2] = q[2]; w[4 * v + 3] = q[3];
+        for (int t = 0; t < 16; ++t) dbacc += av[t];
       }
 #pragma unroll
-      for (int t = 0; t < 16; ++t)
+      for (int rl = 0; rl < 3; ++rl) {
+        const float* bp = ring + slot_of(p - 1 + rl) * SLOT + b_lane;      // input row p - 1 + rl
+        float w[24];
 #pragma unroll
-        for (int s = 0; s < 3; ++s)
-          acc[rl * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], w[t + s + 3], acc[rl * 3 + s], 0, 0, 0);
-    }
+        for (int v = 0; v < 6; ++v) {
+          const f32x4 q = *(const f32x4*)(bp + 4 * v);
+          w[4 * v] = q[0]; w[4 * v + 1] = q[1]; w[4 * v + 2] = q[2]; w[4 * v + 3] = q[3];
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+#pragma unroll
+          for (int s = 0; s < 3; ++s)
+            acc[rl * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], w[t + s + 3], acc[rl * 3 + s], 0, 0, 0);
+      }
     }
     __syncthreads();
     if (have_next && !same_strip) {      // strip change: (re)load the three rows of the new strip
       FCD_RN_DECODE(tile + 1, nn, tqn, pn)
-      FCD_RN_LOAD_ROW(nn, tqn, pn - 1)
-      FCD_RN_LOAD_ROW(nn, tqn, pn)
-      FCD_RN_LOAD_ROW(nn, tqn, pn + 1)
+      FCD_RN_LOAD_ROW(nn, tqn, pn * STRIDE - 1)
+      FCD_RN_LOAD_ROW(nn, tqn, pn * STRIDE)
+      FCD_RN_LOAD_ROW(nn, tqn, pn * STRIDE + 1)
       __syncthreads();
     }
     buf ^= 1;
@@ -903,7 +918,11 @@ static int wgrad_roll() {
 static bool wgrad_nchw_ok(const fcd_conv_desc* d, const WgradPlan& pl, const float* x, const float* dy, const float* relu_out) {
   const char* e = getenv("FCD_WGRAD_NCHW");
   if (e && e[0] == '0') return false;
-  return d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1 && pl.TW == 32 && (d->W % 32) == 0 && relu_out == nullptr &&
+  const char* sp = getenv("FCD_WGRAD_SPLIT");
+  const bool split = !(sp && sp[0] == '0');
+  const bool geom = d->stride == 1 ? (pl.TW == 32 && (d->W % 32) == 0)
+                                   : (d->stride == 2 && split && pl.TW == 16 && (d->W % 8) == 0 && d->Q == d->W / 2);     // [r5] stride 2: bf16 pipe only
+  return d->R == 3 && d->S == 3 && d->pad == 1 && geom && relu_out == nullptr &&
          ((((size_t)x) | ((size_t)dy)) & 15) == 0 && (long long)pl.Cp * d->H * d->W < (1LL << 31) &&
          (long long)pl.Kp * d->P * d->Q < (1LL << 31);
 }
@@ -1009,8 +1028,9 @@ extern "C" int fcd_conv2d_bwd_weight_bias(const fcd_conv_desc* d, const float* x
     a.x = x; a.dy = dy; a.db_part = db ? psum : nullptr;
     dim3 grid((unsigned)(pl.k_tiles * pl.c_tiles), (unsigned)pl.splits, 1);
     const char* e = getenv("FCD_WGRAD_SPLIT");        // =0: the fp32 matrix pipe (A/B, tests)
-    if (e && e[0] == '0') hipLaunchKernelGGL(conv_wgrad_roll_nchw_kernel<false>, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(conv_wgrad_roll_nchw_kernel<true>, grid, dim3(256), 0, st, a);
+    if (d->stride == 2) hipLaunchKernelGGL((conv_wgrad_roll_nchw_kernel<true, 2>), grid, dim3(256), 0, st, a);
+    else if (e && e[0] == '0') hipLaunchKernelGGL((conv_wgrad_roll_nchw_kernel<false, 1>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv_wgrad_roll_nchw_kernel<true, 1>), grid, dim3(256), 0, st, a);
     if (db) hipLaunchKernelGGL(channel_psum_fin_kernel, dim3(d->K), dim3(256), 0, st, (const float*)psum, db, d->K, pl.Kp, pl.splits);
   } else if (R == 3 && S == 3 && sd == 1 && d->pad == 1 && wgrad_roll()) {
     // p-fastest tile order + rolling 4-row ring (see conv_wgrad_roll_kernel)

@@ -922,7 +922,9 @@ def test_weight_gradient_from_the_forward_v_equals_the_one_from_x(case):
     assert_close(out['v'][1], dy.cpu().double().sum(dim=(0, 2, 3)), tol=2e-5, what='db')
 
 
-@pytest.mark.parametrize('case', [(2, 64, 40, 64, 64), (3, 64, 17, 96, 128), (2, 128, 24, 32, 64), (1, 40, 20, 64, 72), (5, 64, 9, 128, 64)],
+@pytest.mark.parametrize('case', [(2, 64, 40, 64, 64), (3, 64, 17, 96, 128), (2, 128, 24, 32, 64), (1, 40, 20, 64, 72), (5, 64, 9, 128, 64),
+                                  # stride 2 (the Discriminator's layers; bf16 pipe only): square, odd height, ragged last tile + ragged filter count, one short tile
+                                  (2, 64, 32, 32, 128, 2), (3, 64, 17, 48, 64, 2), (2, 128, 24, 40, 72, 2), (1, 256, 16, 16, 512, 2), (4, 64, 64, 128, 128, 2)],
                          ids=lambda c: 'x'.join(map(str, c)))
 def test_weight_gradient_on_nchw_operands(case, monkeypatch):
     """The rolling 3x3 weight-gradient kernel that reads x and dy as they are (``conv_wgrad_roll_nchw_kernel``, W % 32 == 0, no ReLU
@@ -932,11 +934,13 @@ def test_weight_gradient_on_nchw_operands(case, monkeypatch):
     import ctypes
     ops = _ops()
     lib = ops.lib
-    N, C, H, W, K = case
-    d = ops._desc((N, C, H, W), (K, C, 3, 3), 1, 1)
-    x, dy = rnd(N, C, H, W, seed=171).cuda(), rnd(N, K, H, W, seed=174).cuda()
+    N, C, H, W, K = case[:5]
+    st = case[5] if len(case) > 5 else 1
+    d = ops._desc((N, C, H, W), (K, C, 3, 3), st, 1)
+    P, Q = (H - 1) // st + 1, (W - 1) // st + 1
+    x, dy = rnd(N, C, H, W, seed=171).cuda(), rnd(N, K, P, Q, seed=174).cuda()
     out = {}
-    for tag in ('nchw', 'nchw_fp32_pipe', 'copies'):
+    for tag in (('nchw', 'nchw_fp32_pipe', 'copies') if st == 1 else ('nchw', 'copies')):
         monkeypatch.setenv('FCD_WGRAD_NCHW', '0' if tag == 'copies' else '1')
         monkeypatch.setenv('FCD_WGRAD_SPLIT', '0' if tag == 'nchw_fp32_pipe' else '1')     # default: bf16 pipe, operands split exactly in three
         dw, db = torch.full((K, C, 3, 3), float('nan'), device='cuda'), torch.full((K,), float('nan'), device='cuda')
@@ -945,12 +949,12 @@ def test_weight_gradient_on_nchw_operands(case, monkeypatch):
                                                  ws.numel(), ops._stream()), 'bwd_weight_bias')
         out[tag] = (dw.cpu().double(), db.cpu().double())
     xr, wr = x.cpu().double(), torch.zeros(K, C, 3, 3, dtype=torch.double, requires_grad=True)
-    F.conv2d(xr, wr, None, padding=1).backward(dy.cpu().double())
+    F.conv2d(xr, wr, None, stride=st, padding=1).backward(dy.cpu().double())
     for tag in out:
         assert_close(out[tag][0], wr.grad, tol=2e-5, what='dw (%s)' % tag)
         assert_close(out[tag][1], dy.cpu().double().sum(dim=(0, 2, 3)), tol=2e-5, what='db (%s)' % tag)
     scale = wr.grad.abs().max().item()
-    for tag in ('nchw', 'nchw_fp32_pipe'):
+    for tag in [t for t in out if t != 'copies']:
         assert (out[tag][0] - out['copies'][0]).abs().max().item() <= 4e-6 * scale, tag      # same products (the split ones: up to 2^-24 each), another summation order
 
 
