@@ -106,6 +106,7 @@ struct WinoGemmArgs {
   float* C;         // [split][batch][M][N]
   int M, N, Kc, m_tiles, n_tiles, xcd_remap;
   long long a_ld, a_batch, b_ld, b_adv, b_batch;
+  long long a_adv;  // split kernel <2, 2>: elements from stage q to stage q + 1 of an A row (0: 32, rows contiguous along the reduction)
   int stages_per_split;   // blockIdx.z = split of the reduction: stages [z * sps, min((z + 1) * sps, Kc / 32))
   const unsigned short* As;   // split kernel: bf16 planes (high, middle, low part) of A, plane p at As + p * as_plane,
   long long as_plane;         // each laid out like A (a_ld, a_batch in elements)

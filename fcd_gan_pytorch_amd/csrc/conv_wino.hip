@@ -694,7 +694,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void wino_gem
   const int Q = min(a.stages_per_split, q_all - q_beg);
   const int b_first = (int)by_ * a.xb;
   const int nb = min(a.xb, a.batches - b_first);
-  const unsigned short* Ab = a.As + (size_t)b_first * a.a_batch + (size_t)q_beg * KC + (size_t)m0 * a.a_ld;
+  const long long a_adv = a.a_adv ? a.a_adv : KC;
+  const unsigned short* Ab = a.As + (size_t)b_first * a.a_batch + (size_t)q_beg * a_adv + (size_t)m0 * a.a_ld;
   const float* Bb = BT ? a.B + (size_t)b_first * a.b_batch
                        : a.B + (size_t)b_first * a.b_batch + (size_t)q_beg * a.b_adv + (size_t)n0 * a.b_ld;
 
@@ -746,7 +747,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void wino_gem
   int fq = 0, fb = 0;
 #define WS_DMA(SA, SB)                                                                           \
   {                                                                                              \
-    const unsigned short* as_ = Ab + (size_t)fb * a.a_batch + (size_t)fq * KC;                   \
+    const unsigned short* as_ = Ab + (size_t)fb * a.a_batch + (size_t)fq * a_adv;                   \
     const float* bs_ = BT ? Bb + (size_t)fb * a.b_batch : Bb + (size_t)fb * a.b_batch + (size_t)fq * a.b_adv; \
     _Pragma("unroll") for (int j = 0; j < PPW_A; ++j)                                            \
       __builtin_amdgcn_global_load_lds((gbl_void_t*)(as_ + a_goff[j]),                           \
@@ -1304,7 +1305,7 @@ static void wino_gemm_launch(WinoGemmArgs ga, int batches, int splits, hipStream
   int cfg = wino_gemm_cfg();
   if (ga.As && ga.M > 64 && wino_split()) {
     ga.batches = batches;
-    if (splits > 1 || ga.bt) {          // weight gradient: split reduction, one transform position per workgroup
+    if (splits > 1 || ga.bt || ga.a_adv) {          // weight gradient: split reduction, one transform position per workgroup (the only kernel that reads A in stage slabs)
       ga.m_tiles = cdiv(ga.M, 128); ga.n_tiles = cdiv(ga.N, 128);
       ga.xb = 1;
       ga.xcd_remap = wino_xcd_mode(ga.m_tiles * ga.n_tiles, batches * splits) == 2 ? 2 : 0;      // (mode 1 was never on for these launches)
@@ -2190,11 +2191,20 @@ __global__ __launch_bounds__(256) void wino_wg_input_kernel(WinoWgArgs a) {
 // W[xi][k][t] = A dY A^T, plus per-block channel sums of dY (bias gradient)
 __global__ __launch_bounds__(256) void wino_wg_dy_kernel(WinoWgArgs a) {
   // one thread = TWO consecutive tiles (Tpad is even): float4 row reads where the rows allow it, and the three bf16
-  // planes leave as 4-byte pairs (2-byte stores run at half the rate: the pass is store-bound, 3.4x the bytes it reads)
+  // planes leave as 4-byte pairs (2-byte stores run at half the rate: the pass is store-bound, 3.4x the bytes it reads).
+  // [r5] The planes are laid out for the GEMM's stage loop, [plane][xi][stage = t / 32][k][t % 32]: the 64 bytes a row
+  // contributes to a 32-tile stage sit next to the neighbouring rows' (a stage slab of 128 rows = 8 KB contiguous per
+  // plane) instead of Tpad x 2 bytes apart.  Read as rows, every 128-B line was touched by two consecutive stages of a
+  // workgroup, and with 512 workgroups' lines in flight L2 did not hold them from one stage to the next: the weight-gradient
+  // GEMMs ran at 3.7 - 3.9 TB/s on their operand bytes, 4.2 - 4.7 from slabs.  A block = 2 filters x 256 tiles, lanes
+  // (tile pair, filter parity, stage) so that one store instruction covers whole 128-B lines [k, k + 1][32 tiles].
   constexpr int A = 6;
   __shared__ double red[16];
-  const long long t0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 2;
-  const int k = blockIdx.y;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int ks = (lane >> 4) & 1, stg = (lane >> 5) + 2 * wv;
+  const long long t0 = (long long)blockIdx.x * 256 + stg * 32 + (lane & 15) * 2;
+  const int k = min((int)blockIdx.y * 2 + ks, a.CH - 1);
+  const bool kok = (int)blockIdx.y * 2 + ks < a.CH;
   float dy[2][4][4];
   float lsum = 0.f;
   const bool vec = (a.W & 3) == 0;
@@ -2205,7 +2215,7 @@ __global__ __launch_bounds__(256) void wino_wg_dy_kernel(WinoWgArgs a) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) dy[e][i][j] = 0.f;
-    if (t < a.T) {
+    if (t < a.T && kok) {
       const int tx = (int)(t % a.TW);
       const long long r2 = t / a.TW;
       const int ty = (int)(r2 % a.TH), n = (int)(r2 / a.TH);
@@ -2241,14 +2251,18 @@ __global__ __launch_bounds__(256) void wino_wg_dy_kernel(WinoWgArgs a) {
         for (int j = 0; j < 4; ++j) lsum += dy[e][i][j];
     }
   }
-  if (a.psum != nullptr) {       // uniform: every thread of the block takes part
-    const double bs = block_sum_d((double)lsum, red);
-    if (threadIdx.x == 0) a.psum[(size_t)blockIdx.x * a.CH + k] = (float)bs;
+  if (a.psum != nullptr) {       // uniform: every thread of the block takes part; one sum per filter of the pair
+    const double b0 = block_sum_d(ks == 0 ? (double)lsum : 0.0, red);
+    const double b1 = block_sum_d(ks == 1 ? (double)lsum : 0.0, red);
+    if (threadIdx.x == 0) {
+      a.psum[(size_t)blockIdx.x * a.CH + blockIdx.y * 2] = (float)b0;
+      if ((int)blockIdx.y * 2 + 1 < a.CH) a.psum[(size_t)blockIdx.x * a.CH + blockIdx.y * 2 + 1] = (float)b1;
+    }
   }
-  if (t0 >= a.Tpad) return;
+  if (t0 >= a.Tpad || !kok) return;
   float* wout = a.dst + (size_t)k * a.Tpad + t0;
   const size_t xs = (size_t)a.CH * a.Tpad;
-  unsigned short* pout = a.planes ? a.planes + (size_t)k * a.Tpad + t0 : nullptr;
+  unsigned short* pout = a.planes ? a.planes + ((size_t)(t0 >> 5) * a.CH + k) * 32 + (t0 & 31) : nullptr;
   const size_t ps = 36 * xs;
   float t1[2][A][4];   // A dY : A[q][i] = AT(i, q)
 #pragma unroll
@@ -2389,9 +2403,27 @@ int fcd_wino_wgrad_plan(const fcd_conv_desc* d, WinoWgPlan* pl) {
   pl->Tpad = (pl->T + 31) / 32 * 32;
   pl->stages = (int)(pl->Tpad / 32);
   const int blocks = cdiv(d->K, 128) * cdiv(d->C, 128) * 36;
-  static int wg_wgs = -1;             // FCD_WINO_WG_WGS: workgroups the reduction split aims at
-  if (wg_wgs < 0) { const char* e = getenv("FCD_WINO_WG_WGS"); wg_wgs = e ? atoi(e) : 1024; if (wg_wgs < 1) wg_wgs = 1024; }   // [r4] 1024 (was 1536): -2 % over the Segmentor's 16 layers
-  int splits = cdiv(wg_wgs, blocks);
+  static int wg_wgs = -1;             // FCD_WINO_WG_WGS=<n>: the round-4 rule (splits = ceil(n / blocks)); unset / 0: the round model below
+  if (wg_wgs < 0) { const char* e = getenv("FCD_WINO_WG_WGS"); wg_wgs = e ? atoi(e) : 0; if (wg_wgs < 0) wg_wgs = 0; }
+  int splits;
+  if (wg_wgs > 0) {
+    splits = cdiv(wg_wgs, blocks);
+  } else {
+    // [r5] Every workgroup of the launch does the same work and 512 are resident (2 per CU), so the launch runs in
+    // ROUNDS of 512: ceil(1024 / blocks) put every layer at 1044 ... 1152 workgroups = a third round for 2 - 12 % of
+    // the work.  Pick the split count that minimises rounds x (stages per split + fill / drain of one workgroup,
+    // ~5 stages) + the extra dU planes written and summed (0.3 stage-equivalents per 128 x 128 tile and split).
+    const int tiles = blocks / 36;
+    long best = -1;
+    splits = 1;
+    for (int s = 1; s <= 64 && s <= pl->stages; ++s) {
+      const int sps = cdiv(pl->stages, s), s2 = cdiv(pl->stages, sps);
+      if (s2 != s) continue;
+      const long rounds = cdiv(blocks * s, 512);
+      const long cost = rounds * (sps + 5) * 10 + 3L * tiles * (s - 1);
+      if (best < 0 || cost < best) { best = cost; splits = s; }
+    }
+  }
   if (splits > pl->stages) splits = pl->stages;
   if (splits > 64) splits = 64;
   if (splits < 1) splits = 1;
@@ -2480,8 +2512,8 @@ static int wino_wgrad_run_impl(const fcd_conv_desc* d, const float* x, const Win
     memset(&ya.cat, 0, sizeof(ya.cat));
     ya.src = dy; ya.mask = relu_out; ya.dst = Wb; ya.CH = d->K; ya.psum = db ? psum : nullptr;
     ya.planes = split ? (unsigned short*)Wb : nullptr;
-    const unsigned tb2 = (unsigned)cdiv64(pl.Tpad, 512);     // two tiles per thread
-    hipLaunchKernelGGL(wino_wg_dy_kernel, dim3(tb2, (unsigned)d->K), dim3(256), 0, st, ya);
+    const unsigned tb2 = (unsigned)cdiv64(pl.Tpad, 256);     // two tiles per thread, two filters per block
+    hipLaunchKernelGGL(wino_wg_dy_kernel, dim3(tb2, (unsigned)cdiv(d->K, 2)), dim3(256), 0, st, ya);
     if (db) hipLaunchKernelGGL(wino_psum_fin_kernel, dim3((unsigned)d->K), dim3(256), 0, st, (const float*)psum, db, d->K, (int)tb2);
   }
   WinoGemmArgs ga;
@@ -2498,6 +2530,7 @@ static int wino_wgrad_run_impl(const fcd_conv_desc* d, const float* x, const Win
     ga.b_batch = (long long)(d->C / 32) * pl.T * 32;
   }
   ga.stages_per_split = pl.sps;
+  if (split) { ga.a_ld = 32; ga.a_adv = (long long)d->K * 32; }      // dY~ planes in stage slabs [stage][k][32] (wino_wg_dy_kernel)
   {
     FcdProfScope p2(split ? FCD_K_WINO_GEMM_SPLIT : FCD_K_WINO_GEMM, st, 2.0 * 36 * d->K * (double)d->C * (double)pl.Tpad,
                     (double)pl.w_bytes / 6 * (split ? 6 : 4) + (double)pl.v_bytes + (double)pl.du_bytes,
