@@ -799,6 +799,214 @@ __global__ __launch_bounds__(256, (MI * NI > 4) ? 2 : FCD_WPE) void conv_igemm_g
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// [r5] Sub-pixel data gradient of the stride-2 layers (see pack_weights_s2_kernel below for the algebra) in the global_load_lds
+// form: the register-staged kernel above spent 45 - 55 % of a wave's life staging (profiles/r04_igemm_segments.md) -- a step of 8
+// channels is only 16 ... 64 MFMAs per wave behind two barriers and a filter slab that goes global -> VGPR -> LDS.  Here the
+// slab [h][m][20] (per lane half h the 16 k-values (4 channels x 2 x 2 pseudo-taps) of GEMM row m, 80-B rows as in the 3x3
+// kernel) arrives by LDS-DMA into one of two buffers, the (TH + 1) x (TW + 1) patch of 8 dy channels is double-buffered too:
+// one barrier per step, three workgroups per CU.  Rows stay class-major (row = phase * C + c), so a wave whose 64 rows lie
+// in one phase skips that phase's zero taps as before (9 real taps of 16 over the four phases).
+#define FCD_S2_KROW 20
+#define FCD_S2_KH 16
+template <int MI, int NI, int WM, int WN, int TH, int TW>
+__global__ __launch_bounds__(256, 3) void conv_s2sub_glds_kernel(ConvArgs a) {
+  constexpr int CB = 8;
+  constexpr int BM = 32 * MI * WM;
+  constexpr int BN = 32 * NI * WN;
+  static_assert(WM * WN == 4, "4 waves");
+  static_assert(TH * TW == BN, "pixel tile");
+  constexpr int PH = TH + 1, PW = TW + 1;
+  constexpr int PWP = PW | 1;
+  constexpr int PLANE = PH * PWP;
+  constexpr int WS_SZ = 2 * BM * FCD_S2_KROW;
+  static_assert(WS_SZ % 256 == 0, "slab must be a whole number of wave loads");
+  constexpr int W_INSTR = WS_SZ / 256;
+  constexpr int W_PER_WAVE = (W_INSTR + 3) / 4;
+  constexpr int X_ELEMS = CB * PH * PW;
+  constexpr int X_PER_T = (X_ELEMS + 255) / 256;
+  constexpr int XS_SZ = CB * PLANE;
+  __shared__ __attribute__((aligned(16))) float smem_w0[WS_SZ];
+  __shared__ __attribute__((aligned(16))) float smem_w1[WS_SZ];
+  __shared__ __attribute__((aligned(16))) float smem_x[2 * XS_SZ];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wm = wave / WN, wn = wave % WN;
+  int ktile, bx;
+  if (a.xcd_remap) {
+    const unsigned total = gridDim.x, b = blockIdx.x;
+    const unsigned q8 = total >> 3, r8 = total & 7u, xcd = b & 7u;
+    const unsigned v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
+    ktile = (int)(v % (unsigned)a.k_tiles);
+    bx = (int)(v / (unsigned)a.k_tiles);
+  } else {
+    ktile = blockIdx.y;
+    bx = blockIdx.x;
+  }
+  const int tq = bx % a.tiles_q;
+  bx /= a.tiles_q;
+  const int tp = bx % a.tiles_p;
+  const int n = bx / a.tiles_p;
+  const int ko0 = ktile * BM;
+  const int p0 = tp * TH, q0 = tq * TW;
+
+  int xoff[NI], aoff[MI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int pidx = wn * (32 * NI) + ni * 32 + l31;
+    xoff[ni] = half * (CB / 2) * PLANE + (pidx / TW) * PWP + (pidx % TW);
+  }
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) aoff[mi] = (half * BM + wm * (32 * MI) + mi * 32 + l31) * FCD_S2_KROW;
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  int w_goff[W_PER_WAVE];
+#pragma unroll
+  for (int j = 0; j < W_PER_WAVE; ++j) {
+    const int u = (wave + 4 * j) * 64 + lane;
+    const int h = u / (BM * (FCD_S2_KROW / 4)), m = (u / (FCD_S2_KROW / 4)) % BM, part = u % (FCD_S2_KROW / 4);
+    w_goff[j] = (h * a.Kpad + ko0 + m) * FCD_S2_KROW + part * 4;
+  }
+  const size_t w_chunk_stride = (size_t)2 * a.Kpad * FCD_S2_KROW;
+
+  float xr[X_PER_T];
+  unsigned x_boff[X_PER_T];
+  int x_loff[X_PER_T], x_cc[X_PER_T];
+#pragma unroll
+  for (int i = 0; i < X_PER_T; ++i) {
+    const int idx = tid + i * 256;
+    const int cc = idx / (PH * PW), rem = idx % (PH * PW);
+    const int ph = rem / PW, pw = rem % PW;
+    const int ih = p0 + ph, iw = q0 + pw;
+    const bool ok = idx < X_ELEMS && ih < a.H && iw < a.W;
+    x_loff[i] = cc * PLANE + ph * PWP + pw;
+    x_cc[i] = ok ? cc : -1;
+    x_boff[i] = ok ? (unsigned)((cc * a.H + ih) * a.W + iw) * 4u : 0u;
+  }
+  const float* xin = a.x + (size_t)n * a.C * a.H * a.W;
+  const int chunk_elems = CB * a.H * a.W;
+
+  // taps (u, v) that are non-zero for some phase among this wave's rows (bit u * 2 + v)
+  unsigned tapmask;
+  {
+    const int lo = ko0 + wm * (32 * MI), hi = min(lo + 32 * MI, a.K) - 1;
+    unsigned m = 0;
+    if (lo <= hi)
+      for (int cls = lo / a.shuf_C; cls <= hi / a.shuf_C; ++cls)
+        m |= 1u | ((cls & 1) ? 2u : 0u) | ((cls & 2) ? 4u : 0u) | ((cls & 3) == 3 ? 8u : 0u);
+    tapmask = (unsigned)__builtin_amdgcn_readfirstlane((int)m);
+  }
+
+#define S2_GLDS_W(CCHUNK, WDST)                                                                       \
+  {                                                                                                   \
+    const float* wsrc = a.wp + (size_t)(CCHUNK) * w_chunk_stride;                                     \
+    _Pragma("unroll") for (int j = 0; j < W_PER_WAVE; ++j) {                                          \
+      if (W_INSTR % 4 == 0 || wave + 4 * j < W_INSTR)                                                 \
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(wsrc + w_goff[j]),                             \
+                                         (lds_void_t*)((WDST) + (wave + 4 * j) * 256), 16, 0, 0);     \
+    }                                                                                                 \
+  }
+#define S2_LOAD_X(CCHUNK)                                                                             \
+  {                                                                                                   \
+    const int cleft = a.C - (CCHUNK) * CB;                                                            \
+    const bool tail = cleft < CB;                                                                     \
+    const char* xsrc = (const char*)(xin + (size_t)(CCHUNK) * chunk_elems);                           \
+    _Pragma("unroll") for (int i = 0; i < X_PER_T; ++i) {                                             \
+      unsigned off = x_boff[i];                                                                       \
+      if (tail) off = (x_cc[i] < cleft) ? off : 0u;                                                   \
+      xr[i] = *(const float*)(xsrc + off);                                                            \
+    }                                                                                                 \
+  }
+#define S2_STORE_X(BUF, CCHUNK)                                                                       \
+  {                                                                                                   \
+    const int cleft = a.C - (CCHUNK) * CB;                                                            \
+    _Pragma("unroll") for (int i = 0; i < X_PER_T; ++i) {                                             \
+      if (X_ELEMS % 256 == 0 || tid + i * 256 < X_ELEMS)                                              \
+        smem_x[(BUF) * XS_SZ + x_loff[i]] = ((unsigned)x_cc[i] < (unsigned)cleft) ? xr[i] : 0.f;      \
+    }                                                                                                 \
+  }
+
+  const int nsteps = a.nchunks;
+  S2_GLDS_W(0, smem_w0)
+  S2_LOAD_X(0)
+  S2_STORE_X(0, 0)
+  __syncthreads();
+
+#define S2_STEP(STEP, WCUR, WNXT)                                                                     \
+  {                                                                                                   \
+    const int chunk = (STEP);                                                                         \
+    const bool have_next = chunk + 1 < nsteps;                                                        \
+    const int xb = chunk & 1;                                                                         \
+    if (have_next) {                                                                                  \
+      S2_GLDS_W(chunk + 1, WNXT)                                                                      \
+      S2_LOAD_X(chunk + 1)                                                                            \
+    }                                                                                                 \
+    const float* xl = smem_x + xb * XS_SZ;                                                            \
+    float av[MI][FCD_S2_KH];                                                                          \
+    _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) {                                               \
+      const float* ap = (WCUR) + aoff[mi];                                                            \
+      _Pragma("unroll") for (int v4 = 0; v4 < 4; ++v4) {                                              \
+        const f32x4 t4 = *(const f32x4*)(ap + 4 * v4);                                                \
+        av[mi][4 * v4] = t4[0]; av[mi][4 * v4 + 1] = t4[1];                                           \
+        av[mi][4 * v4 + 2] = t4[2]; av[mi][4 * v4 + 3] = t4[3];                                       \
+      }                                                                                               \
+    }                                                                                                 \
+    _Pragma("unroll") for (int tap = 0; tap < 4; ++tap) {                                             \
+      if (!((tapmask >> tap) & 1u)) continue;                                                         \
+      _Pragma("unroll") for (int cl = 0; cl < CB / 2; ++cl) {                                         \
+        float bv[NI];                                                                                 \
+        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                             \
+          bv[ni] = xl[xoff[ni] + cl * PLANE + (tap >> 1) * PWP + (tap & 1)];                          \
+        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                             \
+          _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                           \
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][cl * 4 + tap], bv[ni], acc[mi][ni], 0, 0, 0); \
+      }                                                                                               \
+    }                                                                                                 \
+    if (have_next) S2_STORE_X(xb ^ 1, chunk + 1)                                                      \
+    __syncthreads();                                                                                  \
+  }
+
+  for (int step = 0; step < nsteps; step += 2) {
+    S2_STEP(step, smem_w0, smem_w1)
+    if (step + 1 < nsteps) S2_STEP(step + 1, smem_w1, smem_w0)
+  }
+#undef S2_STEP
+#undef S2_GLDS_W
+#undef S2_LOAD_X
+#undef S2_STORE_X
+
+  // scatter epilogue: row ko = phase * shuf_C + c  ->  dx[n][c][2 p + (phase >> 1)][2 q + (phase & 1)]
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int pidx = wn * (32 * NI) + ni * 32 + l31;
+    const int p = p0 + pidx / TW, q = q0 + pidx % TW;
+    if (p >= a.P || q >= a.Q) continue;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ko = ko0 + wm * (32 * MI) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (ko < a.K) {
+          const int cls = ko / a.shuf_C, c = ko - cls * a.shuf_C;
+          const int ph2 = 2 * p + (cls >> 1), qw2 = 2 * q + (cls & 1);
+          if (ph2 < a.shuf_H && qw2 < a.shuf_W)
+            a.y[(((size_t)n * a.shuf_C + c) * a.shuf_H + ph2) * a.shuf_W + qw2] = acc[mi][ni][r];
+        }
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // weight packing
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int K, int C,
@@ -1253,6 +1461,29 @@ __global__ void pack_weights_s2_kernel(const float* __restrict__ w, float* __res
   }
 }
 
+// the same pseudo-filters in the slab layout of conv_s2sub_glds_kernel: wt[q][h][m][20], k-value j = cl * 4 + u * 2 + v of
+// forward filter k = 8 q + 4 h + cl (j >= 16: padding)
+__global__ void pack_weights_s2t_kernel(const float* __restrict__ w, float* __restrict__ wt, int K, int C, int Mpad,
+                                        int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int j = (int)(i % FCD_S2_KROW);
+    int64_t t = i / FCD_S2_KROW;
+    const int m = (int)(t % Mpad); t /= Mpad;
+    const int h = (int)(t & 1), q = (int)(t >> 1);
+    float val = 0.f;
+    if (j < FCD_S2_KH) {
+      const int k = q * 8 + h * 4 + (j >> 2), u = (j >> 1) & 1, v = j & 1;
+      if (k < K && m < 4 * C) {
+        const int cls = m / C, c = m - cls * C, pi = cls >> 1, pj = cls & 1;
+        const int r = pi == 0 ? (u == 0 ? 1 : -1) : (u == 0 ? 2 : 0);
+        const int sx = pj == 0 ? (v == 0 ? 1 : -1) : (v == 0 ? 2 : 0);
+        if (r >= 0 && sx >= 0) val = w[(((int64_t)k * C + c) * 3 + r) * 3 + sx];
+      }
+    }
+    wt[i] = val;
+  }
+}
+
 extern "C" int fcd_conv_s2_dgrad_plan(const fcd_conv_desc* d) {
   static int on = -1;
   if (on < 0) {
@@ -1262,17 +1493,20 @@ extern "C" int fcd_conv_s2_dgrad_plan(const fcd_conv_desc* d) {
   return (on && d && d->R == 3 && d->S == 3 && d->stride == 2 && d->pad == 1 && d->C >= 8) ? 1 : 0;
 }
 
-extern "C" int64_t fcd_conv_s2_dgrad_packed_elems(int K, int C) {
-  return (int64_t)round_up(K, 8) * 4 * round_up(4 * C, 128);
-}
+static int64_t s2_rows_elems(int K, int C) { return (int64_t)round_up(K, 8) * 4 * round_up(4 * C, 128); }
+static int64_t s2_slab_elems(int K, int C) { return (int64_t)(round_up(K, 8) / 8) * 2 * round_up(4 * C, 128) * FCD_S2_KROW; }
+// [row layout of the register-staged kernel | slab layout of the LDS-DMA kernel]
+extern "C" int64_t fcd_conv_s2_dgrad_packed_elems(int K, int C) { return s2_rows_elems(K, C) + s2_slab_elems(K, C); }
 
 extern "C" int fcd_conv_s2_dgrad_pack(const float* w, float* wp, int K, int C, void* stream) {
   FCD_CHECK_ARG(w && wp && K > 0 && C > 0, "fcd_conv_s2_dgrad_pack: bad arguments");
-  const int64_t total = fcd_conv_s2_dgrad_packed_elems(K, C);
+  const int64_t total = s2_rows_elems(K, C), total_t = s2_slab_elems(K, C);
   const int grid = (int)std::min<int64_t>(cdiv64(total, 256), 4096);
-  FcdProfScope prof(FCD_K_PACK, (hipStream_t)stream, 0.0, 4.0 * total);
+  FcdProfScope prof(FCD_K_PACK, (hipStream_t)stream, 0.0, 4.0 * (total + total_t));
   hipLaunchKernelGGL(pack_weights_s2_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, wp, K, C,
                      round_up(4 * C, 128), total);
+  hipLaunchKernelGGL(pack_weights_s2t_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total_t, 256), 4096)), dim3(256), 0,
+                     (hipStream_t)stream, w, wp + total, K, C, round_up(4 * C, 128), total_t);
   FCD_LAUNCH_CHECK("pack_weights_s2");
   return FCD_OK;
 }
@@ -1293,6 +1527,24 @@ extern "C" int fcd_conv2d_bwd_data_s2(const fcd_conv_desc* d, const float* dy, c
   const double flops = 2.0 * d->N * d->K * (double)d->P * d->Q * d->C * 9;
   const double bytes = 4.0 * ((double)d->N * d->C * d->H * d->W + (double)d->N * d->K * d->P * d->Q + (double)d->K * d->C * 9);
   FcdProfScope prof(FCD_K_CONV_DGRAD, (hipStream_t)stream, flops, bytes, fcd_prof_tag_desc("dgrad_s2sub", d));
+  static int glds = -1;      // FCD_S2_GLDS=0: the register-staged kernel for every layer
+  if (glds < 0) { const char* e = getenv("FCD_S2_GLDS"); glds = (e && e[0] == '0') ? 0 : 1; }
+  if (glds && !relu_out && a.K > 64) {
+    a.wp = wp_s2 + s2_rows_elems(d->K, d->C);
+    a.nchunks = cdiv(a.C, 8);
+    const bool wide = a.Q > 16;
+    // (256-pixel tiles, each wave 64 x 128 at two workgroups per CU -- half the filter-slab DMA per MFMA: no change, 297 vs 297 us)
+    a.tiles_p = cdiv(a.P, wide ? 4 : 8);
+    a.tiles_q = cdiv(a.Q, wide ? 32 : 16);
+    a.k_tiles = cdiv(a.K, 128);
+    a.xcd_remap = xcd_remap_on();
+    const unsigned pix = (unsigned)(a.N * a.tiles_p * a.tiles_q);
+    const dim3 grid = a.xcd_remap ? dim3(pix * (unsigned)a.k_tiles) : dim3(pix, (unsigned)a.k_tiles);
+    if (wide) hipLaunchKernelGGL((conv_s2sub_glds_kernel<2, 2, 2, 2, 4, 32>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((conv_s2sub_glds_kernel<2, 2, 2, 2, 8, 16>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    FCD_LAUNCH_CHECK("conv2d_bwd_data_s2");
+    return FCD_OK;
+  }
   rc = conv_dispatch(a, 2, 2, 1, 1, (hipStream_t)stream);
   FCD_CHECK_ARG(rc == 0, "fcd_conv2d_bwd_data_s2: dispatch failed");
   FCD_LAUNCH_CHECK("conv2d_bwd_data_s2");

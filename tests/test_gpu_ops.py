@@ -43,6 +43,8 @@ CONV_CASES = [
     (3, 64, 24, 20, 128, 3, 2, 1),
     (2, 128, 19, 25, 256, 3, 2, 1),
     (2, 40, 18, 22, 48, 3, 2, 1),       # sub-pixel data gradient: phase blocks of 40 rows straddle the waves' 64-row tiles
+    (2, 24, 12, 80, 20, 3, 2, 1),       # ... its LDS-DMA kernel on a wide map (4 x 32 pixel tiles), last chunk of dy channels half full
+    (1, 72, 14, 70, 136, 3, 2, 1),      # ... three row tiles, odd output width, 17 chunks
     (2, 4, 32, 32, 64, 9, 1, 4),
     (1, 13, 24, 40, 64, 9, 1, 4),
     (2, 64, 24, 40, 13, 9, 1, 4),
