@@ -360,13 +360,13 @@ class Discriminator_SRGAN_simple(nn.Module):
             nn.AdaptiveAvgPool2d(1), nn.Conv2d(512, 1024, kernel_size=1), nn.LeakyReLU(0.2, inplace=True),
             nn.Conv2d(1024, 1, kernel_size=1))
 
-    def features(self, z, groups):
+    def features(self, z, groups, order=None):
         """Shared ``net`` on a batch made of ``groups`` independent calls (BN statistics
-        per call, running stats updated call by call)."""
+        per call, running stats updated call by call -- in the sequence ``order`` when given)."""
         s = self.net
         z = ops.bn_act(_conv(s[0], z), None, ops.ACT_LEAKY, slope_imm=0.2, groups=groups)
         for ci, bi in ((2, 3), (5, 6), (8, 9)):
-            z = ops.bn_act(_conv(s[ci], z), s[bi], ops.ACT_LEAKY, slope_imm=0.2, groups=groups)
+            z = ops.bn_act(_conv(s[ci], z), s[bi], ops.ACT_LEAKY, slope_imm=0.2, groups=groups, order=order)
         return z
 
     def classify(self, diff):
@@ -402,6 +402,27 @@ class Discriminator_SRGAN_simple(nn.Module):
         """Evaluate several (x, y) pairs in one batched pass; equivalent to calling
         ``forward`` on each pair in order (BN running stats see x1,y1,x2,y2,...)."""
         return self.forward_stacked(torch.cat([t for p in pairs for t in p], dim=0), len(pairs))
+
+    def forward_shared_first(self, z, nsecond):
+        """``[forward(x, y_1), ..., forward(x, y_k)]`` for ``z`` = cat([x, y_1, ..., y_k], dim=0): the reference's k calls with the SAME
+        first argument (Demo_RSSS.py:293,302: ``netD(x_mask, y_mask)``, ``netD(x_unc, y_unc)`` with x_unc == x_mask) run ``net`` on x
+        k times in train mode -- the same samples, weights and batch statistics, hence the same features.  Here x goes through
+        ``net`` once: its features feed every pair (autograd sums the k gradients before the one backward pass through ``net``,
+        which is what the k separate passes add up to), and the BatchNorm running statistics replay the reference's call order
+        x, y_1, x, y_2, ...  Falls back to ``forward_stacked`` on the repeated batch where that replay is not available (eval
+        mode, SyncBN)."""
+        k = int(nsecond)
+        if z.shape[0] % (k + 1):
+            raise ValueError('forward_shared_first: %d samples are not 1 + %d equal groups' % (z.shape[0], k))
+        n = z.shape[0] // (k + 1)
+        if not self.training or ops.sync_bn_active():
+            rep = torch.cat([t for i in range(k) for t in (z[:n], z[(i + 1) * n:(i + 2) * n])], dim=0)
+            return self.forward_stacked(rep, k)
+        order = [g for i in range(k) for g in (0, i + 1)]
+        with ops.batched_bn_counters():
+            f = self.features(z, groups=k + 1, order=order)
+            pairs = torch.cat([t for i in range(k) for t in (f[:n], f[(i + 1) * n:(i + 2) * n])], dim=0)
+            return self._classify_pairs(pairs, k)
 
     def forward_stacked(self, z, npairs):
         """``forward_pairs`` on the already batched tensor ``z`` = cat([x1, y1, x2, y2, ...], dim=0) (what

@@ -122,6 +122,8 @@ _SIGS = {
     'fcd_bn_act_ws_bytes': (c_size_t, [c_int, c_int]),
     'fcd_bn_act_fwd': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_float, c_float, c_int,
                                P, P, c_int, P, c_float, P, c_size_t, P]),
+    'fcd_bn_act_fwd_replay': (c_int, [P, P, c_int, c_int, c_int, c_int, P, c_int, P, P, P, P, c_float, c_float, P, P, c_int, P,
+                                      c_float, P, c_size_t, P]),
     'fcd_bn_act_bwd': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_float, c_int, P, P,
                                c_int, P, c_float, P, P, P, P, c_size_t, P]),
     'fcd_bn_act_fwd_parts': (c_int, [P, P, c_int, c_int, c_int, c_int, P, c_int, P, P, P, P, c_float, c_float, P, P, c_int, P, c_float,

@@ -682,10 +682,15 @@ def _sync_world():
     return 0
 
 
+def sync_bn_active():
+    """True when train-mode BatchNorm layers exchange their statistics across ranks right now."""
+    return bool(_sync_world())
+
+
 class _BnAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, slope, running_mean, running_var, training, momentum, eps, groups, act,
-                slope_imm):
+                slope_imm, order=None):
         x = _dev(x, 'bn input')
         N, C, H, W = x.shape
         has_bn = gamma is not None
@@ -699,7 +704,16 @@ class _BnAct(torch.autograd.Function):
         parts = getattr(x, '_fcd_bn', None) if (has_bn and training and not world) else None
         if parts is not None and (parts[3] != x.data_ptr() or parts[4] != x._version):
             parts = None
-        if parts is not None and parts[2] == groups and parts[1] > 0:
+        if order is not None:
+            # running statistics replayed in `order` (a group normalised once, counted as often as the reference calls the layer on it)
+            if not (has_bn and training) or world:
+                raise ValueError('bn_act(order=...): train-mode BatchNorm without SyncBN only')
+            arr = (ctypes.c_int * len(order))(*[int(g) for g in order])
+            check(lib.fcd_bn_act_fwd_replay(_p(x), _p(y), N, C, H * W, groups, arr, len(order), _p(gamma), _p(beta),
+                                            _p(running_mean), _p(running_var), float(momentum), float(eps), _p(save_mean),
+                                            _p(save_invstd), act, _p(slope), float(slope_imm), _p(ws), ws.numel(), _stream()),
+                  'fcd_bn_act_fwd_replay')
+        elif parts is not None and parts[2] == groups and parts[1] > 0:
             # the producing convolution's output transform already summed y and y^2 per workgroup (conv2d(bn_groups=...))
             check(lib.fcd_bn_act_fwd_parts(_p(x), _p(y), N, C, H * W, groups, _p(parts[0]), parts[1], _p(gamma), _p(beta),
                                            _p(running_mean), _p(running_var), float(momentum), float(eps), _p(save_mean),
@@ -760,7 +774,7 @@ class _BnAct(torch.autograd.Function):
             check(lib.fcd_bn_bwd_from_sums(_p(dz), _p(x), _p(dx), N, C, H * W, groups, _p(tot), count, _p(gamma),
                                            _p(beta), _p(save_mean), _p(save_invstd), act, _p(slope), slope_imm, _p(ws),
                                            ws.numel(), _stream()), 'fcd_bn_bwd_from_sums')
-            return dx, dgamma, dbeta, dslope, None, None, None, None, None, None, None, None
+            return dx, dgamma, dbeta, dslope, None, None, None, None, None, None, None, None, None
         if has_bn and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
             dgamma = _grad_out(gamma, (C,), x.device)
             dbeta = _grad_out(beta, (C,), x.device)
@@ -770,7 +784,7 @@ class _BnAct(torch.autograd.Function):
                                  _p(running_mean), _p(running_var), eps, int(training), _p(save_mean),
                                  _p(save_invstd), act, _p(slope), slope_imm, _p(dgamma), _p(dbeta), _p(dslope),
                                  _p(ws), ws.numel(), _stream()), 'fcd_bn_act_bwd')
-        return dx, dgamma, dbeta, dslope, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, dslope, None, None, None, None, None, None, None, None, None
 
 
 _COUNTERS = None
@@ -813,20 +827,26 @@ class batched_bn_counters:
         return False
 
 
-def bn_act(x, bn=None, act=ACT_NONE, slope=None, slope_imm=0.0, groups=1):
+def bn_act(x, bn=None, act=ACT_NONE, slope=None, slope_imm=0.0, groups=1, order=None):
     """y = act(BatchNorm(x)).  ``bn``: an nn.BatchNorm2d-like holder (weight, bias,
     running_mean, running_var, momentum, eps, training, num_batches_tracked) or
-    None for a bare activation.  ``slope``: PReLU weight tensor (1 element)."""
+    None for a bare activation.  ``slope``: PReLU weight tensor (1 element).
+    ``order``: train mode only -- the sequence of group indices whose statistics update the running buffers (repeats allowed;
+    default 0 .. groups - 1): a group the reference feeds to the layer twice is normalised once and counted twice."""
     if bn is None:
         return _BnAct.apply(x, None, None, slope, None, None, False, 0.0, 0.0, groups, act, slope_imm)
     training = bn.training or bn.running_mean is None
+    if order is not None and not (training and bn.running_mean is not None):
+        order = None
+    calls = len(order) if order is not None else groups
     if training and bn.track_running_stats and bn.num_batches_tracked is not None:
         if _COUNTERS is not None:
-            _COUNTERS.append((bn.num_batches_tracked, groups))      # one multi-tensor add at the end of the net's forward
+            _COUNTERS.append((bn.num_batches_tracked, calls))      # one multi-tensor add at the end of the net's forward
         else:
-            bn.num_batches_tracked += groups
+            bn.num_batches_tracked += calls
     return _BnAct.apply(x, bn.weight, bn.bias, slope, bn.running_mean, bn.running_var, training,
-                        bn.momentum if bn.momentum is not None else 0.1, bn.eps, groups, act, slope_imm)
+                        bn.momentum if bn.momentum is not None else 0.1, bn.eps, groups, act, slope_imm,
+                        tuple(order) if order is not None else None)
 
 
 # ------------------------------------------------ 1x1 head (one output channel + sigmoid)

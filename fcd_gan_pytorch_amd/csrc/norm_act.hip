@@ -80,16 +80,21 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
   }
 }
 
-// one thread per channel: finish stats for every group in order, update running stats
+// one thread per channel: finish stats for every group in order, update running stats.
+// [r5] norder > 0: the running statistics take the groups' updates in the order the 4-bit entries of order_code list (entry i =
+// bits 4 i .. 4 i + 3; a group may appear more than once) instead of 0 .. G - 1 once each: a net that was called twice on the SAME
+// samples in train mode (the Discriminator's shared first argument, Demo_RSSS.py:293,302) normalises them once here and still leaves
+// the running statistics the two calls would have left.
 __global__ void bn_finalize_kernel(const double* __restrict__ part, int C, int G, int split, double count,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ running_mean, float* __restrict__ running_var,
                                    float momentum, float eps, float* __restrict__ save_mean,
                                    float* __restrict__ save_invstd, float* __restrict__ scale,
-                                   float* __restrict__ shift) {
+                                   float* __restrict__ shift, unsigned long long order_code = 0ull, int norder = 0) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 1.f;
+  float gm[16], gu[16];          // replay only (G <= 16 there)
   for (int g = 0; g < G; ++g) {
     double s1 = 0.0, s2 = 0.0;
     const double* p = part + (size_t)(g * C + c) * split * 3;
@@ -108,8 +113,18 @@ __global__ void bn_finalize_kernel(const double* __restrict__ part, int C, int G
     scale[g * C + c] = sc;
     shift[g * C + c] = beta[c] - meanf * sc;
     const float unbiased = (float)(count > 1.0 ? var * count / (count - 1.0) : var);
-    rm = (1.f - momentum) * rm + momentum * meanf;
-    rv = (1.f - momentum) * rv + momentum * unbiased;
+    if (norder > 0) {
+      gm[g & 15] = meanf;
+      gu[g & 15] = unbiased;
+    } else {
+      rm = (1.f - momentum) * rm + momentum * meanf;
+      rv = (1.f - momentum) * rv + momentum * unbiased;
+    }
+  }
+  for (int i = 0; i < norder; ++i) {
+    const int g = (int)((order_code >> (4 * i)) & 15ull);
+    rm = (1.f - momentum) * rm + momentum * gm[g];
+    rv = (1.f - momentum) * rv + momentum * gu[g];
   }
   if (running_mean) running_mean[c] = rm;
   if (running_var) running_var[c] = rv;
@@ -169,11 +184,11 @@ static dim3 plane_grid(int planes, int HW) {
   return dim3((unsigned)planes, (unsigned)chunks);
 }
 
-extern "C" int fcd_bn_act_fwd(const float* x, float* y, int N, int C, int HW, int groups, int has_bn,
-                              const float* gamma, const float* beta, float* running_mean, float* running_var,
-                              float momentum, float eps, int training, float* save_mean, float* save_invstd,
-                              int act, const float* slope, float slope_imm, void* ws, size_t ws_bytes,
-                              void* stream) {
+static int bn_act_fwd_impl(const float* x, float* y, int N, int C, int HW, int groups, int has_bn,
+                           const float* gamma, const float* beta, float* running_mean, float* running_var,
+                           float momentum, float eps, int training, float* save_mean, float* save_invstd,
+                           int act, const float* slope, float slope_imm, void* ws, size_t ws_bytes,
+                           void* stream, unsigned long long order_code, int norder) {
   FCD_CHECK_ARG(x && y && N > 0 && C > 0 && HW > 0 && groups > 0 && N % groups == 0,
                 "fcd_bn_act_fwd: bad geometry N=%d C=%d HW=%d groups=%d", N, C, HW, groups);
   hipStream_t st = (hipStream_t)stream;
@@ -193,7 +208,7 @@ extern "C" int fcd_bn_act_fwd(const float* x, float* y, int N, int C, int HW, in
       hipLaunchKernelGGL(bn_stats_kernel, dim3(C, groups, split), dim3(256), 0, st, x, w.part, C, HW, Ng, split);
       hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, (const double*)w.part, C, groups,
                          split, (double)Ng * HW, gamma, beta, running_mean, running_var, momentum, eps, save_mean,
-                         save_invstd, w.scale, w.shift);
+                         save_invstd, w.scale, w.shift, order_code, norder);
     } else {
       FCD_CHECK_ARG(running_mean && running_var, "fcd_bn_act_fwd: eval needs running stats");
       hipLaunchKernelGGL(bn_eval_prep_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, C, groups, gamma, beta,
@@ -205,6 +220,31 @@ extern "C" int fcd_bn_act_fwd(const float* x, float* y, int N, int C, int HW, in
                      (const float*)w.scale, (const float*)w.shift, act, slope, slope_imm);
   FCD_LAUNCH_CHECK("bn_act_fwd");
   return FCD_OK;
+}
+
+extern "C" int fcd_bn_act_fwd(const float* x, float* y, int N, int C, int HW, int groups, int has_bn,
+                              const float* gamma, const float* beta, float* running_mean, float* running_var,
+                              float momentum, float eps, int training, float* save_mean, float* save_invstd,
+                              int act, const float* slope, float slope_imm, void* ws, size_t ws_bytes,
+                              void* stream) {
+  return bn_act_fwd_impl(x, y, N, C, HW, groups, has_bn, gamma, beta, running_mean, running_var, momentum, eps, training,
+                         save_mean, save_invstd, act, slope, slope_imm, ws, ws_bytes, stream, 0ull, 0);
+}
+
+// train-mode BatchNorm + activation whose running statistics replay the groups' updates in the order `order[0 .. norder)` (host
+// array of group indices, repeats allowed, <= 16 entries, groups <= 16)
+extern "C" int fcd_bn_act_fwd_replay(const float* x, float* y, int N, int C, int HW, int groups, const int* order, int norder,
+                                     const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                     float momentum, float eps, float* save_mean, float* save_invstd, int act,
+                                     const float* slope, float slope_imm, void* ws, size_t ws_bytes, void* stream) {
+  FCD_CHECK_ARG(order && norder > 0 && norder <= 16 && groups > 0 && groups <= 16, "fcd_bn_act_fwd_replay: 1 .. 16 groups / order entries");
+  unsigned long long code = 0ull;
+  for (int i = 0; i < norder; ++i) {
+    FCD_CHECK_ARG(order[i] >= 0 && order[i] < groups, "fcd_bn_act_fwd_replay: order[%d] = %d is not a group", i, order[i]);
+    code |= (unsigned long long)order[i] << (4 * i);
+  }
+  return bn_act_fwd_impl(x, y, N, C, HW, groups, 1, gamma, beta, running_mean, running_var, momentum, eps, 1, save_mean,
+                         save_invstd, act, slope, slope_imm, ws, ws_bytes, stream, code, norder);
 }
 
 __global__ void bn_train_prep_kernel(int C, int G, const float* __restrict__ gamma, const float* __restrict__ beta,

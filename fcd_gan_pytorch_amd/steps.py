@@ -144,7 +144,13 @@ def rsss_adversarial_step(netS, netD, netG, crit, optS, optD, x, y, region, perc
         if side is not None:
             side.wait_stream(main)              # cmap, y_unc are ready
         with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
-            c_out, nc_out = netD.forward_stacked(_masked_batch([x, y, x, y_unc], cmask.detach()), 2)
+            # x_unc == x (Demo_RSSS.py:297): both calls take the same masked x, which goes through D's net once
+            # (FCD_D_SHARE=0: twice, as a batch of four groups -- the round-4 form, for A/B runs)
+            import os
+            if os.environ.get('FCD_D_SHARE', '1') == '0':
+                c_out, nc_out = netD.forward_stacked(_masked_batch([x, y, x, y_unc], cmask.detach()), 2)
+            else:
+                c_out, nc_out = netD.forward_shared_first(_masked_batch([x, y, y_unc], cmask.detach()), 2)
             optD.zero_grad()
             d_loss = 1 + nc_out.mean() - c_out.mean()
             optD.begin_overlap(group)

@@ -262,6 +262,16 @@ int fcd_bn_act_fwd(const float* x, float* y, int N, int C, int HW, int groups, i
                    float momentum, float eps, int training, float* save_mean, float* save_invstd,
                    int act, const float* slope, float slope_imm, void* ws, size_t ws_bytes,
                    void* stream);
+/* [r5] Train-mode BatchNorm + activation as fcd_bn_act_fwd (has_bn = 1, training = 1), but the running statistics take the
+ * groups' momentum updates in the order order[0 .. norder) (HOST array of group indices; repeats allowed; groups, norder <= 16)
+ * instead of 0 .. groups - 1 once each.  For a net the reference calls twice on the SAME samples in one step
+ * (Discriminator_SRGAN_simple: x_mask is the first argument of both calls, Demo_RSSS.py:293,302 -> Module.py:220): the shared
+ * samples are normalised once, the running statistics end up as after the reference's four calls. */
+int fcd_bn_act_fwd_replay(const float* x, float* y, int N, int C, int HW, int groups, const int* order, int norder,
+                          const float* gamma, const float* beta, float* running_mean, float* running_var,
+                          float momentum, float eps, float* save_mean, float* save_invstd, int act,
+                          const float* slope, float slope_imm, void* ws, size_t ws_bytes, void* stream);
+
 size_t fcd_bn_act_ws_bytes(int C, int groups);
 /* Backward of the above.  dz: grad wrt the activated output.  Writes dx and
  * OVERWRITES dgamma/dbeta [C] (sum over groups) and dslope [1] when non-NULL. */
