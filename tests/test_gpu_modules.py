@@ -178,6 +178,37 @@ def test_module_vs_reference_fixture_and_oracle(tag):
                 assert int(v) == int(osd[k]), k
 
 
+def test_discriminator_shared_first_argument_equals_two_calls():
+    """``forward_shared_first`` (x through D's net once, Demo_RSSS.py:293,302) against the reference's two train-mode calls
+    ``netD(x, y1)``, ``netD(x, y2)`` on a second copy of the net: outputs, parameter gradients of ``1 + mean(out2) - mean(out1)``,
+    BatchNorm running statistics (the replayed order x, y1, x, y2) and batch counters."""
+    a, sd = build('D4_32', 4, 77)
+    b, _ = build('D4_32', 4, 77)
+    a.train(); b.train()
+    n = 3
+    x, y1, y2 = (probe_like((n, 4, 64, 48), 20 + i).to(DEV) for i in range(3))
+    o1, o2 = a.forward_shared_first(torch.cat([x, y1, y2], 0), 2)
+    (1 + o2.mean() - o1.mean()).backward()
+    r1 = b(x, y1)
+    r2 = b(x, y2)
+    (1 + r2.mean() - r1.mean()).backward()
+    assert (o1 - r1).abs().max().item() <= 2e-6 and (o2 - r2).abs().max().item() <= 2e-6
+    for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        if is_pre_bn_bias(k):
+            continue
+        grad_close(pa.grad, pb.grad, 'shared-first ' + k, l2_tol=2e-4, bad_frac=1e-3)
+    for (k, ba), (_, bb) in zip(a.named_buffers(), b.named_buffers()):
+        if k.endswith('num_batches_tracked'):
+            assert int(ba) == int(bb) == 4, k
+        else:
+            assert rel_err(ba, bb) <= 1e-6, (k, rel_err(ba, bb))
+    # eval mode takes the repeated batch (no replay there): same values as two plain calls
+    a.eval(); b.eval()
+    with torch.no_grad():
+        e1, e2 = a.forward_shared_first(torch.cat([x, y1, y2], 0), 2)
+        assert (e1 - b(x, y1)).abs().max().item() <= 2e-6 and (e2 - b(x, y2)).abs().max().item() <= 2e-6
+
+
 def test_binary_map_bit_exact_with_margin():
     """north_star: thresholded change map bit-exact.  Pixels whose density lies within
     the achieved error of the threshold are excluded (SURVEY.md section 7 'hard parts')."""
