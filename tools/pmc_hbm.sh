@@ -24,6 +24,7 @@ print(ctr, len(agg), 'kernels aggregated')
 PY
 find "$1" -name '*.csv' -delete
 }
+[ -x $ROOT/tools/hbm_calib.bin ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w $ROOT/tools/hbm_calib.hip -o $ROOT/tools/hbm_calib.bin   # (the binary is git-ignored)
 for pass in FETCH_SIZE WRITE_SIZE; do
   OUT=$ROOT/gpurun_out/pmc_calib_$pass; rm -rf $OUT; mkdir -p $OUT
   timeout 300 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $OUT -o c -- $ROOT/tools/hbm_calib.bin > $OUT/run.log 2>&1
