@@ -53,8 +53,18 @@ class DoubleConv(nn.Module):
             (w0, b0), (w1, b1) = self._folded_params()
             return ops.conv2d(ops.conv2d(x, w0, b0, 1, 1, relu=True), w1, b1, 1, 1, relu=True)
         g = groups if self.training else 0        # train-mode BatchNorm behind the conv: statistics out of its output transform
-        x = ops.bn_act(_conv(s[0], x, bn_groups=g), s[1], ops.ACT_RELU, groups=groups)
-        return ops.bn_act(_conv(s[3], x, bn_groups=g), s[4], ops.ACT_RELU, groups=groups)
+        return self._tail(_conv(s[0], x, bn_groups=g), groups, g)
+
+    def _tail(self, z, groups, g):
+        """BatchNorm -> ReLU -> conv -> BatchNorm -> ReLU behind the first convolution's output ``z``.  In train mode the first
+        BatchNorm + ReLU is applied by the second convolution's loader where that layer runs as F(4x4) (``ops.bn_relu_conv3x3``):
+        the activation between the two convolutions is never a tensor."""
+        s = self.double_conv
+        if ops.bn_relu_conv3x3_ok(z, s[1], s[3].weight, groups):
+            z = ops.bn_relu_conv3x3(z, s[1], s[3].weight, s[3].bias, groups=groups, bn_groups=g)
+        else:
+            z = _conv(s[3], ops.bn_act(z, s[1], ops.ACT_RELU, groups=groups), bn_groups=g)
+        return ops.bn_act(z, s[4], ops.ACT_RELU, groups=groups)
 
     def forward_pair_cat(self, f2n, up):
         """``forward(torch.cat([f2n[:n], f2n[n:], up], dim=1))`` with the first convolution reading the three tensors in
@@ -64,8 +74,7 @@ class DoubleConv(nn.Module):
             (w0, b0), (w1, b1) = self._folded_params()
             return ops.conv2d(ops.conv3x3_pair_cat(f2n, up, w0, b0, relu=True), w1, b1, 1, 1, relu=True)
         g = 1 if self.training else 0
-        x = ops.bn_act(ops.conv3x3_pair_cat(f2n, up, s[0].weight, s[0].bias, bn_groups=g), s[1], ops.ACT_RELU)
-        return ops.bn_act(_conv(s[3], x, bn_groups=g), s[4], ops.ACT_RELU)
+        return self._tail(ops.conv3x3_pair_cat(f2n, up, s[0].weight, s[0].bias, bn_groups=g), 1, g)
 
     def _folded_params(self):
         s = self.double_conv
@@ -106,6 +115,12 @@ class Down(nn.Module):
 
     def forward(self, x, groups=1):
         return self.maxpool_conv[1](ops.maxpool2(x), groups=groups)
+
+    def forward_skip(self, x, groups=1):
+        """``(x, forward(x))`` for an ``x`` that is also a skip connection: use the returned x for the skip (``ops.maxpool2_skip``:
+        the two gradients of x are summed inside the max-pool's backward kernel)."""
+        skip, pooled = ops.maxpool2_skip(x)
+        return skip, self.maxpool_conv[1](pooled, groups=groups)
 
 
 class Up(nn.Module):
@@ -248,10 +263,11 @@ class Segmentor(nn.Module):
     def _after_inc(self, f, n):
         # f: both temporal branches in one (2N, C, h, w) batch; the reference's skip tensor is cat([branch1, branch2], 1)
         # (Module.py:116-132) -- kept as the un-paired batch and read in place by the decoder's first convolutions
-        feats = [f]
+        feats = []
         for stage in (self.down1, self.down2, self.down3, self.down4):
-            f = stage(f, groups=2)
-            feats.append(f)
+            skip, f = stage.forward_skip(f, groups=2)      # skip IS f, as the output of the node that sums f's two gradients
+            feats.append(skip)
+        feats.append(f)
         x = self.up1.forward_pair(self._pair(feats[4], n), feats[3])
         x = self.up2.forward_pair(x, feats[2])
         x = self.up3.forward_pair(x, feats[1])

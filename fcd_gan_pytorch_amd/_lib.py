@@ -48,7 +48,8 @@ def kernel_source_hash():
 
 
 class WinoFwdExtras(Structure):
-    _fields_ = [('v_keep', c_void_p), ('bn_part', c_void_p), ('bn_groups', c_int32)]
+    _fields_ = [('v_keep', c_void_p), ('bn_part', c_void_p), ('bn_groups', c_int32), ('in_groups', c_int32),
+                ('in_scale', c_void_p), ('in_shift', c_void_p)]
 
 
 class ConvDesc(Structure):
@@ -81,6 +82,7 @@ _SIGS = {
     'fcd_conv2d_bwd_weight_bias_cat': (c_int, [P, P, P, c_int, P, P, P, P, P, c_size_t, P]),
     'fcd_conv_wino_ws_bytes': (c_size_t, [POINTER(ConvDesc), c_int]),
     'fcd_conv_wino_keepv_bytes': (c_size_t, [POINTER(ConvDesc)]),
+    'fcd_conv_wino_in_affine_ok': (c_int, [POINTER(ConvDesc)]),
     'fcd_conv_wino_bn_split': (c_int, [POINTER(ConvDesc), c_int]),
     'fcd_conv_wino_bn_part_bytes': (c_size_t, [POINTER(ConvDesc), c_int]),
     'fcd_conv2d_fwd_wino_x': (c_int, [POINTER(ConvDesc), P, P, P, P, c_int, P, P, P, c_size_t, P, P]),
@@ -126,6 +128,7 @@ _SIGS = {
                                       c_float, P, c_size_t, P]),
     'fcd_bn_act_bwd': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_float, c_int, P, P,
                                c_int, P, c_float, P, P, P, P, c_size_t, P]),
+    'fcd_bn_train_stats': (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, P, P, P, P, c_float, c_float, P, P, P, P, P, c_size_t, P]),
     'fcd_bn_act_fwd_parts': (c_int, [P, P, c_int, c_int, c_int, c_int, P, c_int, P, P, P, P, c_float, c_float, P, P, c_int, P, c_float,
                                      P, c_size_t, P]),
     'fcd_bn_partial_stats': (c_int, [P, P, c_int, c_int, c_int, c_int, P, c_size_t, P]),
@@ -136,6 +139,7 @@ _SIGS = {
                                      P, c_size_t, P]),
     'fcd_maxpool2_fwd': (c_int, [P, P, c_int, c_int, c_int, P]),
     'fcd_maxpool2_bwd': (c_int, [P, P, P, c_int, c_int, c_int, P]),
+    'fcd_maxpool2_bwd_add': (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
     'fcd_upsample2x_fwd': (c_int, [P, P, c_int, c_int, c_int, P]),
     'fcd_upsample2x_bwd': (c_int, [P, P, c_int, c_int, c_int, P]),
     'fcd_avgpool2_pad_fwd': (c_int, [P, P, c_int, c_int, c_int, P]),

@@ -787,6 +787,118 @@ class _BnAct(torch.autograd.Function):
         return dx, dgamma, dbeta, dslope, None, None, None, None, None, None, None, None, None
 
 
+# ------------------------------------------------ train-mode BatchNorm + ReLU applied by the NEXT convolution's loader
+class _BnReluConv2d(torch.autograd.Function):
+    """``conv3x3(relu(BatchNorm2d_train(z)), weight) + bias`` -- the middle of the reference's DoubleConv (Module.py:25-31:
+    Conv2d -> BatchNorm2d -> ReLU -> Conv2d) -- with the normalise + ReLU pass done by the F(4x4) input transform of the
+    convolution while it loads z (``fcd_wino_fwd_extras.in_scale / in_shift``): the activation is never written or read as a
+    tensor.  Forward: ``fcd_bn_train_stats`` (statistics from the producing convolution's partial sums when z carries them,
+    running-statistics update, scale / shift) + ``fcd_conv2d_fwd_wino_x``; the transformed input V stays for the weight
+    gradient.  Backward: the convolution's data gradient IS the BatchNorm + ReLU's incoming gradient -> ``fcd_bn_act_bwd``
+    on it and z.  Same kernels' arithmetic as ``conv2d(bn_act(z))``: bit-identical results (tests/test_gpu_ops.py)."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, running_mean, running_var, momentum, eps, groups, weight, bias, parts, bn_part, bn_groups):
+        z = _dev(z, 'bn input')
+        _dev(weight, 'conv weight')
+        N, C, H, W = z.shape
+        d = _desc(z.shape, weight.shape, 1, 1)
+        dev = z.device
+        save_mean = torch.empty(groups * C, dtype=torch.float32, device=dev)
+        save_invstd = torch.empty(groups * C, dtype=torch.float32, device=dev)
+        sc = torch.empty(2, groups * C, dtype=torch.float32, device=dev)
+        ws = _ws(lib.fcd_bn_act_ws_bytes(C, groups), dev)
+        check(lib.fcd_bn_train_stats(_p(z), N, C, H * W, groups, _p(parts[0]) if parts is not None else None,
+                                     parts[1] if parts is not None else 0, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+                                     float(momentum), float(eps), _p(save_mean), _p(save_invstd), _p(sc[0]), _p(sc[1]), _p(ws),
+                                     ws.numel(), _stream()), 'fcd_bn_train_stats')
+        if running_mean is not None:
+            torch._C._increment_version([running_mean, running_var])
+        y = torch.empty((d.N, d.K, d.P, d.Q), dtype=torch.float32, device=dev)
+        b = _dev(bias, 'conv bias') if bias is not None else None
+        vk = _keepv(d, ctx.needs_input_grad[8], dev)
+        ex = _lib.WinoFwdExtras(vk.data_ptr() if vk is not None else None, bn_part.data_ptr() if bn_part is not None else None,
+                                int(bn_groups), int(groups), sc[0].data_ptr(), sc[1].data_ptr())
+        wsc = _ws(lib.fcd_conv_wino_ws_bytes(ctypes.byref(d), 0), dev)
+        check(lib.fcd_conv2d_fwd_wino_x(ctypes.byref(d), _p(z), _p(wino_weight(weight, 0, 4)), _p(b), _p(y), 0, None, None, _p(wsc),
+                                        wsc.numel(), ctypes.byref(ex), _stream()), 'fcd_conv2d_fwd_wino_x')
+        if ctx.needs_input_grad[8] and vk is None:
+            raise _lib.FcdError('bn_relu_conv3x3: the layer keeps no transformed input for its weight gradient (check bn_relu_conv3x3_ok)')
+        ctx.save_for_backward(z, gamma, beta, save_mean, save_invstd, weight, vk)
+        ctx.cfg = (float(eps), int(groups), bias is not None)
+        ctx.bias_param = bias
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        z, gamma, beta, save_mean, save_invstd, weight, vk = ctx.saved_tensors
+        eps, groups, has_bias = ctx.cfg
+        dy = _dev(dy, 'conv grad')
+        N, C, H, W = z.shape
+        d = _desc(z.shape, weight.shape, 1, 1)
+        dev = dy.device
+        dz = dgamma = dbeta = dw = db = None
+        want_bn = ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        if want_bn:
+            da = torch.empty(z.shape, dtype=torch.float32, device=dev)      # gradient of the activation that was never stored
+            _bwd_data_conv(d, dy, weight, da)
+            dz = torch.empty_like(z)
+            if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+                dgamma = _grad_out(gamma, (C,), dev)
+                dbeta = _grad_out(beta, (C,), dev)
+            ws = _ws(lib.fcd_bn_act_ws_bytes(C, groups), dev)
+            check(lib.fcd_bn_act_bwd(_p(da), _p(z), _p(dz), N, C, H * W, groups, 1, _p(gamma), _p(beta), None, None, eps, 1,
+                                     _p(save_mean), _p(save_invstd), ACT_RELU, None, 0.0, _p(dgamma), _p(dbeta), None, _p(ws),
+                                     ws.numel(), _stream()), 'fcd_bn_act_bwd')
+            del da
+        want_db = has_bias and ctx.needs_input_grad[9]
+        if ctx.needs_input_grad[8]:
+            dw = _grad_out(weight, weight.shape, dev)
+            if want_db:
+                db = _grad_out(ctx.bias_param, (d.K,), dev)
+            ws = _ws(lib.fcd_conv2d_bwd_weight_ws_bytes(ctypes.byref(d)), dev)
+            check(lib.fcd_conv2d_bwd_weight_bias_v(ctypes.byref(d), _p(vk), _p(dy), None, _p(dw), _p(db), _p(ws), ws.numel(),
+                                                   _stream()), 'fcd_conv2d_bwd_weight_bias_v')
+        elif want_db:
+            db = _channel_sum(dy, None, d.N, d.K, d.P * d.Q)
+        return dz, dgamma, dbeta, None, None, None, None, None, dw, db, None, None, None
+
+
+def bn_relu_conv3x3_ok(z, bn, weight, groups=1):
+    """True when ``conv2d(bn_act(z, bn, ACT_RELU, groups=groups), weight, bias, 1, 1)`` can run as :func:`bn_relu_conv3x3`:
+    train-mode affine BatchNorm with per-replica statistics in front of a 3x3 / stride-1 / pad-1 layer whose forward runs as
+    F(4x4) through the rolling input transform and which keeps its transformed input for the weight gradient."""
+    if not (torch.is_tensor(z) and z.is_cuda and z.dim() == 4 and z.dtype == torch.float32):
+        return False
+    if not (bn.training or bn.running_mean is None) or bn.weight is None or bn.bias is None or _sync_world():
+        return False
+    if tuple(weight.shape[2:]) != (3, 3) or weight.shape[1] != z.shape[1] or z.shape[0] % groups:
+        return False
+    d = _desc(z.shape, weight.shape, 1, 1)
+    if lib.fcd_conv_wino2_plan(ctypes.byref(d), 0) or not lib.fcd_conv_wino_in_affine_ok(ctypes.byref(d)):
+        return False
+    return not (weight.requires_grad and torch.is_grad_enabled()) or lib.fcd_conv_wino_keepv_bytes(ctypes.byref(d)) > 0
+
+
+def bn_relu_conv3x3(z, bn, weight, bias=None, groups=1, bn_groups=0):
+    """``conv2d(bn_act(z, bn, ACT_RELU, groups=groups), weight, bias, 1, 1, bn_groups=bn_groups)`` without the activation tensor
+    (:class:`_BnReluConv2d`; check :func:`bn_relu_conv3x3_ok` first)."""
+    if bn.track_running_stats and bn.num_batches_tracked is not None:
+        if _COUNTERS is not None:
+            _COUNTERS.append((bn.num_batches_tracked, groups))
+        else:
+            bn.num_batches_tracked += groups
+    parts = getattr(z, '_fcd_bn', None)
+    if parts is not None and (parts[3] != z.data_ptr() or parts[4] != z._version or parts[2] != groups or parts[1] <= 0):
+        parts = None
+    d = _desc(z.shape, weight.shape, 1, 1)
+    part = _bn_part(d, bn_groups, False, z.device)
+    y = _BnReluConv2d.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                            bn.momentum if bn.momentum is not None else 0.1, bn.eps, int(groups), weight, bias,
+                            (parts[0], parts[1]) if parts is not None else None, part, int(bn_groups) if part is not None else 0)
+    return _tag_bn(y, d, part, bn_groups)
+
+
 _COUNTERS = None
 
 
@@ -926,6 +1038,47 @@ class _MaxPool2(torch.autograd.Function):
         dx = torch.empty_like(x)
         check(lib.fcd_maxpool2_bwd(_p(x), _p(dy), _p(dx), N * C, H, W, _stream()), 'fcd_maxpool2_bwd')
         return dx
+
+
+class _MaxPool2Skip(torch.autograd.Function):
+    """``(x, maxpool2(x))`` as ONE autograd node for a tensor with two consumers -- the U-Net skip connection: the encoder
+    feature feeds the next ``Down``'s MaxPool2d and, concatenated, the decoder (reference Module.py:116-132).  Autograd would
+    write the pooled path's routed gradient as a tensor and add the skip path's gradient to it in a pass of its own (read 2,
+    write 1 of the largest activations of the net); here both arrive at this node and ``fcd_maxpool2_bwd_add`` writes
+    skip gradient + routed gradient in one pass (in place over the skip gradient).  Same fp32 sum."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _dev(x, 'maxpool input')
+        N, C, H, W = x.shape
+        y = torch.empty((N, C, H // 2, W // 2), dtype=torch.float32, device=x.device)
+        check(lib.fcd_maxpool2_fwd(_p(x), _p(y), N * C, H, W, _stream()), 'fcd_maxpool2_fwd')
+        ctx.save_for_backward(x)
+        ctx.set_materialize_grads(False)
+        return x.view_as(x), y
+
+    @staticmethod
+    def backward(ctx, dskip, dy):
+        (x,) = ctx.saved_tensors
+        if dy is None:
+            return dskip
+        dy = _dev(dy, 'maxpool grad')
+        N, C, H, W = x.shape
+        if dskip is None:
+            dx = torch.empty_like(x)
+            check(lib.fcd_maxpool2_bwd(_p(x), _p(dy), _p(dx), N * C, H, W, _stream()), 'fcd_maxpool2_bwd')
+            return dx
+        dskip = _dev(dskip, 'skip grad')
+        # in place over the skip gradient when this node is its only holder (a fresh tensor out of the decoder's data gradient);
+        # a gradient somebody else may still read (retain_graph hooks, views) gets a buffer of its own
+        dx = dskip if (dskip._base is None and not dskip.requires_grad) else torch.empty_like(x)
+        check(lib.fcd_maxpool2_bwd_add(_p(x), _p(dy), _p(dskip), _p(dx), N * C, H, W, _stream()), 'fcd_maxpool2_bwd_add')
+        return dx
+
+
+def maxpool2_skip(x):
+    """``(x, maxpool2(x))``; use the FIRST result wherever x's other consumer would have read x (see :class:`_MaxPool2Skip`)."""
+    return _MaxPool2Skip.apply(x)
 
 
 def maxpool2(x):

@@ -90,6 +90,13 @@ struct WinoInArgs {
   int exp;                    // diagnostics (FCD_WINO_IN_EXP): 2 = no V stores, 4 = no source loads
   int xcd;                    // 1: blocks renumbered so that each XCD (own L2) walks a contiguous range
   WinoCat cat;                // plain source of the rolling kernel only: x = cat(cat.p[...]) (cat.n > 0)
+  // SRC 3 (rolling kernel only): x is the INPUT of a train-mode BatchNorm + ReLU whose only consumer is this convolution
+  // (reference Module.py:25-31: conv -> BN -> ReLU -> conv): the strip is normalised and rectified on its way into LDS,
+  // relu(x * aff_scale[(n / aff_ng) C + c] + aff_shift[...]) -- the arithmetic of bn_act_apply_kernel -- and the activation
+  // never exists as a tensor.  Padding stays zero (the affine map is applied to in-range elements only).
+  const float* aff_scale;
+  const float* aff_shift;
+  int aff_ng;
 };
 
 // Workgroups are handed to the 8 XCDs round-robin in launch order, so neighbouring strips of one plane --

@@ -291,7 +291,8 @@ __global__ __launch_bounds__(256) void wino_input_kernel(WinoInArgs a) {
 // transform and store phases of the one-strip kernel run back to back (measured: load + compute 0.86 ms, compute +
 // store 0.65 ms of a 1.42 ms launch), here they overlap inside the block as well as across blocks.
 template <int MM, int SRC, int TRB, int TWB>      // SRC 0 plain, 1 gated by the ReLU output `mask` (kept raw in registers too),
-                                                  // 2 pooled gradient + argmax codes (routed when the strip is written to LDS)
+                                                  // 2 pooled gradient + argmax codes (routed when the strip is written to LDS),
+                                                  // 3 [r5] BatchNorm + ReLU of the layer in front applied to the strip (WinoInArgs.aff_*)
 __global__ __launch_bounds__(256) void wino_input_roll_kernel(WinoInArgs a, int roll) {
   constexpr int A = WinoMat<MM>::A;
   constexpr int RH = TRB * MM + 2, CW = TWB * MM + 2;
@@ -321,7 +322,27 @@ __global__ __launch_bounds__(256) void wino_input_roll_kernel(WinoInArgs a, int 
   const int ty_beg = by * roll * TRB, ty_end = min(a.TH, ty_beg + roll * TRB);      // tile rows [ty_beg, ty_end), TRB per strip
 
   f32x4 pre[NV], msk[SRC == 1 ? NV : 1];
-  float preh[NH], mskh[SRC != 0 ? NH : 1];
+  float preh[NH], mskh[(SRC == 1 || SRC == 2) ? NH : 1];
+  // SRC 3: scale / shift of the BatchNorm in front, per strip item of this thread (the items' channels do not change with the strip)
+  float asc[SRC == 3 ? NV : 1], ash[SRC == 3 ? NV : 1], hsc[SRC == 3 ? NH : 1], hsh[SRC == 3 ? NH : 1];
+  if (SRC == 3) {
+    const float* scp = a.aff_scale + (size_t)(n / a.aff_ng) * a.C + q * 32;
+    const float* shp = a.aff_shift + (size_t)(n / a.aff_ng) * a.C + q * 32;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int c = min((tid + 256 * k) / (RH * V4), 31);
+      const bool in = q * 32 + c < a.C;
+      asc[k] = in ? scp[c] : 0.f;
+      ash[k] = in ? shp[c] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < NH; ++k) {
+      const int c = min((tid + 256 * k) / (RH * 2), 31);
+      const bool in = q * 32 + c < a.C;
+      hsc[k] = in ? scp[c] : 0.f;
+      hsh[k] = in ? shp[c] : 0.f;
+    }
+  }
   auto issue = [&](int ty) {
     const int ih0 = ty * MM - 1;
 #pragma unroll
@@ -385,7 +406,7 @@ __global__ __launch_bounds__(256) void wino_input_roll_kernel(WinoInArgs a, int 
         }
       }
       preh[k] = v;
-      if (SRC != 0) mskh[k] = m;
+      if (SRC == 1 || SRC == 2) mskh[k] = m;
     }
   };
   auto commit = [&](int ty) {
@@ -403,6 +424,14 @@ __global__ __launch_bounds__(256) void wino_input_roll_kernel(WinoInArgs a, int 
         t[1] = c0 == (rowbit | 1u) ? pre[k][0] : 0.f;
         t[2] = c1 == rowbit ? pre[k][1] : 0.f;
         t[3] = c1 == (rowbit | 1u) ? pre[k][1] : 0.f;
+      } else if (SRC == 3) {
+        const int ih = ty * MM - 1 + r, iw = iw0 + 1 + v4 * 4;
+        const bool in = q * 32 + c < a.C && ih >= 0 && ih < a.H && iw < a.W;      // zero padding is not normalised
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float y = fmaf(pre[k][e], asc[k], ash[k]);
+          t[e] = (in && y > 0.f) ? y : 0.f;
+        }
       } else {
         if (SRC == 1 && a.mbits) {
           const unsigned wv = __float_as_uint(msk[k][0]) >> (4 * ((ty * MM - 1 + r) & 3));
@@ -423,8 +452,13 @@ __global__ __launch_bounds__(256) void wino_input_roll_kernel(WinoInArgs a, int 
       if (SRC == 1 && a.mbits) {
         const unsigned bit = (__float_as_uint(mskh[k]) >> (4 * ((ty * MM - 1 + r) & 3) + ((iw0 + col) & 3))) & 1u;
         tile[c * PL + r * CW + col] = bit ? preh[k] : 0.f;
+      } else if (SRC == 3) {
+        const int ih = ty * MM - 1 + r, iw = iw0 + col;
+        const bool in = q * 32 + c < a.C && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+        const float y = fmaf(preh[k], hsc[k], hsh[k]);
+        tile[c * PL + r * CW + col] = (in && y > 0.f) ? y : 0.f;
       } else {
-        tile[c * PL + r * CW + col] = (SRC != 0 && !(mskh[k] > 0.f)) ? 0.f : preh[k];
+        tile[c * PL + r * CW + col] = ((SRC == 1 || SRC == 2) && !(mskh[k] > 0.f)) ? 0.f : preh[k];
       }
     }
   };
@@ -1709,11 +1743,15 @@ static void wino_launch_input(const WinoInArgs& ia, int src, hipStream_t st) {
 #define WINO_ROLL(SRC_, TRB_) hipLaunchKernelGGL((wino_input_roll_kernel<MM, SRC_, TRB_, NT / TRB_>), grid, dim3(256), 0, st, ia, r)
       if (src == 0) { if (trb == 1) WINO_ROLL(0, 1); else WINO_ROLL(0, 2); }
       else if (src == 1) { if (trb == 1) WINO_ROLL(1, 1); else WINO_ROLL(1, 2); }
+      else if (src == 3) {
+        if constexpr (MM == 4) { if (trb == 1) WINO_ROLL(3, 1); else WINO_ROLL(3, 2); }
+      }
       else { if (trb == 1) WINO_ROLL(2, 1); else WINO_ROLL(2, 2); }
 #undef WINO_ROLL
       return;
     }
   }
+  if (src == 3) return;      // callers check wino_cat_input_ok (the rolling kernel's geometry) first: never reached
   if (ia.TW > NT / 2 && (ia.exp & 1)) wino_launch_input_cfg<MM, 1, NT / 2>(ia, src, st);
   else if (ia.TW > NT / 2) wino_launch_input_cfg<MM, 1, NT>(ia, src, st);
   else if (ia.TW > NT / 4) wino_launch_input_cfg<MM, 2, NT / 2>(ia, src, st);
@@ -1745,6 +1783,7 @@ static bool wino_blk_path(const WinoPlan& pl) {
 struct WinoInSrc {
   const float* src; const float* mask; const unsigned short* mask_bits; const unsigned char* code; int Hp, Wp;
   const WinoCat* cat;
+  const float* aff_scale; const float* aff_shift; int aff_ng;      // BatchNorm + ReLU in front, applied by the loader (SRC 3)
 };
 static void wino_stage_input(const WinoPlan& pl, int N, int in_ch, int H, int W, const WinoInSrc& in, float* V, hipStream_t st) {
   WinoInArgs ia;
@@ -1753,7 +1792,8 @@ static void wino_stage_input(const WinoPlan& pl, int N, int in_ch, int H, int W,
   ia.x = in.src; ia.mask = in.mask; ia.mbits = in.mask_bits; ia.code = in.code; ia.V = V;
   ia.N = N; ia.C = in_ch; ia.H = H; ia.W = W; ia.Hp = in.Hp; ia.Wp = in.Wp;
   ia.TH = pl.TH; ia.TW = pl.TW; ia.Q = pl.Q; ia.T = pl.T;
-  const int srcmode = in.code ? 2 : ((in.mask || in.mask_bits) ? 1 : 0);
+  const int srcmode = in.aff_scale ? 3 : (in.code ? 2 : ((in.mask || in.mask_bits) ? 1 : 0));
+  ia.aff_scale = in.aff_scale; ia.aff_shift = in.aff_shift; ia.aff_ng = in.aff_ng > 0 ? in.aff_ng : 1;
   {
     static int exp = -1;
     if (exp < 0) { const char* e = getenv("FCD_WINO_IN_EXP"); exp = e ? atoi(e) : 0; }
@@ -1825,10 +1865,11 @@ static int wino_run(const WinoPlan& pl, int N, int in_ch, int H, int W, const fl
                     float* pool_y, unsigned char* code_out, void* ws, hipStream_t st,
                     const WinoCat* in_cat = nullptr, const WinoCat* out_cat = nullptr, float* v_keep = nullptr,
                     const unsigned short* mask_bits = nullptr, unsigned short* relu_bits_out = nullptr,
-                    double* bn_part = nullptr, int bn_bpg = 0) {
+                    double* bn_part = nullptr, int bn_bpg = 0, const float* aff_scale = nullptr, const float* aff_shift = nullptr,
+                    int aff_ng = 0) {
   float* V = v_keep ? v_keep : (float*)ws;       // v_keep: the caller keeps the transformed input for the weight gradient
   float* Mb = (float*)((char*)ws + ((pl.v_bytes + 255) & ~(size_t)255));
-  const WinoInSrc in = {src, mask, mask_bits, code_in, Hp, Wp, in_cat};
+  const WinoInSrc in = {src, mask, mask_bits, code_in, Hp, Wp, in_cat, aff_scale, aff_shift, aff_ng};
   wino_stage_input(pl, N, in_ch, H, W, in, V, st);
   const WinoGemmArgs ga = wino_stage_gemm(pl, U, V, Mb, N, H, W, st);
   const WinoOutDst out = {bias, relu, y, pool_y, code_out, out_cat, relu_bits_out, nullptr, bn_part, bn_bpg};
@@ -1884,13 +1925,28 @@ extern "C" size_t fcd_conv_wino_bn_part_bytes(const fcd_conv_desc* d, int groups
   return (size_t)fcd_conv_wino_bn_split(d, groups) * groups * d->K * 3 * sizeof(double);
 }
 
+// 1: the forward call of this layer can apply the train-mode BatchNorm + ReLU in front of it while loading x
+// (fcd_wino_fwd_extras.in_scale / in_shift): F(4x4) plan whose input goes through the rolling transform kernel
+extern "C" int fcd_conv_wino_in_affine_ok(const fcd_conv_desc* d) {
+  WinoPlan pl;
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("FCD_BN_FUSE"); on = (e && e[0] == '0') ? 0 : 1; }
+  if (!d || !on || !wino_plan(d, 0, &pl)) return 0;
+  if (getenv("FCD_WINO_IN_ROLL") && atoi(getenv("FCD_WINO_IN_ROLL")) <= 1) return 0;
+  return wino_cat_input_ok(pl, d->W) ? 1 : 0;
+}
+
 extern "C" int fcd_conv2d_fwd_wino_x(const fcd_conv_desc* d, const float* x, const float* U, const float* bias, float* y,
                                      int fuse_relu, float* pool_y, unsigned char* code, void* ws, size_t ws_bytes,
                                      const fcd_wino_fwd_extras* ex, void* stream) {
   float* v_keep = ex ? ex->v_keep : nullptr;
   double* bn_part = ex ? ex->bn_part : nullptr;
   const int bn_bpg = bn_part ? fcd_conv_wino_bn_split(d, ex->bn_groups) : 0;
+  const float* in_scale = ex ? ex->in_scale : nullptr;
+  const float* in_shift = ex ? ex->in_shift : nullptr;
   FCD_CHECK_ARG(d && x && U && (y || (pool_y && code)), "fcd_conv2d_fwd_wino: null pointer");
+  FCD_CHECK_ARG(!in_scale || (in_shift && ex->in_groups > 0 && d->N % ex->in_groups == 0 && fcd_conv_wino_in_affine_ok(d)),
+                "fcd_conv2d_fwd_wino_x: in_scale needs in_shift, in_groups | N and fcd_conv_wino_in_affine_ok(d)");
   FCD_CHECK_ARG(!bn_part || (bn_bpg > 0 && !pool_y && !fuse_relu), "fcd_conv2d_fwd_wino_x: BatchNorm partial sums not available for this call "
                 "(fcd_conv_wino_bn_split(d, groups) == 0, or a fused ReLU / pool in front of the BatchNorm)");
   FCD_CHECK_ARG(!v_keep || fcd_conv_wino_keepv_bytes(d) > 0, "fcd_conv2d_fwd_wino_keepv: fcd_conv_wino_keepv_bytes(d) == 0 for this layer");
@@ -1902,7 +1958,8 @@ extern "C" int fcd_conv2d_fwd_wino_x(const fcd_conv_desc* d, const float* x, con
   }
   FcdProfScope prof(FCD_K_WINO_FWD, (hipStream_t)stream, conv_flops(d), wino_bytes(pl), fcd_prof_tag_desc("wino_fwd", d));
   wino_run(pl, d->N, d->C, d->H, d->W, x, nullptr, nullptr, 0, 0, U, bias, (fuse_relu || pool_y) ? 1 : 0,
-           pool_y ? nullptr : y, pool_y, code, ws, (hipStream_t)stream, nullptr, nullptr, v_keep, nullptr, nullptr, bn_part, bn_bpg);
+           pool_y ? nullptr : y, pool_y, code, ws, (hipStream_t)stream, nullptr, nullptr, v_keep, nullptr, nullptr, bn_part, bn_bpg,
+           in_scale, in_shift, in_scale ? d->N / ex->in_groups : 0);
   FCD_LAUNCH_CHECK("conv2d_fwd_wino");
   return FCD_OK;
 }

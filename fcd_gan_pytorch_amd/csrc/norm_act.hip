@@ -602,6 +602,37 @@ extern "C" int fcd_bn_act_fwd_parts(const float* x, float* y, int N, int C, int 
   return FCD_OK;
 }
 
+// [r5] train-mode statistics of a BatchNorm whose normalise + activate pass is done by its CONSUMER's loader (the F(4x4) input
+// transform of the next convolution, fcd_wino_fwd_extras.in_scale / in_shift; reference Module.py:25-31): finalises mean / invstd, updates
+// the running statistics and leaves scale = gamma * invstd, shift = beta - mean * scale per (group, channel) in caller-owned buffers --
+// everything fcd_bn_act_fwd does except the pass over x.  `part` / `split`: the producing convolution's partial sums as in
+// fcd_bn_act_fwd_parts, or NULL / 0 (the statistics kernel reads x).
+extern "C" int fcd_bn_train_stats(const float* x, int N, int C, int HW, int groups, const double* part, int split, const float* gamma,
+                                  const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                                  float* save_mean, float* save_invstd, float* scale, float* shift, void* ws, size_t ws_bytes,
+                                  void* stream) {
+  FCD_CHECK_ARG((x || part) && N > 0 && C > 0 && HW > 0 && groups > 0 && N % groups == 0 && gamma && beta && save_mean && save_invstd &&
+                    scale && shift && (!part || split > 0),
+                "fcd_bn_train_stats: bad arguments");
+  if (!ws || ws_bytes < fcd_bn_act_ws_bytes(C, groups)) {
+    fcd_set_error("fcd_bn_train_stats: workspace too small");
+    return FCD_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  BnWs w = carve(ws, C, groups);
+  const int Ng = N / groups;
+  FcdProfScope prof(FCD_K_NORM, st, 0.0, part ? 0.0 : 4.0 * N * C * (double)HW);
+  if (!part) {
+    split = pick_split(C, groups, (long long)Ng * HW);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(C, groups, split), dim3(256), 0, st, x, w.part, C, HW, Ng, split);
+    part = w.part;
+  }
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, part, C, groups, split, (double)Ng * HW, gamma,
+                     beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, scale, shift);
+  FCD_LAUNCH_CHECK("bn_train_stats");
+  return FCD_OK;
+}
+
 extern "C" int fcd_bn_bwd_partial(const float* dz, const float* x, double* out, int N, int C, int HW, int groups,
                                   const float* gamma, const float* beta, const float* save_mean,
                                   const float* save_invstd, int act, const float* slope, float slope_imm, void* ws,

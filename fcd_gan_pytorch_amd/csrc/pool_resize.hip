@@ -46,8 +46,11 @@ __global__ void maxpool2_fwd_scalar_kernel(const float* __restrict__ x, float* _
 }
 
 // one thread per 2x2 input window (plus edge cells): recompute the argmax, route dy
+// `add` != NULL: dx = add + routed gradient -- the gradient a SECOND consumer of x (the decoder's skip connection, reference
+// Module.py:116-132) has already produced, summed here instead of by a three-pass add of its own
 __global__ void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                    float* __restrict__ dx, int NC, int H, int W, int P, int Q) {
+                                    float* __restrict__ dx, int NC, int H, int W, int P, int Q,
+                                    const float* __restrict__ add = nullptr) {
   const int PH = (H + 1) / 2, PW = (W + 1) / 2;  // cover trailing odd row/col with zero windows
   const long long total = (long long)NC * PH * PW;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -65,16 +68,27 @@ __global__ void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __
       if (v10 > m || v10 != v10) { m = v10; arg = 2; }
       if (v11 > m || v11 != v11) { m = v11; arg = 3; }
       const float g = dy[(pl * P + p) * Q + q];
-      dx[base] = arg == 0 ? g : 0.f;
-      dx[base + 1] = arg == 1 ? g : 0.f;
-      dx[base + W] = arg == 2 ? g : 0.f;
-      dx[base + W + 1] = arg == 3 ? g : 0.f;
+      if (add) {
+        const float a00 = add[base], a01 = add[base + 1], a10 = add[base + W], a11 = add[base + W + 1];
+        dx[base] = a00 + (arg == 0 ? g : 0.f);
+        dx[base + 1] = a01 + (arg == 1 ? g : 0.f);
+        dx[base + W] = a10 + (arg == 2 ? g : 0.f);
+        dx[base + W + 1] = a11 + (arg == 3 ? g : 0.f);
+      } else {
+        dx[base] = arg == 0 ? g : 0.f;
+        dx[base + 1] = arg == 1 ? g : 0.f;
+        dx[base + W] = arg == 2 ? g : 0.f;
+        dx[base + W + 1] = arg == 3 ? g : 0.f;
+      }
     } else {
       // trailing odd row / column never pooled: zero gradient
       const int h = 2 * p, w = 2 * q;
       for (int a = 0; a < 2; ++a)
         for (int b = 0; b < 2; ++b)
-          if (h + a < H && w + b < W) dx[(pl * H + h + a) * W + w + b] = 0.f;
+          if (h + a < H && w + b < W) {
+            const long long o = (pl * H + h + a) * W + w + b;
+            dx[o] = add ? add[o] + 0.f : 0.f;
+          }
     }
   }
 }
@@ -106,6 +120,20 @@ extern "C" int fcd_maxpool2_bwd(const float* x, const float* dy, float* dx, int 
   hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, NC, H,
                      W, P, Q);
   FCD_LAUNCH_CHECK("maxpool2_bwd");
+  return FCD_OK;
+}
+
+// dx = add + maxpool2 backward(x, dy): the pooled path's gradient summed onto the gradient `add` that the other consumer of x
+// produced (U-Net skip connection: x feeds MaxPool2d and, concatenated, the decoder -- reference Module.py:116-132).  One pass
+// instead of the routed tensor + a separate three-pass add; add + routed in fp32, the value torch's accumulation gives.  dx may be add.
+extern "C" int fcd_maxpool2_bwd_add(const float* x, const float* dy, const float* add, float* dx, int NC, int H, int W, void* stream) {
+  FCD_CHECK_ARG(x && dy && add && dx && NC > 0 && H >= 2 && W >= 2, "fcd_maxpool2_bwd_add: bad arguments");
+  const int P = H / 2, Q = W / 2;
+  const long long total = (long long)NC * ((H + 1) / 2) * ((W + 1) / 2);
+  FcdProfScope prof(FCD_K_POOL, (hipStream_t)stream, 0.0, 4.0 * NC * (3.0 * H * W + (double)P * Q));
+  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, NC, H,
+                     W, P, Q, add);
+  FCD_LAUNCH_CHECK("maxpool2_bwd_add");
   return FCD_OK;
 }
 

@@ -153,12 +153,20 @@ int fcd_conv2d_bwd_weight_bias_cat(const fcd_conv_desc* d, const float* const* s
  *   bn_part  per-workgroup {sum y, sum y^2} of every output channel and BatchNorm sample group -- the statistics pass of the
  *            BatchNorm2d that follows the convolution (reference Module.py:25-31, 177-181) done by the output transform while
  *            y is in registers; hand it to fcd_bn_act_fwd_parts.  Layout [(g K + k) split + s][3] doubles with
- *            split = fcd_conv_wino_bn_split(d, groups) (0: not available for this layer / grouping), no fused ReLU. */
+ *            split = fcd_conv_wino_bn_split(d, groups) (0: not available for this layer / grouping), no fused ReLU.
+ *   in_scale / in_shift / in_groups   [r5] x is the INPUT of a train-mode BatchNorm2d + ReLU whose only consumer is this convolution
+ *            (the middle of reference Module.py:25-31 DoubleConv): the input transform computes relu(x * in_scale[(n / (N / in_groups)) C + c]
+ *            + in_shift[...]) while loading -- the arithmetic of fcd_bn_act_fwd's apply pass, bit for bit -- and the activation is never
+ *            written.  scale / shift come from fcd_bn_train_stats; allowed when fcd_conv_wino_in_affine_ok(d). */
 typedef struct fcd_wino_fwd_extras {
   float* v_keep;
   double* bn_part;
   int32_t bn_groups;
+  int32_t in_groups;
+  const float* in_scale;
+  const float* in_shift;
 } fcd_wino_fwd_extras;
+int fcd_conv_wino_in_affine_ok(const fcd_conv_desc* d);
 int fcd_conv_wino_bn_split(const fcd_conv_desc* d, int groups);
 size_t fcd_conv_wino_bn_part_bytes(const fcd_conv_desc* d, int groups);
 int fcd_conv2d_fwd_wino_x(const fcd_conv_desc* d, const float* x, const float* U, const float* bias, float* y, int fuse_relu,
@@ -302,6 +310,13 @@ int fcd_bn_act_fwd_parts(const float* x, float* y, int N, int C, int HW, int gro
                          const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
                          float eps, float* save_mean, float* save_invstd, int act, const float* slope, float slope_imm,
                          void* ws, size_t ws_bytes, void* stream);
+/* [r5] the statistics half of a train-mode BatchNorm2d whose normalise + ReLU pass is done by the NEXT convolution's loader
+ * (fcd_wino_fwd_extras.in_scale / in_shift; reference Module.py:25-31): mean / invstd saved, running statistics updated, scale =
+ * gamma * invstd and shift = beta - mean * scale written per (group, channel).  part / split as in fcd_bn_act_fwd_parts, or NULL / 0
+ * (x is read once).  The backward pass is fcd_bn_act_bwd on the convolution's data gradient and the same x. */
+int fcd_bn_train_stats(const float* x, int N, int C, int HW, int groups, const double* part, int split, const float* gamma,
+                       const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* save_mean,
+                       float* save_invstd, float* scale, float* shift, void* ws, size_t ws_bytes, void* stream);
 int fcd_bn_bwd_partial(const float* dz, const float* x, double* out, int N, int C, int HW,
                        int groups, const float* gamma, const float* beta, const float* save_mean,
                        const float* save_invstd, int act, const float* slope, float slope_imm,
@@ -318,6 +333,9 @@ int fcd_bn_bwd_from_sums(const float* dz, const float* x, float* dx, int N, int 
  * ssim.py:213-215; nn.AdaptiveAvgPool2d(1) Module.py:211. */
 int fcd_maxpool2_fwd(const float* x, float* y, int NC, int H, int W, void* stream);
 int fcd_maxpool2_bwd(const float* x, const float* dy, float* dx, int NC, int H, int W, void* stream);
+/* [r5] dx = add + maxpool2 backward: x has a second consumer (the decoder's skip connection, reference Module.py:116-132) whose
+ * gradient `add` is summed in the same pass (dx may alias add) */
+int fcd_maxpool2_bwd_add(const float* x, const float* dy, const float* add, float* dx, int NC, int H, int W, void* stream);
 int fcd_upsample2x_fwd(const float* x, float* y, int NC, int H, int W, void* stream);
 int fcd_upsample2x_bwd(const float* dy, float* dx, int NC, int H, int W, void* stream);
 int fcd_avgpool2_pad_fwd(const float* x, float* y, int NC, int H, int W, void* stream);

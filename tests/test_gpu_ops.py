@@ -620,6 +620,85 @@ def test_bn_statistics_from_the_output_transform(case, monkeypatch):
         assert err < 2e-6, (what, err)
 
 
+@pytest.mark.parametrize('tagged', [False, True])
+@pytest.mark.parametrize('case', [(4, 128, 32, 32, 128, 2), (2, 128, 64, 64, 256, 1), (2, 96, 40, 36, 128, 2), (3, 256, 24, 72, 128, 1),
+                                  (2, 128, 128, 128, 128, 1), (4, 64, 64, 64, 128, 2)], ids=lambda c: 'x'.join(map(str, c)))
+def test_bn_relu_applied_by_the_next_convolutions_loader(case, tagged):
+    """Conv2d -> BatchNorm2d(train) -> ReLU -> Conv2d (reference Module.py:25-31, the middle of DoubleConv): ``ops.bn_relu_conv3x3``
+    -- the BatchNorm + ReLU pass done by the F(4x4) input transform of the second convolution, the activation never written --
+    against ``conv2d(bn_act(z))``.  The loader computes what the apply kernel computes (fma, compare), padding stays zero, the
+    backward pass runs the same kernels on the same operands: outputs, all gradients (z, gamma, beta, filter, bias), running
+    statistics and the partial sums for the BatchNorm behind must be BIT-identical.  ``tagged``: z comes out of a convolution
+    whose output transform summed the statistics (Siamese sample groups included); ragged channel chunk and odd tile counts in
+    the cases."""
+    ops = _ops()
+    N, C, H, W, K, G = case
+    zsrc = rnd(N, C, H, W, seed=101)
+    w0 = rnd(C, C, 3, 3, seed=100, scale=(2.0 / (C * 9)) ** 0.5)
+    w = rnd(K, C, 3, 3, seed=102, scale=(2.0 / (C * 9)) ** 0.5)
+    b = rnd(K, seed=103, scale=0.1)
+    g = rnd(N, K, H, W, seed=104)
+    res = {}
+    for tag in ('fused', 'separate'):
+        bn = torch.nn.BatchNorm2d(C).cuda().train()
+        with torch.no_grad():
+            bn.weight.copy_(rnd(C, seed=105).cuda() * 0.2 + 1.0)
+            bn.bias.copy_(rnd(C, seed=106).cuda() * 0.1)
+        zin = zsrc.cuda().requires_grad_(True)
+        wg, bg = (t.cuda().requires_grad_(True) for t in (w, b))
+        if tagged:
+            z = ops.conv2d(zin, w0.cuda(), None, 1, 1, bn_groups=G)
+            if getattr(z, '_fcd_bn', None) is None:
+                pytest.skip('no statistics from the producing layer at this shape')
+        else:
+            z = zin * 1.0
+        if tag == 'fused':
+            if not ops.bn_relu_conv3x3_ok(z, bn, wg, G):
+                pytest.skip('layer does not take the fused loader')
+            y = ops.bn_relu_conv3x3(z, bn, wg, bg, groups=G, bn_groups=G)
+        else:
+            y = ops.conv2d(ops.bn_act(z, bn, ops.ACT_RELU, groups=G), wg, bg, 1, 1, bn_groups=G)
+        part = getattr(y, '_fcd_bn', None)
+        y.backward(g.cuda())
+        res[tag] = [t.detach().cpu() for t in (y, zin.grad, wg.grad, bg.grad, bn.weight.grad, bn.bias.grad, bn.running_mean,
+                                               bn.running_var)] + ([part[0].view(-1, 3)[:, :2].cpu()] if part is not None else [])   # {sum, sum of squares, unused}
+        assert int(bn.num_batches_tracked) == G
+    assert len(res['fused']) == len(res['separate'])
+    for a, r, what in zip(res['fused'], res['separate'], ('y', 'dz', 'dw', 'db', 'dgamma', 'dbeta', 'running_mean', 'running_var', 'bn_part')):
+        assert torch.equal(a, r), (what, (a.double() - r.double()).abs().max().item())
+
+
+@pytest.mark.parametrize('shape', [(2, 3, 8, 8), (1, 5, 11, 13), (2, 4, 27, 55), (3, 16, 64, 64), (1, 2, 2, 2)], ids=lambda c: 'x'.join(map(str, c)))
+@pytest.mark.parametrize('use', ['both', 'skip_only', 'pool_only'])
+def test_maxpool_with_a_skip_consumer_sums_both_gradients_in_one_pass(shape, use):
+    """U-Net skip connection (reference Module.py:116-132): the encoder feature feeds MaxPool2d and the decoder.  ``ops.maxpool2_skip``
+    returns (x, pooled) from ONE node whose backward writes skip gradient + routed pooled gradient in a single kernel
+    (fcd_maxpool2_bwd_add); the result must equal autograd's accumulation over ``maxpool2(x)`` and x bit for bit, odd trailing
+    rows / columns and unused outputs included."""
+    ops = _ops()
+    x0 = rnd(*shape, seed=111)
+    gs = rnd(*shape, seed=112).cuda()
+    gp = rnd(shape[0], shape[1], shape[2] // 2, shape[3] // 2, seed=113).cuda()
+    out = {}
+    for tag in ('fused', 'plain'):
+        x = x0.cuda().requires_grad_(True)
+        h = x * 1.0
+        if tag == 'fused':
+            skip, pooled = ops.maxpool2_skip(h)
+        else:
+            skip, pooled = h, ops.maxpool2(h)
+        loss = 0.0
+        if use != 'pool_only':
+            loss = loss + (skip * gs).sum()
+        if use != 'skip_only':
+            loss = loss + (pooled * gp).sum()
+        loss.backward()
+        out[tag] = (x.grad.cpu(), skip.detach().cpu(), pooled.detach().cpu())
+    for a, r, what in zip(out['fused'], out['plain'], ('dx', 'skip', 'pooled')):
+        assert torch.equal(a, r), what
+    assert torch.equal(out['fused'][1], x0)
+
+
 def _split_modes_conv(ops, x, w, b):
     """y of the 3x3 layer with the F(4x4) GEMMs on the fp32 matrix pipe (mode 0) and on the two split-bf16 kernels."""
     lib = ops.lib

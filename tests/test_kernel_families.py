@@ -38,7 +38,7 @@ def test_no_convolution_kernel_is_left_out():
     """Every kernel of the convolution sources belongs to a family, except the filter packers (their own bench family) and the
     lab-only GEMM variant; a new kernel must be added to the map (or here) before the traffic figures mean anything."""
     not_in_a_traffic_family = {
-        'pack_weights_kernel', 'pack_weights_s2_kernel', 'pack_weights_t_kernel', 'wino_filter_kernel', 'wino_filter_multi_kernel', 'wino2_pack_kernel',      # pack_weights
+        'pack_weights_kernel', 'pack_weights_s2_kernel', 'pack_weights_s2t_kernel', 'pack_weights_t_kernel', 'wino_filter_kernel', 'wino_filter_multi_kernel', 'wino2_pack_kernel',      # pack_weights
         'channel_sum_part_kernel', 'channel_sum_fin_kernel', 'channel_psum_fin_kernel',                                            # misc (bias gradients of frozen-filter calls)
     }
     for f, ks in _kernels_by_file().items():

@@ -20,7 +20,7 @@ FAMILIES = {
                     'head_wgrad_kernel', 'head_wgrad_final_kernel'],
                    ['conv_wgrad'], ['conv_wgrad_wino']),
     # what stays on the direct forward / data-gradient entry points
-    'conv_igemm': (['conv_igemm_kernel', 'conv_igemm_glds_kernel', 'conv_igemm_rows16_kernel', 'small_fc_kernel', 'small_fc_narrow_kernel',
+    'conv_igemm': (['conv_igemm_kernel', 'conv_igemm_glds_kernel', 'conv_igemm_rows16_kernel', 'conv_s2sub_glds_kernel', 'small_fc_kernel', 'small_fc_narrow_kernel',
                     'conv3x3_fwd_thin_kernel', 'conv3x3_dgrad_thin_kernel', 'conv3x3_dgrad_thin_v4_kernel', 'conv3x3_dgrad_c1_mfma_kernel',
                     'head_fwd_kernel', 'head_dgrad_kernel'],
                    ['conv_igemm_fwd', 'conv_igemm_dgrad'], []),
