@@ -55,7 +55,7 @@ class DoubleConv(nn.Module):
         g = groups if self.training else 0        # train-mode BatchNorm behind the conv: statistics out of its output transform
         return self._tail(_conv(s[0], x, bn_groups=g), groups, g)
 
-    def _tail(self, z, groups, g):
+    def _tail(self, z, groups, g, defer=False):
         """BatchNorm -> ReLU -> conv -> BatchNorm -> ReLU behind the first convolution's output ``z``.  In train mode the first
         BatchNorm + ReLU is applied by the second convolution's loader where that layer runs as F(4x4) (``ops.bn_relu_conv3x3``):
         the activation between the two convolutions is never a tensor."""
@@ -64,9 +64,11 @@ class DoubleConv(nn.Module):
             z = ops.bn_relu_conv3x3(z, s[1], s[3].weight, s[3].bias, groups=groups, bn_groups=g)
         else:
             z = _conv(s[3], ops.bn_act(z, s[1], ops.ACT_RELU, groups=groups), bn_groups=g)
+        if defer:       # the caller applies double_conv[4] + ReLU itself (OutConv.forward_bn: inside the head's kernels)
+            return z
         return ops.bn_act(z, s[4], ops.ACT_RELU, groups=groups)
 
-    def forward_pair_cat(self, f2n, up):
+    def forward_pair_cat(self, f2n, up, defer=False):
         """``forward(torch.cat([f2n[:n], f2n[n:], up], dim=1))`` with the first convolution reading the three tensors in
         place (``ops.conv3x3_pair_cat``; caller checked ``ops.conv3x3_pair_cat_ok``)."""
         s = self.double_conv
@@ -74,7 +76,7 @@ class DoubleConv(nn.Module):
             (w0, b0), (w1, b1) = self._folded_params()
             return ops.conv2d(ops.conv3x3_pair_cat(f2n, up, w0, b0, relu=True), w1, b1, 1, 1, relu=True)
         g = 1 if self.training else 0
-        return self._tail(ops.conv3x3_pair_cat(f2n, up, s[0].weight, s[0].bias, bn_groups=g), 1, g)
+        return self._tail(ops.conv3x3_pair_cat(f2n, up, s[0].weight, s[0].bias, bn_groups=g), 1, g, defer=defer)
 
     def _folded_params(self):
         s = self.double_conv
@@ -147,7 +149,7 @@ class Up(nn.Module):
             x1 = F.pad(x1, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])
         return self.conv(torch.cat([x2, x1], dim=1))
 
-    def forward_pair(self, x1, f2n):
+    def forward_pair(self, x1, f2n, defer=False):
         """``forward(x1, cat([f2n[:n], f2n[n:]], dim=1))`` for the Segmentor, whose skip tensor is the channel pair of the two
         temporal branches living in ONE (2N, C, h, w) batch (reference Module.py:116-132): neither concatenation is
         materialised when the first convolution takes tensor lists; otherwise this is ``forward``."""
@@ -158,11 +160,15 @@ class Up(nn.Module):
             u = ops.conv_transpose2x2(x1, self.up.weight, self.up.bias)
         w0 = self.conv.double_conv[0].weight
         if tuple(u.shape[2:]) == tuple(f2n.shape[2:]) and ops.conv3x3_pair_cat_ok(f2n, u, w0):
-            return self.conv.forward_pair_cat(f2n, u)
+            return self.conv.forward_pair_cat(f2n, u, defer=defer)
         dy, dx = f2n.shape[2] - u.shape[2], f2n.shape[3] - u.shape[3]
         if dy or dx:
             u = F.pad(u, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])
-        return self.conv(torch.cat([f2n[:n], f2n[n:], u], dim=1))
+        x = torch.cat([f2n[:n], f2n[n:], u], dim=1)
+        if defer:       # (``defer``: train mode only -- the last BatchNorm + ReLU of the DoubleConv is left to the caller)
+            c = self.conv
+            return c._tail(_conv(c.double_conv[0], x, bn_groups=1), 1, 1, defer=True)
+        return self.conv(x)
 
 
 class OutConv(nn.Module):
@@ -177,6 +183,13 @@ class OutConv(nn.Module):
         if ops.conv1x1_head_supported(x, self.conv.weight):      # one output channel: streaming kernels, sigmoid fused
             return ops.conv1x1_head(x, self.conv.weight, self.conv.bias, sigmoid=True)
         return torch.sigmoid(_conv(self.conv, x))
+
+    def forward_bn(self, z, bn):
+        """``forward(relu(bn(z)))`` for a train-mode BatchNorm ``bn`` whose only consumer is this head (the decoder's last DoubleConv,
+        reference Module.py:131-133): normalisation, ReLU, 1x1 filter and sigmoid in one pass over z (``ops.bn_relu_head``)."""
+        if ops.bn_relu_head_ok(z, bn, self.conv.weight):
+            return ops.bn_relu_head(z, bn, self.conv.weight, self.conv.bias, sigmoid=True)
+        return self.forward(ops.bn_act(z, bn, ops.ACT_RELU))
 
 
 class Segmentor(nn.Module):
@@ -271,6 +284,8 @@ class Segmentor(nn.Module):
         x = self.up1.forward_pair(self._pair(feats[4], n), feats[3])
         x = self.up2.forward_pair(x, feats[2])
         x = self.up3.forward_pair(x, feats[1])
+        if self.training and self.up4.conv.training:       # the last BatchNorm + ReLU runs inside the head's kernels
+            return self.outc.forward_bn(self.up4.forward_pair(x, feats[0], defer=True), self.up4.conv.double_conv[4])
         x = self.up4.forward_pair(x, feats[0])
         return self.outc(x)
 

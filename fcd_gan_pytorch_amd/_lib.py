@@ -73,6 +73,9 @@ _SIGS = {
     'fcd_conv1x1_head_fwd': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
     'fcd_conv1x1_head_bwd_ws_bytes': (c_size_t, [c_int, c_int]),
     'fcd_conv1x1_head_bwd': (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, P, c_size_t, P]),
+    'fcd_conv1x1_head_bn_fwd': (c_int, [P, P, P, c_int, P, P, P, c_int, c_int, c_int, c_int, P]),
+    'fcd_conv1x1_head_bn_bwd_ws_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'fcd_conv1x1_head_bn_bwd': (c_int, [P, P, P, P, P, P, P, P, c_int, P, P, P, P, P, c_int, c_int, c_int, P, c_size_t, P]),
     'fcd_conv_wino_plan': (c_int, [POINTER(ConvDesc), c_int]),
     'fcd_conv_wino_set': (c_int, [c_int]),
     'fcd_conv_wino_split_set': (c_int, [c_int]),

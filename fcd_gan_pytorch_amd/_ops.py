@@ -1006,6 +1006,82 @@ class _Conv1x1Head(torch.autograd.Function):
         return dx, (dw.view(ctx.wshape) if dw is not None else None), db, None
 
 
+class _BnReluHead(torch.autograd.Function):
+    """``sigmoid(conv1x1(relu(BatchNorm2d_train(z)); w, b))`` with ONE output channel: the Segmentor's last BatchNorm + ReLU and its
+    OutConv head (reference Module.py:25-31 -> :82-90) as one node on ``fcd_bn_train_stats`` + ``fcd_conv1x1_head_bn_fwd`` /
+    ``_bwd``: the 128-channel activation and its gradient -- the largest tensors of the net -- are never written (csrc/conv_head.hip)."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, running_mean, running_var, momentum, eps, groups, weight, bias, sigmoid, parts):
+        z = _dev(z, 'bn input')
+        N, C, H, W = z.shape
+        dev = z.device
+        st = torch.empty(4, groups * C, dtype=torch.float32, device=dev)      # save_mean, save_invstd, scale, shift
+        ws = _ws(lib.fcd_bn_act_ws_bytes(C, groups), dev)
+        check(lib.fcd_bn_train_stats(_p(z), N, C, H * W, groups, _p(parts[0]) if parts is not None else None,
+                                     parts[1] if parts is not None else 0, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+                                     float(momentum), float(eps), _p(st[0]), _p(st[1]), _p(st[2]), _p(st[3]), _p(ws), ws.numel(),
+                                     _stream()), 'fcd_bn_train_stats')
+        if running_mean is not None:
+            torch._C._increment_version([running_mean, running_var])
+        w = weight.detach().reshape(-1).contiguous()
+        y = torch.empty((N, 1, H, W), dtype=torch.float32, device=dev)
+        check(lib.fcd_conv1x1_head_bn_fwd(_p(z), _p(st[2]), _p(st[3]), groups, _p(w), _p(bias) if bias is not None else None, _p(y),
+                                          N, C, H * W, 1 if sigmoid else 0, _stream()), 'fcd_conv1x1_head_bn_fwd')
+        ctx.save_for_backward(z, w, y if sigmoid else None, st, gamma, beta)
+        ctx.cfg = (int(groups), bias is not None, tuple(weight.shape))
+        ctx.bias_param = bias
+        ctx.weight_param = weight
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        z, w, y, st, gamma, beta = ctx.saved_tensors
+        groups, has_bias, wshape = ctx.cfg
+        dy = _dev(dy, 'head grad')
+        N, C, H, W = z.shape
+        dev = dy.device
+        dz = torch.empty_like(z)
+        dw = _grad_out(ctx.weight_param, wshape, dev) if ctx.needs_input_grad[8] else None
+        db = _grad_out(ctx.bias_param, (1,), dev) if (has_bias and ctx.needs_input_grad[9]) else None
+        dgamma = dbeta = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dgamma = _grad_out(gamma, (C,), dev)
+            dbeta = _grad_out(beta, (C,), dev)
+        nb = int(lib.fcd_conv1x1_head_bn_bwd_ws_bytes(N, C, groups))
+        ws = _ws(nb, dev)
+        check(lib.fcd_conv1x1_head_bn_bwd(_p(z), _p(w), _p(dy), _p(y) if y is not None else None, _p(st[2]), _p(st[3]), _p(st[0]),
+                                          _p(st[1]), groups, _p(dz), _p(dw), _p(db), _p(dgamma), _p(dbeta), N, C, H * W, _p(ws),
+                                          ws.numel(), _stream()), 'fcd_conv1x1_head_bn_bwd')
+        return dz, dgamma, dbeta, None, None, None, None, None, dw, db, None, None
+
+
+def bn_relu_head_ok(z, bn, weight, groups=1):
+    """True when ``conv1x1_head(bn_act(z, bn, ACT_RELU, groups=groups), weight, bias)`` can run as :func:`bn_relu_head`."""
+    if not (torch.is_tensor(z) and z.is_cuda and z.dim() == 4 and z.dtype == torch.float32):
+        return False
+    if os.environ.get('FCD_BN_FUSE') == '0' or _sync_world():
+        return False
+    if not (bn.training or bn.running_mean is None) or bn.weight is None or bn.bias is None or z.shape[0] % groups:
+        return False
+    return conv1x1_head_supported(z, weight) and weight.shape[1] == z.shape[1]
+
+
+def bn_relu_head(z, bn, weight, bias, sigmoid=True, groups=1):
+    """``conv1x1_head(bn_act(z, bn, ACT_RELU, groups=groups), weight, bias, sigmoid)`` without the activation tensor
+    (:class:`_BnReluHead`; check :func:`bn_relu_head_ok` first)."""
+    if bn.track_running_stats and bn.num_batches_tracked is not None:
+        if _COUNTERS is not None:
+            _COUNTERS.append((bn.num_batches_tracked, groups))
+        else:
+            bn.num_batches_tracked += groups
+    parts = getattr(z, '_fcd_bn', None)
+    if parts is not None and (parts[3] != z.data_ptr() or parts[4] != z._version or parts[2] != groups or parts[1] <= 0):
+        parts = None
+    return _BnReluHead.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum if bn.momentum is not None else 0.1,
+                             bn.eps, int(groups), weight, bias, bool(sigmoid), (parts[0], parts[1]) if parts is not None else None)
+
+
 def conv1x1_head_supported(x, weight):
     """True when ``conv1x1_head`` can take this layer (a 1x1 filter with one output channel on a wide map)."""
     if not (x.is_cuda and x.dim() == 4 and weight.dim() == 4 and weight.shape[0] == 1 and weight.shape[2:] == (1, 1)):

@@ -97,6 +97,17 @@ int fcd_conv1x1_head_fwd(const float* x, const float* w, const float* bias, floa
 size_t fcd_conv1x1_head_bwd_ws_bytes(int N, int C);
 int fcd_conv1x1_head_bwd(const float* x, const float* w, const float* dy, const float* y_sig, float* dx, float* dw,
                          float* db, int N, int C, int HW, void* ws, size_t ws_bytes, void* stream);
+/* [r5] The head behind a train-mode BatchNorm2d + ReLU (reference Module.py:25-31 -> :82-90: the decoder's last DoubleConv feeds OutConv
+ * and nothing else): y = [sigmoid](b + sum_c w[c] relu(z[c] scale[c] + shift[c])) straight from the BatchNorm INPUT z, and the whole
+ * backward tail (head data / weight gradient, BatchNorm reduce + apply) as two passes over z: the 128-channel activation and its
+ * gradient are never tensors (10 -> 4 passes over the Segmentor's largest tensor).  scale / shift from fcd_bn_train_stats, mean /
+ * invstd its saved statistics, all [groups][C]; workspace fcd_conv1x1_head_bn_bwd_ws_bytes. */
+int fcd_conv1x1_head_bn_fwd(const float* z, const float* scale, const float* shift, int groups, const float* w, const float* bias,
+                            float* y, int N, int C, int HW, int sigmoid, void* stream);
+size_t fcd_conv1x1_head_bn_bwd_ws_bytes(int N, int C, int groups);
+int fcd_conv1x1_head_bn_bwd(const float* z, const float* w, const float* dy, const float* y_sig, const float* scale,
+                            const float* shift, const float* mean, const float* invstd, int groups, float* dz, float* dw, float* db,
+                            float* dgamma, float* dbeta, int N, int C, int HW, void* ws, size_t ws_bytes, void* stream);
 /* ---- Winograd F(m x m, 3 x 3) path for wide 3x3 / stride-1 / pad-1 layers (m = 2 or 4) ------------
  * fcd_conv_wino_plan(): tile size the library uses for this layer and direction (mode 0 forward,
  * 1 data gradient), 0 = the layer runs on the direct kernels (then none of the *_wino calls apply).

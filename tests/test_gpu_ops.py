@@ -699,6 +699,43 @@ def test_maxpool_with_a_skip_consumer_sums_both_gradients_in_one_pass(shape, use
     assert torch.equal(out['fused'][1], x0)
 
 
+@pytest.mark.parametrize('case', [(2, 128, 64, 64, 1), (4, 32, 32, 32, 2), (3, 21, 32, 36, 1), (8, 128, 128, 128, 1)], ids=lambda c: 'x'.join(map(str, c)))
+def test_head_behind_batchnorm_relu_without_the_activation_tensor(case):
+    """BatchNorm2d(train) -> ReLU -> OutConv (reference Module.py:25-31 -> :82-90): ``ops.bn_relu_head`` (normalisation, ReLU, 1x1
+    filter, sigmoid in one pass over the BatchNorm input; backward = two passes) against ``conv1x1_head(bn_act(z))``.  The forward
+    kernels form the same products in the same order: bit-identical y and running statistics.  The gradients sum w[c] * g once per
+    channel instead of per element (fp64 sums): 2e-6 of the largest entry."""
+    ops = _ops()
+    N, C, H, W, G = case
+    z0 = rnd(N, C, H, W, seed=121)
+    w = rnd(1, C, 1, 1, seed=122, scale=C ** -0.5)
+    b = rnd(1, seed=123, scale=0.1)
+    g = rnd(N, 1, H, W, seed=124)
+    res = {}
+    for tag in ('fused', 'separate'):
+        bn = torch.nn.BatchNorm2d(C).cuda().train()
+        with torch.no_grad():
+            bn.weight.copy_(rnd(C, seed=125).cuda() * 0.2 + 1.0)
+            bn.bias.copy_(rnd(C, seed=126).cuda() * 0.1)
+        zin = z0.cuda().requires_grad_(True)
+        wg, bg = (t.cuda().requires_grad_(True) for t in (w, b))
+        z = zin * 1.0
+        if tag == 'fused':
+            assert ops.bn_relu_head_ok(z, bn, wg, G)
+            y = ops.bn_relu_head(z, bn, wg, bg, sigmoid=True, groups=G)
+        else:
+            y = ops.conv1x1_head(ops.bn_act(z, bn, ops.ACT_RELU, groups=G), wg, bg, sigmoid=True)
+        y.backward(g.cuda())
+        res[tag] = [t.detach().cpu() for t in (y, bn.running_mean, bn.running_var, zin.grad, wg.grad, bg.grad, bn.weight.grad, bn.bias.grad)]
+        assert int(bn.num_batches_tracked) == G
+    names = ('y', 'running_mean', 'running_var', 'dz', 'dw', 'db', 'dgamma', 'dbeta')
+    for a, r, what in zip(res['fused'][:3], res['separate'][:3], names[:3]):
+        assert torch.equal(a, r), what
+    for a, r, what in zip(res['fused'][3:], res['separate'][3:], names[3:]):
+        err = (a.double() - r.double()).abs().max().item() / max(r.double().abs().max().item(), 1e-30)
+        assert err < 2e-6, (what, err)
+
+
 def _split_modes_conv(ops, x, w, b):
     """y of the 3x3 layer with the F(4x4) GEMMs on the fp32 matrix pipe (mode 0) and on the two split-bf16 kernels."""
     lib = ops.lib
