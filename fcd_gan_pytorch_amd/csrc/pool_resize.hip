@@ -241,6 +241,22 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_v4_kernel(const float* __r
     const float h0l = 1.f - lh;
     const float* s0 = x + pl * H * W + (long long)h0 * W;
     const float* s1 = x + pl * H * W + (long long)h1 * W;
+    // [r5] src(o) = o (W - 1) / (2 W - 1) lies in [o / 2 - 1 / 2, o / 2]: the four outputs 4 q4 .. 4 q4 + 3 read source columns
+    // 2 q4 - 1 .. 2 q4 + 2 only.  That window is fetched once per row as scalar + aligned pair + scalar (6 loads per thread) and the
+    // taps are picked from registers, instead of 16 four-byte gathers: the kernel was bound by its load instructions (2.0 TB/s),
+    // not by bytes.  Same values, same expression.  (x 8-B aligned and W even: the pair at column 2 q4 is aligned; else gathers.)
+    const int cw = 2 * q4 - 1;
+    const bool win_ok = (((size_t)x) & 7) == 0;
+    float r0[4], r1[4];
+    if (win_ok) {
+      typedef float v2 __attribute__((ext_vector_type(2)));
+      const v2 m0 = *(const v2*)(s0 + cw + 1), m1 = *(const v2*)(s1 + cw + 1);       // columns 2 q4, 2 q4 + 1 < W (W even)
+      r0[1] = m0[0]; r0[2] = m0[1]; r1[1] = m1[0]; r1[2] = m1[1];
+      r0[0] = cw >= 0 ? s0[cw] : 0.f;
+      r1[0] = cw >= 0 ? s1[cw] : 0.f;
+      r0[3] = cw + 3 < W ? s0[cw + 3] : 0.f;
+      r1[3] = cw + 3 < W ? s1[cw + 3] : 0.f;
+    }
     v4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -248,7 +264,17 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_v4_kernel(const float* __r
       float lw;
       ac_src(4 * q4 + e, sw, W, &w0, &w1, &lw);
       const float w0l = 1.f - lw;
-      o[e] = h0l * (w0l * s0[w0] + lw * s0[w1]) + lh * (w0l * s1[w0] + lw * s1[w1]);
+      float a0, a1, b0, b1;
+      const int i0 = w0 - cw, i1 = w1 - cw;
+      if (win_ok && i0 >= 0 && i1 <= 3) {
+        a0 = i0 == 0 ? r0[0] : (i0 == 1 ? r0[1] : (i0 == 2 ? r0[2] : r0[3]));
+        a1 = i1 == 0 ? r0[0] : (i1 == 1 ? r0[1] : (i1 == 2 ? r0[2] : r0[3]));
+        b0 = i0 == 0 ? r1[0] : (i0 == 1 ? r1[1] : (i0 == 2 ? r1[2] : r1[3]));
+        b1 = i1 == 0 ? r1[0] : (i1 == 1 ? r1[1] : (i1 == 2 ? r1[2] : r1[3]));
+      } else {
+        a0 = s0[w0]; a1 = s0[w1]; b0 = s1[w0]; b1 = s1[w1];
+      }
+      o[e] = h0l * (w0l * a0 + lw * a1) + lh * (w0l * b0 + lw * b1);
     }
     *(v4*)(y + (pl * OH + oh) * OW + 4 * q4) = o;
   }
@@ -364,6 +390,95 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_win4_kernel(const float* _
   }
 }
 
+// [r5] The adjoint kernel above spends ~1000 instructions per 16 bytes stored -- 64-bit index divisions and the COLUMN source indices /
+// weights recomputed for every row -- and ran at 2.4 - 3.0 TB/s.  Here a thread owns its four columns and walks `rpb` consecutive rows
+// of the (plane, row) space: column weights once per thread, 32-bit index math, the same terms in the same order (bit-identical,
+// tests/test_gpu_ops.py).  Block (tx, ty): tx = column group, ty = row lane.  Same box, us: 128 -> 256 maps 112 -> 90, 64 -> 128: 59 -> 39,
+// 32 -> 64: 35 -> 31; 16 -> 32: 25 -> 28 (stays on the kernel above).  The same restructuring of the FORWARD kernel bought nothing
+// (164 -> 181 us on the largest map): it is bound by its 16 four-byte gathers per thread, not by index arithmetic.
+__global__ __launch_bounds__(256) void upsample2x_bwd_rows_kernel(const float* __restrict__ dy, float* __restrict__ dx, int rows_total,
+                                                                  int H, int W, float sh, float sw, int rpb) {
+  const int OH = 2 * H, OW = 2 * W, W4 = W >> 2;
+  const int wq = blockIdx.x * blockDim.x + threadIdx.x;
+  if (wq >= W4) return;
+  const int w = 4 * wq;
+  const int cb = 2 * w - 4;                      // first of the 16 gradient columns (upsample2x_bwd_win4_kernel)
+  float wv[4][6];
+  {
+    int c0[16], c1[16];
+    float cl[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      c0[k] = -1; c1[k] = -1; cl[k] = 0.f;
+      if (k >= 2 && k < 14 && cb + k >= 0 && cb + k < OW) ac_src(cb + k, sw, W, &c0[k], &c1[k], &cl[k]);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const int k = 2 * e + 2 + j;
+        float v = 0.f;
+        if (c0[k] == w + e) v += 1.f - cl[k];
+        if (c1[k] == w + e) v += cl[k];
+        wv[e][j] = v;
+      }
+  }
+  const bool q_ok[4] = {cb >= 0, true, true, cb + 12 < OW};
+  const int r0 = (blockIdx.y * blockDim.y + threadIdx.y) * rpb;
+  if (r0 >= rows_total) return;
+  int pl = r0 / H, h = r0 % H;
+  const int r1 = min(r0 + rpb, rows_total);
+  for (int r = r0; r < r1; ++r) {
+    const int oh_lo = max(2 * h - 2, 0), oh_hi = min(2 * h + 3, OH - 1);
+    const float* g = dy + (size_t)pl * OH * OW;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int rr = 0; rr < 6; ++rr) {
+      const int oh = oh_lo + rr;
+      if (oh > oh_hi) break;
+      int h0, h1; float lh;
+      ac_src(oh, sh, H, &h0, &h1, &lh);
+      float wh = 0.f;
+      if (h0 == h) wh += 1.f - lh;
+      if (h1 == h) wh += lh;
+      if (wh == 0.f) continue;
+      float gv[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float4 v = {0.f, 0.f, 0.f, 0.f};
+        if (q_ok[q]) v = *reinterpret_cast<const float4*>(g + (size_t)oh * OW + cb + 4 * q);
+        gv[4 * q] = v.x; gv[4 * q + 1] = v.y; gv[4 * q + 2] = v.z; gv[4 * q + 3] = v.w;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float rowacc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+          if (wv[e][j] != 0.f) rowacc += wv[e][j] * gv[2 * e + 2 + j];
+        acc[e] += wh * rowacc;
+      }
+    }
+    *reinterpret_cast<float4*>(dx + ((size_t)pl * H + h) * W + w) = float4{acc[0], acc[1], acc[2], acc[3]};
+    if (++h == H) { h = 0; ++pl; }
+  }
+}
+
+// launch geometry of the row-walking kernel: tx column groups (<= 256), 256 / tx row lanes, rpb rows per lane
+static bool rows_geom(int groups, long long rows_total, dim3* grid, dim3* block, int* rpb) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("FCD_UPSAMPLE_ROWS"); on = (e && e[0] == '0') ? 0 : 1; }
+  if (!on || rows_total >= (1ll << 31) || groups < 1) return false;
+  int tx = 1;
+  while (tx < groups && tx < 256) tx <<= 1;
+  const int ty = 256 / tx;
+  *rpb = 8;
+  const long long by = (rows_total + (long long)ty * *rpb - 1) / ((long long)ty * *rpb);
+  if (by > 65535) return false;
+  *block = dim3((unsigned)tx, (unsigned)ty);
+  *grid = dim3((unsigned)((groups + tx - 1) / tx), (unsigned)by);
+  return true;
+}
+
 static inline float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
 
 extern "C" int fcd_upsample2x_fwd(const float* x, float* y, int NC, int H, int W, void* stream) {
@@ -384,7 +499,13 @@ extern "C" int fcd_upsample2x_bwd(const float* dy, float* dx, int NC, int H, int
   FCD_CHECK_ARG(dy && dx && NC > 0 && H > 0 && W > 0, "fcd_upsample2x_bwd: bad arguments");
   const long long total = (long long)NC * H * W;
   FcdProfScope prof(FCD_K_POOL, (hipStream_t)stream, 0.0, 4.0 * NC * 5.0 * H * W);
-  if (H >= 2 && W >= 4 && (W & 3) == 0 && (((size_t)dy | (size_t)dx) & 15) == 0)
+  dim3 rg, rb;
+  int rpb = 0;
+  const bool v4ok = H >= 2 && W >= 4 && (W & 3) == 0 && (((size_t)dy | (size_t)dx) & 15) == 0;
+  if (v4ok && H >= 32 && rows_geom(W >> 2, (long long)NC * H, &rg, &rb, &rpb))
+    hipLaunchKernelGGL(upsample2x_bwd_rows_kernel, rg, rb, 0, (hipStream_t)stream, dy, dx, NC * H, H, W, ac_scale(H, 2 * H),
+                       ac_scale(W, 2 * W), rpb);
+  else if (v4ok)
     hipLaunchKernelGGL(upsample2x_bwd_win4_kernel, dim3(ew_grid(total / 4)), dim3(256), 0, (hipStream_t)stream, dy, dx, NC, H, W,
                        ac_scale(H, 2 * H), ac_scale(W, 2 * W));
   else if (H >= 2 && W >= 2)

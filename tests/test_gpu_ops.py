@@ -305,9 +305,10 @@ def test_maxpool_upsample_avgpool(shape):
         assert_close(xg.grad, xr.grad, tol=2e-6, what=name + ' dx')
 
 
-@pytest.mark.parametrize('shape', [(3, 2, 4), (2, 7, 12), (4, 16, 16), (1, 33, 64)], ids=lambda c: 'x'.join(map(str, c)))
+@pytest.mark.parametrize('shape', [(3, 2, 4), (2, 7, 12), (4, 16, 16), (1, 33, 64), (5, 20, 24), (2, 64, 128), (5, 36, 40), (3, 32, 8)], ids=lambda c: 'x'.join(map(str, c)))
 def test_upsample_bwd_four_column_kernel_is_bit_identical(shape):
-    """The adjoint of the x2 bilinear upsampling: the four-columns-per-thread kernel (W % 4 == 0, 16-B aligned buffers) against the
+    """The adjoint of the x2 bilinear upsampling: the four-columns-per-thread kernels (W % 4 == 0, 16-B aligned buffers; from H = 32 up
+    the one whose threads walk rows with their column weights kept, row runs crossing plane boundaries in the cases) against the
     one-pixel kernel the same entry point falls back to for a misaligned gradient buffer -- same weights, same summation order."""
     import ctypes
     from fcd_gan_pytorch_amd._lib import lib, check
