@@ -1121,7 +1121,7 @@ class _MaxPool2Skip(torch.autograd.Function):
     feature feeds the next ``Down``'s MaxPool2d and, concatenated, the decoder (reference Module.py:116-132).  Autograd would
     write the pooled path's routed gradient as a tensor and add the skip path's gradient to it in a pass of its own (read 2,
     write 1 of the largest activations of the net); here both arrive at this node and ``fcd_maxpool2_bwd_add`` writes
-    skip gradient + routed gradient in one pass (in place over the skip gradient).  Same fp32 sum."""
+    skip gradient + routed gradient in one pass.  Same fp32 sum."""
 
     @staticmethod
     def forward(ctx, x):
@@ -1145,9 +1145,7 @@ class _MaxPool2Skip(torch.autograd.Function):
             check(lib.fcd_maxpool2_bwd(_p(x), _p(dy), _p(dx), N * C, H, W, _stream()), 'fcd_maxpool2_bwd')
             return dx
         dskip = _dev(dskip, 'skip grad')
-        # in place over the skip gradient when this node is its only holder (a fresh tensor out of the decoder's data gradient);
-        # a gradient somebody else may still read (retain_graph hooks, views) gets a buffer of its own
-        dx = dskip if (dskip._base is None and not dskip.requires_grad) else torch.empty_like(x)
+        dx = torch.empty_like(x)        # (never in place over dskip: a tensor hook on the skip output may still hold it)
         check(lib.fcd_maxpool2_bwd_add(_p(x), _p(dy), _p(dskip), _p(dx), N * C, H, W, _stream()), 'fcd_maxpool2_bwd_add')
         return dx
 
