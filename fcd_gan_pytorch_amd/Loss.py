@@ -293,7 +293,7 @@ class CNetLoss(nn.Module):
         z = masked_pair(target_image, generate_image, cmap)
         perception_loss = self.loss_perception(target_image, generate_image, cmask if generator_mask_switch else cmap,
                                                stacked=None if generator_mask_switch else z)
-        ssim_loss = 1 - self.ssim(z[:n], z[n:])
+        ssim_loss = 1 - self.ssim(*z.split(n, dim=0))
         return generator_loss, l1_loss, perception_loss, ssim_loss
 
 
@@ -313,7 +313,7 @@ class CGeneratorLoss(nn.Module):
         generator_loss = _masked_ratio(target_image, generate_image, cmap, 1, True, 1.0 / C, skip_zero=True)
         n = target_image.shape[0]
         z = masked_pair(target_image, generate_image, cmap)
-        ssim_loss = 1 - self.ssim(z[:n], z[n:])
+        ssim_loss = 1 - self.ssim(*z.split(n, dim=0))
         perception_loss = self.loss_perception(target_image, generate_image, cmap, stacked=z)
         return generator_loss, ssim_loss, perception_loss
 

@@ -215,7 +215,10 @@ class Segmentor(nn.Module):
     @staticmethod
     def _pair(f, n):
         # (2N,C,h,w) two-branch features -> (N,2C,h,w) = cat([branch1, branch2], dim=1)
-        return torch.cat([f[:n], f[n:]], dim=1)
+        # (split, not two slices: its backward is ONE concatenation of the branch gradients instead of two zero-filled full-size
+        #  tensors and an add)
+        a, b = f.split(n, dim=0)
+        return torch.cat([a, b], dim=1)
 
     def forward(self, x1, x2):
         n = x1.shape[0]
@@ -420,7 +423,7 @@ class Discriminator_SRGAN_simple(nn.Module):
         mode = self.POOL_MODE
         if mode == 'fused':
             out = self.classify(ops.pair_gap_diff(f, npairs))
-            return [out[i * n:(i + 1) * n] for i in range(npairs)]
+            return list(out.split(n, dim=0)) if npairs > 1 else [out]
         if mode == 'pooled':
             f = f.mean(dim=(2, 3), keepdim=True)
         return [self.classify(f[(2 * i) * n:(2 * i + 1) * n] - f[(2 * i + 1) * n:(2 * i + 2) * n]) for i in range(npairs)]
@@ -452,7 +455,8 @@ class Discriminator_SRGAN_simple(nn.Module):
         order = [g for i in range(k) for g in (0, i + 1)]
         with ops.batched_bn_counters():
             f = self.features(z, groups=k + 1, order=order)
-            pairs = torch.cat([t for i in range(k) for t in (f[:n], f[(i + 1) * n:(i + 2) * n])], dim=0)
+            parts = f.split(n, dim=0)       # backward: one cat of the group gradients (x's two uses summed first), no zero-filled slices
+            pairs = torch.cat([t for i in range(k) for t in (parts[0], parts[i + 1])], dim=0)
             return self._classify_pairs(pairs, k)
 
     def forward_stacked(self, z, npairs):

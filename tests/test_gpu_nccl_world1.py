@@ -22,7 +22,7 @@ pytestmark = pytest.mark.gpu
 C, N, H = 4, 2, 176
 
 
-def _step(sync_bn, graphed=False, share=True):
+def _step(sync_bn, graphed=False, share=True, head_fused=True):
     import fcd_gan_pytorch_amd as p
     dev = torch.device('cuda', 0)
     p.set_sync_batchnorm(sync_bn)
@@ -31,6 +31,14 @@ def _step(sync_bn, graphed=False, share=True):
     # measures the SyncBN kernels and not the two ways of summing D's gradient (three RMSprop steps amplify those: D's loss
     # subtracts the two calls, the x-branch gradients nearly cancel)
     os.environ['FCD_D_SHARE'] = '1' if share else '0' 
+    # [r5] likewise the change-density head behind the last BatchNorm: per replica it runs inside the head's kernels
+    # (ops.bn_relu_head: w[c] * sum instead of sum of w[c] * term in its gradients, ~1e-7 relative), under SyncBN as BatchNorm
+    # kernels + head kernels.  head_fused=False gives the per-replica run in the SyncBN run's form (ops.bn_relu_head_ok reads the
+    # switch per call; the BatchNorm-in-the-loader fusion of the 3x3 layers is bit-identical either way)
+    if head_fused:
+        os.environ.pop('FCD_BN_FUSE', None)
+    else:
+        os.environ['FCD_BN_FUSE'] = '0'
     netG, netS, netD = p.Module.Generator(C), p.Module.Segmentor(C, 1, True), p.Module.Discriminator_SRGAN_simple(C)
     netG.load_state_dict(seeded_state(onets.generator_spec(C), 101))
     netS.load_state_dict(seeded_state(onets.segmentor_spec(C, 1, True), 102))
@@ -95,7 +103,7 @@ def _worker(port, q, variants):
             out['forced'] = _small(_step(False), plain)               # every collective runs, per-replica BatchNorm
         if 'forced_syncbn' in variants:
             p.dp.force_exchange(False)
-            plain4 = _step(False, share=False)                        # per-replica statistics, D step in the two-pass form SyncBN takes
+            plain4 = _step(False, share=False, head_fused=False)      # per-replica statistics, D step and head in the form SyncBN takes
             p.dp.force_exchange(True)
             out['forced_syncbn'] = _small(_step(True), plain4)        # + the SyncBN sums through ncclAllReduce
             out['forced_syncbn']['rm_ref'] = plain4['rm']

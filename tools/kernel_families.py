@@ -17,12 +17,12 @@ FAMILIES = {
     'conv_wgrad': (['conv_wgrad_kernel', 'conv_wgrad_roll_kernel', 'conv_wgrad_roll_nchw_kernel', 'conv_wgrad_thin_kernel', 'conv_wgrad_thin_finish_kernel',
                     'conv_wgrad_thin9_kernel', 'conv_wgrad_thin9_finish_kernel', 'thin9_bias_part_kernel', 'thin9_bias_fin_kernel',
                     'nchw_to_nhwc_kernel', 'nchw_to_nhwc_v4_kernel', 'wgrad_reduce_kernel', 'wgrad_reduce_wide_kernel',
-                    'head_wgrad_kernel', 'head_wgrad_final_kernel'],
+                    'head_wgrad_kernel', 'head_wgrad_final_kernel', 'head_bn_reduce_kernel', 'head_bn_final_kernel'],
                    ['conv_wgrad'], ['conv_wgrad_wino']),
     # what stays on the direct forward / data-gradient entry points
     'conv_igemm': (['conv_igemm_kernel', 'conv_igemm_glds_kernel', 'conv_igemm_rows16_kernel', 'conv_s2sub_glds_kernel', 'small_fc_kernel', 'small_fc_narrow_kernel',
                     'conv3x3_fwd_thin_kernel', 'conv3x3_dgrad_thin_kernel', 'conv3x3_dgrad_thin_v4_kernel', 'conv3x3_dgrad_c1_mfma_kernel',
-                    'head_fwd_kernel', 'head_dgrad_kernel'],
+                    'head_fwd_kernel', 'head_dgrad_kernel', 'head_fwd_bn_kernel', 'head_bn_apply_kernel'],
                    ['conv_igemm_fwd', 'conv_igemm_dgrad'], []),
     'wino_transform': (['wino_input_kernel', 'wino_input_roll_kernel', 'wino_output_kernel', 'wino_output_blk_kernel',
                         'wino_output_blk_bn_kernel', 'wino_oi_kernel', 'wino_wg_dy_kernel', 'wino_wg_input_kernel', 'wino_wg_final_kernel',
