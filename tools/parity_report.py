@@ -11,6 +11,7 @@ src = sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out'
 extra = sys.argv[2] if len(sys.argv) > 2 else None
 r = json.load(open(os.path.join(src, 'parity_fullsize_bwd.json')))
 dist = r.pop('d_step_error_distribution_16_maps', None)
+decisions = r.pop('usss_g_4x256_decisions', None)      # [r5] test_usss_generator_gradient_with_direct_vgg_decisions
 L = ['# Full-size backward parity against an fp64 truth (round 4)', '',
      '`tests/test_gpu_fullsize_bwd.py` on MI355X: one whole train iteration of each demo on the HIP path; next to it the CPU oracle step',
      '(`oracle/steps.py`, stock fp32 PyTorch, literal reference order) and THE SAME oracle step in double precision.  Every gradient is compared',
@@ -20,6 +21,8 @@ L = ['# Full-size backward parity against an fp64 truth (round 4)', '',
      '|---|---|---|---|---|---|---|---|---|']
 for tag in sorted(r):
     for w, v in sorted(r[tag].items()):
+        if not isinstance(v, dict):
+            continue
         if 'e2e_flat_rel_l2_vs_fp64' in v:
             continue
         L.append('| %s | %s | %.2e | %.2e | %.2f | %.2f (%s: %.2e / %.2e) | %.2f (%s) | %.2e | %.1e |' % (
@@ -96,3 +99,12 @@ for plan in ('direct', 'winograd'):
     for w in rows:
         L.append('| %s | %d | %.1e / %.1e | %.1e / %.1e | %.1e / %.1e |' % ((plan, w['it']) + tuple(w['hip_vs_fp64']) + tuple(w['ref32_vs_fp64']) + tuple(w['hip_vs_ref32'])))
 print('\n'.join(L))
+if decisions:
+    print()
+    print('## Generator step (Demo_USSS, 4 x 256 x 256): F(4x4) arithmetic vs activation decisions')
+    print()
+    print('Relative L2 distance of the whole Generator gradient to the fp64 gradient (`test_usss_generator_gradient_with_direct_vgg_decisions`):')
+    print()
+    for k, v in sorted(decisions.items()):
+        print('* `%s`: %s' % (k, ('%.4g' % v) if isinstance(v, float) else json.dumps(v)))
+
