@@ -44,8 +44,12 @@ class DoubleConv(nn.Module):
             nn.Conv2d(mid, out_channels, kernel_size=3, padding=1), nn.BatchNorm2d(out_channels),
             nn.ReLU(inplace=True))
 
-    def forward(self, x, groups=1):
+    def forward(self, x, groups=1, defer=False):
+        """``defer`` (train mode only): return the second convolution's output and leave ``double_conv[4]`` + ReLU to the caller, who
+        runs them inside the kernels of their consumer (``ops.bn_relu_pool_skip``, ``ops.bn_relu_head``)."""
         s = self.double_conv
+        if defer and not self.training:
+            raise RuntimeError('DoubleConv.forward(defer=True) is a train-mode path')
         if not self.training and not torch.is_grad_enabled():
             # inference (Demo_RSSS.py:451-491: netS.eval() + no_grad): eval-mode BatchNorm is an
             # affine map per channel -> folded into the conv's filter and bias once, and each
@@ -53,7 +57,7 @@ class DoubleConv(nn.Module):
             (w0, b0), (w1, b1) = self._folded_params()
             return ops.conv2d(ops.conv2d(x, w0, b0, 1, 1, relu=True), w1, b1, 1, 1, relu=True)
         g = groups if self.training else 0        # train-mode BatchNorm behind the conv: statistics out of its output transform
-        return self._tail(_conv(s[0], x, bn_groups=g), groups, g)
+        return self._tail(_conv(s[0], x, bn_groups=g), groups, g, defer=defer)
 
     def _tail(self, z, groups, g, defer=False):
         """BatchNorm -> ReLU -> conv -> BatchNorm -> ReLU behind the first convolution's output ``z``.  In train mode the first
@@ -223,8 +227,8 @@ class Segmentor(nn.Module):
     def forward(self, x1, x2):
         n = x1.shape[0]
         with ops.batched_bn_counters():                              # the 18 num_batches_tracked increments as one launch
-            f = self.inc(torch.cat([x1, x2], dim=0), groups=2)      # both temporal branches in one batch
-            return self._after_inc(f, n)
+            f, pending = self._double_conv(self.inc, torch.cat([x1, x2], dim=0))      # both temporal branches in one batch
+            return self._after_inc(f, n, pending)
 
     @torch.no_grad()
     def forward_raw(self, x1_raw, x2_raw, valid, stats):
@@ -276,13 +280,31 @@ class Segmentor(nn.Module):
         self.__dict__.pop('_fcd_raw_filters', None)
         return super()._apply(fn, *a, **k)
 
-    def _after_inc(self, f, n):
+    @staticmethod
+    def _double_conv(dc, x):
+        """An encoder DoubleConv on the two-branch batch: (tensor, the BatchNorm still to be applied to it or None)."""
+        if dc.training and torch.is_grad_enabled():
+            return dc(x, groups=2, defer=True), dc.double_conv[4]
+        return dc(x, groups=2), None
+
+    def _after_inc(self, f, n, pending=None):
         # f: both temporal branches in one (2N, C, h, w) batch; the reference's skip tensor is cat([branch1, branch2], 1)
         # (Module.py:116-132) -- kept as the un-paired batch and read in place by the decoder's first convolutions
+        # ``pending``: the BatchNorm (+ ReLU) that has not been applied to f yet -- in train mode the last BatchNorm of a DoubleConv
+        # runs inside the kernels of what consumes it: with the max-pool and the skip tensor here (ops.bn_relu_pool_skip: one node
+        # that also sums the level's two gradients), inside the head at the end
         feats = []
         for stage in (self.down1, self.down2, self.down3, self.down4):
-            skip, f = stage.forward_skip(f, groups=2)      # skip IS f, as the output of the node that sums f's two gradients
+            if pending is not None and ops.bn_relu_pool_skip_ok(f, pending, 2):
+                skip, pooled = ops.bn_relu_pool_skip(f, pending, groups=2)
+            else:
+                if pending is not None:
+                    f = ops.bn_act(f, pending, ops.ACT_RELU, groups=2)
+                skip, pooled = ops.maxpool2_skip(f)      # skip IS f, as the output of the node that sums f's two gradients
             feats.append(skip)
+            f, pending = self._double_conv(stage.maxpool_conv[1], pooled)
+        if pending is not None:
+            f = ops.bn_act(f, pending, ops.ACT_RELU, groups=2)
         feats.append(f)
         x = self.up1.forward_pair(self._pair(feats[4], n), feats[3])
         x = self.up2.forward_pair(x, feats[2])

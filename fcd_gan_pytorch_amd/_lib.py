@@ -131,6 +131,9 @@ _SIGS = {
                                       c_float, P, c_size_t, P]),
     'fcd_bn_act_bwd': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_float, c_int, P, P,
                                c_int, P, c_float, P, P, P, P, c_size_t, P]),
+    'fcd_bn_relu_pool_plan': (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    'fcd_bn_relu_pool_fwd': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
+    'fcd_bn_relu_pool_bwd': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, c_size_t, P]),
     'fcd_bn_train_stats': (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, P, P, P, P, c_float, c_float, P, P, P, P, P, c_size_t, P]),
     'fcd_bn_act_fwd_parts': (c_int, [P, P, c_int, c_int, c_int, c_int, P, c_int, P, P, P, P, c_float, c_float, P, P, c_int, P, c_float,
                                      P, c_size_t, P]),

@@ -1056,6 +1056,81 @@ class _BnReluHead(torch.autograd.Function):
         return dz, dgamma, dbeta, None, None, None, None, None, dw, db, None, None
 
 
+class _BnReluPoolSkip(torch.autograd.Function):
+    """``a = relu(BatchNorm2d_train(z))``, ``p = maxpool2(a)`` -> ``(a, p)`` as ONE node: the tail of an encoder level, whose
+    activation feeds the next ``Down`` and the decoder's skip connection (reference Module.py:30-31 -> :43-44, :116-132).  Forward:
+    ``fcd_bn_train_stats`` + ``fcd_bn_relu_pool_fwd`` (a and p written from one read of z).  Backward: both gradients arrive here;
+    ``fcd_bn_relu_pool_bwd`` recomputes the pooling argmax and the ReLU gate from z and writes the BatchNorm input gradient -- neither
+    the activation nor the summed gradient is read or written again (csrc/norm_act.hip)."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, running_mean, running_var, momentum, eps, groups, parts):
+        z = _dev(z, 'bn input')
+        N, C, H, W = z.shape
+        dev = z.device
+        st = torch.empty(4, groups * C, dtype=torch.float32, device=dev)      # save_mean, save_invstd, scale, shift
+        ws = _ws(lib.fcd_bn_act_ws_bytes(C, groups), dev)
+        check(lib.fcd_bn_train_stats(_p(z), N, C, H * W, groups, _p(parts[0]) if parts is not None else None,
+                                     parts[1] if parts is not None else 0, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+                                     float(momentum), float(eps), _p(st[0]), _p(st[1]), _p(st[2]), _p(st[3]), _p(ws), ws.numel(),
+                                     _stream()), 'fcd_bn_train_stats')
+        if running_mean is not None:
+            torch._C._increment_version([running_mean, running_var])
+        a = torch.empty_like(z)
+        p = torch.empty((N, C, H // 2, W // 2), dtype=torch.float32, device=dev)
+        check(lib.fcd_bn_relu_pool_fwd(_p(z), _p(a), _p(p), N, C, H, W, groups, _p(st[2]), _p(st[3]), _stream()), 'fcd_bn_relu_pool_fwd')
+        ctx.save_for_backward(z, gamma, beta, st)
+        ctx.groups = int(groups)
+        ctx.set_materialize_grads(False)
+        return a, p
+
+    @staticmethod
+    def backward(ctx, da, dp):
+        z, gamma, beta, st = ctx.saved_tensors
+        groups = ctx.groups
+        N, C, H, W = z.shape
+        dev = z.device
+        if da is None and dp is None:
+            return (None,) * 9
+        da = _dev(da, 'skip grad') if da is not None else torch.zeros_like(z)
+        dp = _dev(dp, 'maxpool grad') if dp is not None else torch.zeros((N, C, H // 2, W // 2), dtype=torch.float32, device=dev)
+        dz = torch.empty_like(z)
+        dgamma = dbeta = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dgamma = _grad_out(gamma, (C,), dev)
+            dbeta = _grad_out(beta, (C,), dev)
+        ws = _ws(lib.fcd_bn_act_ws_bytes(C, groups), dev)
+        check(lib.fcd_bn_relu_pool_bwd(_p(z), _p(da), _p(dp), _p(dz), N, C, H, W, groups, _p(gamma), _p(beta), _p(st[0]), _p(st[1]),
+                                       _p(dgamma), _p(dbeta), _p(ws), ws.numel(), _stream()), 'fcd_bn_relu_pool_bwd')
+        return dz, dgamma, dbeta, None, None, None, None, None, None
+
+
+def bn_relu_pool_skip_ok(z, bn, groups=1):
+    """True when ``a = bn_act(z, bn, ACT_RELU, groups); (a, maxpool2(a))`` can run as :func:`bn_relu_pool_skip`."""
+    if not (torch.is_tensor(z) and z.is_cuda and z.dim() == 4 and z.dtype == torch.float32):
+        return False
+    if os.environ.get('FCD_BN_FUSE') == '0' or _sync_world():
+        return False
+    if not (bn.training or bn.running_mean is None) or bn.weight is None or bn.bias is None:
+        return False
+    N, C, H, W = z.shape
+    return bool(lib.fcd_bn_relu_pool_plan(N, C, H, W, int(groups)))
+
+
+def bn_relu_pool_skip(z, bn, groups=1):
+    """``a = relu(bn(z))`` and ``maxpool2(a)`` from one node (:class:`_BnReluPoolSkip`; check :func:`bn_relu_pool_skip_ok` first)."""
+    if bn.track_running_stats and bn.num_batches_tracked is not None:
+        if _COUNTERS is not None:
+            _COUNTERS.append((bn.num_batches_tracked, groups))
+        else:
+            bn.num_batches_tracked += groups
+    parts = getattr(z, '_fcd_bn', None)
+    if parts is not None and (parts[3] != z.data_ptr() or parts[4] != z._version or parts[2] != groups or parts[1] <= 0):
+        parts = None
+    return _BnReluPoolSkip.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum if bn.momentum is not None else 0.1,
+                                 bn.eps, int(groups), (parts[0], parts[1]) if parts is not None else None)
+
+
 def bn_relu_head_ok(z, bn, weight, groups=1):
     """True when ``conv1x1_head(bn_act(z, bn, ACT_RELU, groups=groups), weight, bias)`` can run as :func:`bn_relu_head`."""
     if not (torch.is_tensor(z) and z.is_cuda and z.dim() == 4 and z.dtype == torch.float32):

@@ -690,3 +690,236 @@ extern "C" int fcd_bn_bwd_from_sums(const float* dz, const float* x, float* dx, 
   FCD_LAUNCH_CHECK("bn_bwd_from_sums");
   return FCD_OK;
 }
+
+// =====================================================================================================================
+// [r5] Encoder tail: train-mode BatchNorm + ReLU whose result feeds MaxPool2d(2) AND a skip connection (reference Module.py:30-31 ->
+// :43-44 and :116-132).  Unfused, the tail of an encoder level is: apply (read z, write a), max-pool (read a, write p); backward:
+// max-pool routing + skip sum (read a, skip gradient; write dz), BatchNorm reduce (read dz, z), BatchNorm apply (read dz, z; write).
+// a = relu(z * scale + shift) is one fma + compare away from z, and the pooling argmax is a function of a: the backward pass needs
+// neither a nor dz as tensors.  Here:
+//   forward   one kernel writes a (the skip tensor) and p from z                                  (the max-pool's read of a is gone)
+//   reduce    reads z + skip gradient (+ the pooled gradient, a quarter): recomputes a, the argmax of each 2 x 2 window, dz = skip
+//             gradient + routed pooled gradient, the ReLU gate, and sums dy', dy' xhat per channel in fp64
+//   apply     the same reads, writes the BatchNorm input gradient
+// 5 passes over the level's activation instead of 8 in the backward tail.  Values: a, p, argmax, dz per element are the unfused
+// kernels' expressions (same fma, same NaN-propagating window order); the fp64 sums run in a different order.
+// One thread = 2 rows x 4 columns = two pooling windows (H, W even, W % 4 == 0, 16-B aligned rows: host-checked).
+typedef float bnp_f4 __attribute__((ext_vector_type(4)));
+typedef float bnp_f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int pool_arg(float v00, float v01, float v10, float v11, float* mx) {
+  int arg = 0;
+  float m = v00;
+  if (v01 > m || v01 != v01) { m = v01; arg = 1; }      // maxpool2_fwd / _bwd_kernel's order (PyTorch: val > max || isnan(val))
+  if (v10 > m || v10 != v10) { m = v10; arg = 2; }
+  if (v11 > m || v11 != v11) { m = v11; arg = 3; }
+  *mx = m;
+  return arg;
+}
+
+// grid (planes, chunks): items of a plane = (H / 2) x (W / 4)
+__global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float* __restrict__ z, float* __restrict__ a, float* __restrict__ p,
+                                                               int C, int H, int W, int Ng, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift) {
+  const int plane = blockIdx.x;
+  const int n = plane / C, c = plane % C;
+  const float sc = scale[(n / Ng) * C + c], sh = shift[(n / Ng) * C + c];
+  const int W4 = W >> 2, items = (H >> 1) * W4, Wp = W >> 1;
+  const float* zp = z + (size_t)plane * H * W;
+  float* ap = a + (size_t)plane * H * W;
+  float* pp = p + (size_t)plane * (H >> 1) * Wp;
+  for (int i = blockIdx.y * 256 + threadIdx.x; i < items; i += gridDim.y * 256) {
+    const int r2 = i / W4, j = i % W4;
+    const size_t o = (size_t)(2 * r2) * W + 4 * j;
+    const bnp_f4 z0 = *(const bnp_f4*)(zp + o), z1 = *(const bnp_f4*)(zp + o + W);
+    bnp_f4 a0, a1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float y0 = fmaf(z0[e], sc, sh), y1 = fmaf(z1[e], sc, sh);
+      a0[e] = y0 > 0.f ? y0 : 0.f;
+      a1[e] = y1 > 0.f ? y1 : 0.f;
+    }
+    *(bnp_f4*)(ap + o) = a0;
+    *(bnp_f4*)(ap + o + W) = a1;
+    bnp_f2 m;
+    float t;
+    pool_arg(a0[0], a0[1], a1[0], a1[1], &t); m[0] = t;
+    pool_arg(a0[2], a0[3], a1[2], a1[3], &t); m[1] = t;
+    *(bnp_f2*)(pp + (size_t)r2 * Wp + 2 * j) = m;
+  }
+}
+
+// what one thread of the two backward kernels sees of its 2 x 4 patch: z, dy' = (skip gradient + routed pooled gradient) gated by
+// the ReLU, per element
+struct BnPoolPatch { bnp_f4 z0, z1, d0, d1; };
+__device__ __forceinline__ BnPoolPatch bn_pool_patch(const float* __restrict__ zp, const float* __restrict__ sp,
+                                                     const float* __restrict__ gp, int W, int Wp, int r2, int j, float sc, float sh) {
+  BnPoolPatch q;
+  const size_t o = (size_t)(2 * r2) * W + 4 * j;
+  q.z0 = __builtin_nontemporal_load((const bnp_f4*)(zp + o));
+  q.z1 = __builtin_nontemporal_load((const bnp_f4*)(zp + o + W));
+  const bnp_f4 s0 = __builtin_nontemporal_load((const bnp_f4*)(sp + o)), s1 = __builtin_nontemporal_load((const bnp_f4*)(sp + o + W));
+  const bnp_f2 g = *(const bnp_f2*)(gp + (size_t)r2 * Wp + 2 * j);
+  bnp_f4 a0, a1;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float y0 = fmaf(q.z0[e], sc, sh), y1 = fmaf(q.z1[e], sc, sh);
+    a0[e] = y0 > 0.f ? y0 : 0.f;
+    a1[e] = y1 > 0.f ? y1 : 0.f;
+  }
+  float t;
+  const int g0 = pool_arg(a0[0], a0[1], a1[0], a1[1], &t), g1 = pool_arg(a0[2], a0[3], a1[2], a1[3], &t);
+  // dz = skip gradient + routed gradient (maxpool2_bwd_kernel with `add`), then the ReLU gate (bn_bwd_*: dz * [y > 0])
+  q.d0[0] = (s0[0] + (g0 == 0 ? g[0] : 0.f)) * (a0[0] > 0.f ? 1.f : 0.f);
+  q.d0[1] = (s0[1] + (g0 == 1 ? g[0] : 0.f)) * (a0[1] > 0.f ? 1.f : 0.f);
+  q.d1[0] = (s1[0] + (g0 == 2 ? g[0] : 0.f)) * (a1[0] > 0.f ? 1.f : 0.f);
+  q.d1[1] = (s1[1] + (g0 == 3 ? g[0] : 0.f)) * (a1[1] > 0.f ? 1.f : 0.f);
+  q.d0[2] = (s0[2] + (g1 == 0 ? g[1] : 0.f)) * (a0[2] > 0.f ? 1.f : 0.f);
+  q.d0[3] = (s0[3] + (g1 == 1 ? g[1] : 0.f)) * (a0[3] > 0.f ? 1.f : 0.f);
+  q.d1[2] = (s1[2] + (g1 == 2 ? g[1] : 0.f)) * (a1[2] > 0.f ? 1.f : 0.f);
+  q.d1[3] = (s1[3] + (g1 == 3 ? g[1] : 0.f)) * (a1[3] > 0.f ? 1.f : 0.f);
+  return q;
+}
+
+// grid (C, G, split): part[((g C + c) split + sp) 3 + {0, 1}] = {sum dy', sum dy' xhat}
+__global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const float* __restrict__ z, const float* __restrict__ dskip,
+                                                                 const float* __restrict__ dpool, double* __restrict__ part, int C,
+                                                                 int H, int W, int Ng, int split, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, const float* __restrict__ mean,
+                                                                 const float* __restrict__ invstd) {
+  __shared__ double red[16];
+  const int c = blockIdx.x, g = blockIdx.y, sp = blockIdx.z;
+  const int sidx = g * C + c;
+  const float mu = mean[sidx], is = invstd[sidx];
+  const float sc = gamma[c] * is, sh = beta[c] - mu * sc;
+  const int W4 = W >> 2, Wp = W >> 1, items = (H >> 1) * W4;
+  const long long total = (long long)Ng * items;
+  const long long chunk = (total + split - 1) / split;
+  const long long beg = sp * chunk, end = min(beg + chunk, total);
+  double s1 = 0.0, s2 = 0.0;
+  for (long long e = beg + threadIdx.x; e < end; e += 256) {
+    const int n = (int)(e / items), i = (int)(e % items);
+    const size_t plane = (size_t)(g * Ng + n) * C + c;
+    const BnPoolPatch q = bn_pool_patch(z + plane * H * W, dskip + plane * H * W, dpool + plane * (H >> 1) * Wp, W, Wp, i / W4, i % W4, sc, sh);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      s1 += (double)q.d0[k];
+      s2 += (double)q.d0[k] * (double)((q.z0[k] - mu) * is);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      s1 += (double)q.d1[k];
+      s2 += (double)q.d1[k] * (double)((q.z1[k] - mu) * is);
+    }
+  }
+  s1 = block_sum_d(s1, red);
+  s2 = block_sum_d(s2, red);
+  if (threadIdx.x == 0) {
+    double* o = part + ((size_t)sidx * split + sp) * 3;
+    o[0] = s1;
+    o[1] = s2;
+    o[2] = 0.0;
+  }
+}
+
+// grid (planes, chunks); the block sums its channel's partials itself (bn_bwd_apply_kernel's [r4] form) and block (n = 0, chunk 0) of
+// a channel writes the parameter gradients
+__global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const float* __restrict__ z, const float* __restrict__ dskip,
+                                                                const float* __restrict__ dpool, float* __restrict__ dx, int C, int H,
+                                                                int W, int Ng, int G, int split, const double* __restrict__ part,
+                                                                double inv_count, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                                                float* __restrict__ dbeta) {
+  const int plane = blockIdx.x;
+  const int n = plane / C, c = plane % C;
+  const int sidx = (n / Ng) * C + c;
+  const float mu = mean[sidx], is = invstd[sidx];
+  const float sc = gamma[c] * is, sh = beta[c] - mu * sc;
+  double t1 = 0.0, t2 = 0.0;
+  const double* p = part + (size_t)sidx * split * 3;
+  for (int s = 0; s < split; ++s) {
+    t1 += p[s * 3];
+    t2 += p[s * 3 + 1];
+  }
+  const float k1 = (float)(t1 * inv_count), k2 = (float)(t2 * inv_count);
+  if (n == 0 && blockIdx.y == 0 && threadIdx.x == 0 && (dgamma || dbeta)) {
+    double tg = 0.0, tb = 0.0;
+    for (int g = 0; g < G; ++g) {
+      double a1 = 0.0, a2 = 0.0;
+      const double* q = part + (size_t)(g * C + c) * split * 3;
+      for (int s = 0; s < split; ++s) {
+        a1 += q[s * 3];
+        a2 += q[s * 3 + 1];
+      }
+      tb += a1;
+      tg += a2;
+    }
+    if (dgamma) dgamma[c] = (float)tg;
+    if (dbeta) dbeta[c] = (float)tb;
+  }
+  const int W4 = W >> 2, Wp = W >> 1, items = (H >> 1) * W4;
+  const float* zp = z + (size_t)plane * H * W;
+  const float* sp = dskip + (size_t)plane * H * W;
+  const float* gp = dpool + (size_t)plane * (H >> 1) * Wp;
+  float* op = dx + (size_t)plane * H * W;
+  for (int i = blockIdx.y * 256 + threadIdx.x; i < items; i += gridDim.y * 256) {
+    const int r2 = i / W4, j = i % W4;
+    const BnPoolPatch q = bn_pool_patch(zp, sp, gp, W, Wp, r2, j, sc, sh);
+    bnp_f4 o0, o1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      o0[k] = sc * (q.d0[k] - k1 - (q.z0[k] - mu) * is * k2);
+      o1[k] = sc * (q.d1[k] - k1 - (q.z1[k] - mu) * is * k2);
+    }
+    const size_t o = (size_t)(2 * r2) * W + 4 * j;
+    *(bnp_f4*)(op + o) = o0;
+    *(bnp_f4*)(op + o + W) = o1;
+  }
+}
+
+// 1: the shapes the three kernels take (even H and W, W % 4 == 0)
+extern "C" int fcd_bn_relu_pool_plan(int N, int C, int H, int W, int groups) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("FCD_BN_POOL"); on = (e && e[0] == '0') ? 0 : 1; }
+  return (on && N > 0 && C > 0 && groups > 0 && N % groups == 0 && H >= 2 && W >= 4 && (H & 1) == 0 && (W & 3) == 0 &&
+          (long long)N * C < (1ll << 31)) ? 1 : 0;
+}
+
+// a = relu(z * scale + shift) (N, C, H, W) and p = maxpool2(a) (N, C, H / 2, W / 2) in one pass; scale / shift from fcd_bn_train_stats
+extern "C" int fcd_bn_relu_pool_fwd(const float* z, float* a, float* p, int N, int C, int H, int W, int groups, const float* scale,
+                                    const float* shift, void* stream) {
+  FCD_CHECK_ARG(z && a && p && scale && shift && fcd_bn_relu_pool_plan(N, C, H, W, groups), "fcd_bn_relu_pool_fwd: bad arguments");
+  FCD_CHECK_ARG(((((size_t)z | (size_t)a) & 15) == 0) && (((size_t)p & 7) == 0), "fcd_bn_relu_pool_fwd: 16-B aligned z / a, 8-B aligned p");
+  hipStream_t st = (hipStream_t)stream;
+  FcdProfScope prof(FCD_K_NORM, st, 0.0, 4.0 * N * C * (double)H * W * 2.25);
+  hipLaunchKernelGGL(bn_relu_pool_fwd_kernel, plane_grid(N * C, H * W / 2), dim3(256), 0, st, z, a, p, C, H, W, N / groups, scale, shift);
+  FCD_LAUNCH_CHECK("bn_relu_pool_fwd");
+  return FCD_OK;
+}
+
+// backward of (a, p) = fcd_bn_relu_pool_fwd(BatchNorm_train statistics of z): dz from the gradient `dskip` of a (the skip consumer's;
+// required) and `dpool` of p; dgamma / dbeta may be NULL.  Workspace fcd_bn_act_ws_bytes(C, groups).
+extern "C" int fcd_bn_relu_pool_bwd(const float* z, const float* dskip, const float* dpool, float* dz, int N, int C, int H, int W,
+                                    int groups, const float* gamma, const float* beta, const float* save_mean,
+                                    const float* save_invstd, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream) {
+  FCD_CHECK_ARG(z && dskip && dpool && dz && gamma && beta && save_mean && save_invstd && fcd_bn_relu_pool_plan(N, C, H, W, groups),
+                "fcd_bn_relu_pool_bwd: bad arguments");
+  FCD_CHECK_ARG(((((size_t)z | (size_t)dskip | (size_t)dz) & 15) == 0) && (((size_t)dpool & 7) == 0),
+                "fcd_bn_relu_pool_bwd: 16-B aligned z / dskip / dz, 8-B aligned dpool");
+  if (ws == nullptr || ws_bytes < fcd_bn_act_ws_bytes(C, groups)) {
+    fcd_set_error("fcd_bn_relu_pool_bwd: workspace too small");
+    return FCD_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int Ng = N / groups, HW = H * W;
+  BnWs w = carve(ws, C, groups);
+  FcdProfScope prof(FCD_K_NORM, st, 0.0, 4.0 * N * C * (double)HW * 5.5);
+  const int split = pick_split(C, groups, (long long)Ng * HW);
+  hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel, dim3(C, groups, split), dim3(256), 0, st, z, dskip, dpool, w.part, C, H, W, Ng, split,
+                     gamma, beta, save_mean, save_invstd);
+  hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, plane_grid(N * C, HW / 2), dim3(256), 0, st, z, dskip, dpool, dz, C, H, W, Ng, groups,
+                     split, (const double*)w.part, 1.0 / ((double)Ng * HW), gamma, beta, save_mean, save_invstd, dgamma, dbeta);
+  FCD_LAUNCH_CHECK("bn_relu_pool_bwd");
+  return FCD_OK;
+}

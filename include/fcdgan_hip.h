@@ -328,6 +328,17 @@ int fcd_bn_act_fwd_parts(const float* x, float* y, int N, int C, int HW, int gro
 int fcd_bn_train_stats(const float* x, int N, int C, int HW, int groups, const double* part, int split, const float* gamma,
                        const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* save_mean,
                        float* save_invstd, float* scale, float* shift, void* ws, size_t ws_bytes, void* stream);
+/* [r5] Encoder tail: train-mode BatchNorm2d + ReLU whose result feeds MaxPool2d(2) and a skip connection (reference Module.py:30-31 ->
+ * :43-44 / :116-132).  _fwd writes a = relu(z * scale + shift) and p = maxpool2(a) in one pass (scale / shift from fcd_bn_train_stats);
+ * _bwd takes the skip consumer's gradient of a and the gradient of p and writes the BatchNorm input gradient: the pooling argmax and the
+ * ReLU gate are recomputed from z, neither a nor the summed gradient is read or written (5 instead of 8 passes).  _plan: shapes taken
+ * (even H, W % 4 == 0); 16-B aligned tensors; workspace fcd_bn_act_ws_bytes(C, groups). */
+int fcd_bn_relu_pool_plan(int N, int C, int H, int W, int groups);
+int fcd_bn_relu_pool_fwd(const float* z, float* a, float* p, int N, int C, int H, int W, int groups, const float* scale,
+                         const float* shift, void* stream);
+int fcd_bn_relu_pool_bwd(const float* z, const float* dskip, const float* dpool, float* dz, int N, int C, int H, int W, int groups,
+                         const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, float* dgamma,
+                         float* dbeta, void* ws, size_t ws_bytes, void* stream);
 int fcd_bn_bwd_partial(const float* dz, const float* x, double* out, int N, int C, int HW,
                        int groups, const float* gamma, const float* beta, const float* save_mean,
                        const float* save_invstd, int act, const float* slope, float slope_imm,

@@ -737,6 +737,49 @@ def test_head_behind_batchnorm_relu_without_the_activation_tensor(case):
         assert err < 2e-6, (what, err)
 
 
+@pytest.mark.parametrize('case', [(4, 16, 16, 24, 2), (2, 64, 64, 64, 1), (6, 8, 10, 12, 3), (16, 64, 128, 128, 2)], ids=lambda c: 'x'.join(map(str, c)))
+@pytest.mark.parametrize('use', ['both', 'pool_only', 'skip_only'])
+def test_encoder_tail_batchnorm_relu_maxpool_skip_as_one_node(case, use):
+    """BatchNorm2d(train) -> ReLU -> {MaxPool2d(2), skip connection} (reference Module.py:30-31 -> :43-44, :116-132):
+    ``ops.bn_relu_pool_skip`` (activation and pooled tensor from one read of z; backward recomputes argmax and ReLU gate from z and
+    never touches the activation or the summed gradient) against ``a = bn_act(z); (a, maxpool2(a))`` with autograd's accumulation.
+    Activation, pooled tensor and running statistics are bit-identical (same fma, same window order); the input / affine
+    gradients differ by the order of the fp64 channel sums only."""
+    ops = _ops()
+    N, C, H, W, G = case
+    z0 = rnd(N, C, H, W, seed=131)
+    gs = rnd(N, C, H, W, seed=132).cuda()
+    gp = rnd(N, C, H // 2, W // 2, seed=133).cuda()
+    res = {}
+    for tag in ('fused', 'separate'):
+        bn = torch.nn.BatchNorm2d(C).cuda().train()
+        with torch.no_grad():
+            bn.weight.copy_(rnd(C, seed=134).cuda() * 0.2 + 1.0)
+            bn.bias.copy_(rnd(C, seed=135).cuda() * 0.1)
+        zin = z0.cuda().requires_grad_(True)
+        z = zin * 1.0
+        if tag == 'fused':
+            assert ops.bn_relu_pool_skip_ok(z, bn, G)
+            a, p = ops.bn_relu_pool_skip(z, bn, groups=G)
+        else:
+            a = ops.bn_act(z, bn, ops.ACT_RELU, groups=G)
+            p = ops.maxpool2(a)
+        loss = 0.0
+        if use != 'pool_only':
+            loss = loss + (a * gs).sum()
+        if use != 'skip_only':
+            loss = loss + (p * gp).sum()
+        loss.backward()
+        res[tag] = [t.detach().cpu() for t in (a, p, bn.running_mean, bn.running_var, zin.grad, bn.weight.grad, bn.bias.grad)]
+        assert int(bn.num_batches_tracked) == G
+    names = ('a', 'pooled', 'running_mean', 'running_var', 'dz', 'dgamma', 'dbeta')
+    for x, r, what in zip(res['fused'][:4], res['separate'][:4], names[:4]):
+        assert torch.equal(x, r), what
+    for x, r, what in zip(res['fused'][4:], res['separate'][4:], names[4:]):
+        err = (x.double() - r.double()).abs().max().item() / max(r.double().abs().max().item(), 1e-30)
+        assert err < 2e-6, (what, err)
+
+
 def _split_modes_conv(ops, x, w, b):
     """y of the 3x3 layer with the F(4x4) GEMMs on the fp32 matrix pipe (mode 0) and on the two split-bf16 kernels."""
     lib = ops.lib
