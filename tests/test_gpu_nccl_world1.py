@@ -31,7 +31,8 @@ def _step(sync_bn, graphed=False, share=True, head_fused=True):
     # measures the SyncBN kernels and not the two ways of summing D's gradient (three RMSprop steps amplify those: D's loss
     # subtracts the two calls, the x-branch gradients nearly cancel)
     os.environ['FCD_D_SHARE'] = '1' if share else '0' 
-    # [r5] likewise the change-density head behind the last BatchNorm: per replica it runs inside the head's kernels
+    # [r5] likewise the change-density head behind the last BatchNorm and the encoder tails (ops.bn_relu_pool_skip: fp64 channel sums
+    # in another order): per replica the head runs inside the head's kernels
     # (ops.bn_relu_head: w[c] * sum instead of sum of w[c] * term in its gradients, ~1e-7 relative), under SyncBN as BatchNorm
     # kernels + head kernels.  head_fused=False gives the per-replica run in the SyncBN run's form (ops.bn_relu_head_ok reads the
     # switch per call; the BatchNorm-in-the-loader fusion of the 3x3 layers is bit-identical either way)
