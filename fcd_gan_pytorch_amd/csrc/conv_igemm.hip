@@ -1183,16 +1183,6 @@ static int launch_family(const ConvArgs& a, hipStream_t st) {
           (int64_t)a.N * cdiv(a.P, 8) * cdiv(a.Q, 32) * cdiv(a.K, 128) >= 2048)
         return launch_cfg<R, S, RCH, STRIDE, DIL, CB, 2, 4, 2, 2, 8, 32>(a, st);
     }
-    if constexpr (R == 3 && S == 3) {
-      // [r5] ... and 64 x 128 tiles when 128 x 128 ones leave most of the 256 CUs without a workgroup (the Discriminator's last
-      // stride-2 layer: 16 ... 24 images x 16 x 16 outputs x 512 filters = 128 ... 192 workgroups, ~200 us whatever the batch)
-      static int small = -1;
-      if (small < 0) { const char* e = getenv("FCD_CONV_SMALLTILE"); small = (e && e[0] == '0') ? 0 : 1; }
-      const int64_t wgs = (int64_t)a.N * (wide ? cdiv(a.P, 4) * cdiv(a.Q, 32) : cdiv(a.P, 8) * cdiv(a.Q, 16)) * cdiv(a.K, 128);
-      if (small && wgs < 256)
-        return wide ? launch_cfg<R, S, RCH, STRIDE, DIL, CB, 2, 1, 1, 4, 4, 32>(a, st)
-                    : launch_cfg<R, S, RCH, STRIDE, DIL, CB, 2, 1, 1, 4, 8, 16>(a, st);
-    }
     return wide ? launch_cfg<R, S, RCH, STRIDE, DIL, CB, 2, 2, 2, 2, 4, 32>(a, st)
                 : launch_cfg<R, S, RCH, STRIDE, DIL, CB, 2, 2, 2, 2, 8, 16>(a, st);
   } else if (a.K > 32) {
