@@ -25,6 +25,23 @@ def install_as_reference_modules():
     sys.modules['ssim'] = ssim
 
 
+_MODULE_CACHES = ('_fcd_folded', '_fcd_folded_key', '_fcd_raw_filters', '_fcd_w1')
+
+
+def invalidate_caches(*modules):
+    """Drop every derived buffer (packed / Winograd-transformed filters, BatchNorm-folded filters, the summed first VGG
+    filter) that ``modules`` and their parameters carry.  Never needed after ``optimizer.step()``, ``load_state_dict``, ``.to()``
+    or any in-place op on the parameters -- those bump ``tensor._version``, which every cache is keyed on.  Needed only after
+    an edit THROUGH ``param.data`` (``p.data.clamp_(-1, 1)``, the commented-out WGAN clip of the reference's Demo_RSSS.py:309-311):
+    ``.data`` has its own version counter, so neither autograd nor this package can see the change."""
+    from . import _ops
+    for m in modules:
+        _ops.invalidate_packs(list(m.parameters()) + list(m.buffers()))
+        for sub in m.modules():
+            for k in _MODULE_CACHES:
+                sub.__dict__.pop(k, None)
+
+
 def set_sync_batchnorm(enabled=True, group=None):
     """Optional SyncBN: train-mode BatchNorm statistics (and the two backward sums)
     are all-reduced over ``group`` so that a data-parallel run reproduces the single-device
