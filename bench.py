@@ -11,12 +11,19 @@ per GPU, gradients all-reduced over RCCL).
     backend nccl = RCCL); under torchrun (RANK / LOCAL_RANK / WORLD_SIZE set by the launcher) it is one of the ranks.
 
 Prints ONE JSON line on rank 0 (see the driver contract) with two extra objects:
-  roofline     -- the dominant kernel family (MFMA implicit-GEMM conv, forward +
-                  data-gradient launches) timed with HIP events on the launch stream
-                  over the timed region: algorithmic FLOPs / event time vs the fp32
-                  MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md)
+  roofline     -- the MFMA kernel family with the largest share of the step (today: the batched
+                  GEMMs of the Winograd F(4x4,3x3) layers), timed with HIP events on the launch
+                  stream in a second, profiled pass: executed FLOPs / event time against the peak
+                  of the matrix pipe the family REALLY runs on -- `pipe` says which: "bf16x6" =
+                  v_mfma_f32_32x32x16_bf16 on exact three-way operand splits, six bf16 products per
+                  fp32 multiply, priced as 6 x the fp32-equivalent FLOPs over the dense bf16 peak
+                  (2500 TFLOP/s); "fp32" = v_mfma_f32_*, priced over 157.3 TFLOP/s
+                  (MI355X_MICROARCH.md).  `other_mfma_kernels` lists the other families the same way.
   cpu_baseline -- the CPU oracle (port of the reference's step on stock torch CPU ops)
                   timed on this box's host cores on a bounded sample (rank 0, N=1 only)
+`config.arithmetic` is generated from the library's switch state (fcd_conv_wino_split_set /
+fcd_conv_wgrad_split_set), and `fp32_mfma_only` is the same step with BOTH of them off: every
+matrix instruction of the step on the fp32 pipe.
 """
 import argparse
 import json
@@ -45,6 +52,114 @@ WORKLOADS = {
     'wsss': (4, 3, 512, 4, 'Demo_WSSS adversarial step (S on the changed and the unchanged pair, D, eval-mode G, masked '
                            'MSE, MS-SSIM, RGB VGG16 perception, RMSprop)'),
 }
+
+
+def arithmetic_text(wino_split, wgrad_split):
+    """What the step computes in, from the state of the two pipe switches (never a hand-written claim)."""
+    base = 'fp32 tensors, fp32 accumulation everywhere.  Matrix pipes: '
+    split_how = ('v_mfma_f32_32x32x16_bf16 with every fp32 operand split EXACTLY into three bf16 parts and six partial products per '
+                 'multiply summed in fp32 (dropped terms <= 2^-24 relative: fp32-equivalent, measured error vs fp64 <= that of the fp32 '
+                 'MFMA path, tests/test_gpu_ops.py, tests/test_split_arithmetic.py)')
+    on_split, on_fp32 = [], ['the direct implicit-GEMM convolutions (forward / data gradient)', 'the fused F(2x2,3x3) kernel',
+                             'the thin-channel / 9x9 / 1x1 weight-gradient kernels']
+    (on_split if wino_split else on_fp32).append('the batched GEMMs of the Winograd F(4x4,3x3) layers (forward, data gradient, weight gradient)')
+    (on_split if wgrad_split else on_fp32).append('the NCHW-direct 3x3 weight-gradient kernel of the layers off the F(4x4) form '
+                                                  '(stride 2: on the split pipe regardless)' if wgrad_split else
+                                                  'the NCHW-direct 3x3 weight-gradient kernel (stride-1 layers; the stride-2 ones fall back '
+                                                  'to channel-minor copies + the fp32 kernel)')
+    txt = base + 'v_mfma_f32_* (fp32 matrix pipe) for ' + '; '.join(on_fp32) + '.'
+    if on_split:
+        txt += '  ' + split_how + ' for ' + '; '.join(on_split) + '.  `fp32_mfma_only` below is the same step with every one of those on the fp32 pipe.'
+    return txt
+
+
+def mfma_entry(name, pipe, ms, fp32_equiv_flops, launches, what, psteps, dt_prof):
+    """One roofline entry.  ``pipe`` 'fp32': executed FLOPs = the FLOPs given, peak 157.3; 'bf16x6': the kernel executes SIX bf16
+    MFMA FLOPs per fp32-equivalent FLOP and is priced on those against the dense bf16 peak."""
+    mult, peak = (6.0, PEAK_BF16_MFMA_TFLOPS) if pipe == 'bf16x6' else (1.0, PEAK_F32_MFMA_TFLOPS)
+    flops = mult * fp32_equiv_flops
+    ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    e = {'bound': 'mfma', 'kernel': name, 'pipe': pipe, 'flops_counted': what, 'achieved': ach,
+         'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
+         'traffic': None, 'launches_per_step': launches / psteps,
+         'avg_launch_ms': ms / max(launches, 1), 'gflop_per_launch': flops / max(launches, 1) / 1e9,
+         'share_of_step_time': ms / (1e3 * dt_prof) if dt_prof else None}
+    if pipe == 'bf16x6':
+        e['fp32_equivalent_tflops'] = ach / 6.0
+        e['fp32_equivalent_over_fp32_mfma_peak'] = ach / 6.0 / PEAK_F32_MFMA_TFLOPS
+        e['gflop_per_launch_fp32_equivalent'] = e['gflop_per_launch'] / 6.0
+    return e
+
+
+def roofline_entries(prof, psteps, dt_prof):
+    """The MFMA-bound kernel families of the profiled pass, each priced on the FLOPs its launches really issue against the peak of the
+    pipe they really run on, sorted by share of the step:
+      * conv_igemm*: direct implicit-GEMM convolution -> algorithmic FLOPs 2 N K P Q C R S, fp32 pipe
+      * wino_gemm: the batched GEMM of the Winograd path on the fp32 pipe -> 2 (m+2)^2 rows Kc T
+      * wino_gemm_bf16x6: the same GEMMs on the bf16 pipe (exact split) -> 6 x that
+      * conv_wgrad minus its nested Winograd and bf16-split parts: the fp32-pipe weight-gradient kernels (re-layout + reduce included)
+      * conv_wgrad_bf16x6: the NCHW-direct 3x3 weight-gradient kernel on the bf16 pipe -> 6 x the algorithmic weight-gradient FLOPs
+      * conv_wino2*: fused F(2x2,3x3), fp32 pipe, executed = algorithmic x 16/36"""
+    zero = dict(ms=0.0, launches=0, flops=0.0, bytes=0.0)
+    g = lambda k: prof.get(k, zero)
+    fwd, dg, wg = g('conv_igemm_fwd'), g('conv_igemm_dgrad'), g('conv_wgrad')
+    w2f, w2d = g('conv_wino2_fwd'), g('conv_wino2_dgrad')
+    wgemm, wsplit, wgw, wgs = g('wino_gemm'), g('wino_gemm_bf16x6'), g('conv_wgrad_wino'), g('conv_wgrad_bf16x6')
+    E = lambda *a: mfma_entry(*a, psteps, dt_prof)
+    cands = [
+        E('conv_igemm_kernel / conv_igemm_glds_kernel (direct fp32 MFMA implicit-GEMM convolution; forward + data-gradient launches)',
+          'fp32', fwd['ms'] + dg['ms'], fwd['flops'] + dg['flops'], fwd['launches'] + dg['launches'], 'algorithmic convolution FLOPs'),
+        E('wino_gemm_kernel (batched fp32 MFMA GEMM of the Winograd F(4x4,3x3) path; forward, data-gradient and weight-gradient launches)',
+          'fp32', wgemm['ms'], wgemm['flops'], wgemm['launches'], 'executed GEMM FLOPs'),
+        E('weight gradient, fp32-pipe kernels: conv_wgrad_roll_kernel / conv_wgrad_kernel / thin-channel and 9x9 kernels (+ channel-minor '
+          're-layout, split-K reduce).  The wide 3x3 layers take the Winograd F(4x4,3x3) form (priced under wino_gemm*, transforms under '
+          'kernel_families.wino_transform) and the NCHW-direct 3x3 kernel runs on the bf16 pipe (own entry): neither is in here',
+          'fp32', wg['ms'] - wgw['ms'] - wgs['ms'], wg['flops'] - wgw['flops'] - wgs['flops'],
+          wg['launches'] - wgw['launches'] - wgs['launches'], 'executed = algorithmic weight-gradient FLOPs of the layers on these kernels'),
+        E('wino_gemm_split256_kernel / wino_gemm_split_kernel / wino_gemm_split_res_kernel (batched GEMM of the Winograd F(4x4,3x3) path, '
+          'forward, data-gradient and weight-gradient launches, on the bf16 matrix pipe: every fp32 operand split exactly into three bf16 '
+          'parts, six partial products per multiply accumulated in fp32 -- fp32-equivalent results, tests/test_gpu_ops.py)',
+          'bf16x6', wsplit['ms'], wsplit['flops'], wsplit['launches'], 'executed bf16 MFMA FLOPs = 6 x the fp32-equivalent GEMM FLOPs'),
+        E('conv_wgrad_roll_nchw_kernel<split> (NCHW-direct 3x3 weight gradient, stride 1 and 2, on the bf16 matrix pipe: x and dY split '
+          'exactly into three bf16 parts in registers, six products per multiply accumulated in fp32)',
+          'bf16x6', wgs['ms'], wgs['flops'], wgs['launches'], 'executed bf16 MFMA FLOPs = 6 x the algorithmic weight-gradient FLOPs'),
+        E('conv_wino2_kernel (fused Winograd F(2x2,3x3): input transform + sixteen 16x16x4 fp32 MFMA GEMMs + output transform in one '
+          'kernel; the 64-row 3x3 layers, forward + data gradient)', 'fp32', w2f['ms'] + w2d['ms'],
+          (w2f['flops'] + w2d['flops']) * 16.0 / 36.0, w2f['launches'] + w2d['launches'],
+          'executed MFMA FLOPs (= algorithmic conv FLOPs x 16/36)'),
+    ]
+    cands = [e for e in cands if e['launches_per_step'] > 0]
+    cands.sort(key=lambda e: -(e['share_of_step_time'] or 0.0))
+    return cands
+
+
+def check_result_consistency(res):
+    """Self-consistency of an emitted bench line (tests/test_bench_launch.py runs it over the committed lines; main() over the
+    line it is about to print): every roofline entry is priced against the peak of the pipe it names."""
+    errs = []
+    rl = res.get('roofline')
+    for e in ([rl] + list(rl.get('other_mfma_kernels', []))) if rl else []:
+        peak = PEAK_BF16_MFMA_TFLOPS if e.get('pipe') == 'bf16x6' else PEAK_F32_MFMA_TFLOPS
+        if e.get('pipe') not in ('fp32', 'bf16x6'):
+            errs.append('%s: no pipe' % e['kernel'][:40])
+        if abs(e['peak'] - peak) > 1e-9:
+            errs.append('%s: pipe %s priced against %s' % (e['kernel'][:40], e.get('pipe'), e['peak']))
+        if abs(e['frac'] - e['achieved'] / e['peak']) > 1e-9 * max(1.0, e['frac']):
+            errs.append('%s: frac != achieved / peak' % e['kernel'][:40])
+        if e.get('pipe') == 'bf16x6' and abs(e['fp32_equivalent_tflops'] * 6.0 - e['achieved']) > 1e-6 * e['achieved']:
+            errs.append('%s: fp32-equivalent figure is not achieved / 6' % e['kernel'][:40])
+        if ('split' in e['kernel'].split('(')[0]) != (e.get('pipe') == 'bf16x6'):      # (the kernel names before the description)
+            errs.append('%s: kernel name and pipe disagree' % e['kernel'][:40])
+    sw = (res.get('config') or {}).get('pipes')
+    if sw is not None:
+        txt = res['config']['arithmetic']
+        if txt != arithmetic_text(sw['wino_split'], sw['wgrad_split']):
+            errs.append('config.arithmetic does not describe config.pipes')
+    if 'value' in res and 'ms_per_step' in res and res.get('config', {}).get('global_batch'):
+        v = res['config']['global_batch'] / (res['ms_per_step'] * 1e-3)
+        if abs(v - res['value']) > 1e-6 * v:
+            errs.append('value != global_batch / ms_per_step')
+    return errs
 
 
 def build_workload(args, dev, rank):
@@ -434,8 +549,10 @@ def main():
     # ---- the same K' steps with the Winograd GEMMs on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32) instead of the
     #      split-bf16 one: reported next to `value`, never as `value`
     alt = None
-    if not args.no_alt and _lib.lib.fcd_conv_wino_split_set(-1) == 1:
+    pipes = {'wino_split': int(_lib.lib.fcd_conv_wino_split_set(-1) != 0), 'wgrad_split': int(_lib.lib.fcd_conv_wgrad_split_set(-1) != 0)}
+    if not args.no_alt and (pipes['wino_split'] or pipes['wgrad_split']):
         _lib.lib.fcd_conv_wino_split_set(0)
+        _lib.lib.fcd_conv_wgrad_split_set(0)
         ksteps = max(1, min(args.steps, 3))
         was_graphed, gstep.enabled = gstep.enabled, False      # (the captured graph holds the split GEMM launches: this pass is eager)
         step()
@@ -445,13 +562,17 @@ def main():
             step()
         barrier()
         dta = time.perf_counter() - t1
-        _lib.lib.fcd_conv_wino_split_set(1)
+        _lib.lib.fcd_conv_wino_split_set(pipes['wino_split'])
+        _lib.lib.fcd_conv_wgrad_split_set(pipes['wgrad_split'])
         gstep.enabled = was_graphed
         if world > 1:
             t = torch.tensor([dta], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dta = float(t.item())
-        alt = {'what': 'same workload with FCD_WINO_SPLIT=0: the Winograd batched GEMMs on v_mfma_f32_32x32x2_f32 (round-1/2 path)',
+        alt = {'what': 'same workload with fcd_conv_wino_split_set(0) AND fcd_conv_wgrad_split_set(0): every matrix instruction of the step on the '
+                       'fp32 pipe (Winograd batched GEMMs on v_mfma_f32_32x32x2_f32, NCHW-direct 3x3 weight gradient on v_mfma_f32_32x32x2_f32; the '
+                       'stride-2 weight gradients through channel-minor copies + the fp32 kernel)',
+               'pipes': {'wino_split': 0, 'wgrad_split': 0},
                'value': args.batch * n_gpus * ksteps / dta, 'unit': 'tile-pairs/s', 'ms_per_step': 1e3 * dta / ksteps, 'steps': ksteps}
     # ---- profiled pass (not part of `value`): every launch bracketed by HIP events on its stream
     prof, detail, dt_prof, psteps = {}, [], None, 0
@@ -486,13 +607,7 @@ def main():
                        'baseline_config': 'BASELINE.json configs[%d]' % WORKLOADS[args.workload][0],
                        'tile_pairs_per_gpu': args.batch, 'global_batch': args.batch * n_gpus,
                        'parallelism': 'dp%d' % n_gpus, 'bn': 'per-replica statistics',
-                       'arithmetic': 'fp32 tensors, fp32 accumulation everywhere.  Matrix pipes: v_mfma_f32_* for the direct / '
-                                     'F(2x2) / weight-gradient kernels; the batched GEMMs of the Winograd F(4x4,3x3) layers run on '
-                                     'v_mfma_f32_32x32x16_bf16 with every fp32 operand split EXACTLY into three bf16 parts and six partial '
-                                     'products per multiply summed in fp32 (dropped terms <= 2^-24 relative: fp32-equivalent, measured '
-                                     'error vs fp64 <= that of the fp32 MFMA path, tests/test_gpu_ops.py); `fp32_mfma_only` below is the '
-                                     'same step with those GEMMs on the fp32 pipe' if _lib.lib.fcd_conv_wino_split_set(-1) == 1 else
-                                     'fp32 tensors, fp32 MFMA (v_mfma_f32_*), fp32 accumulation',
+                       'arithmetic': arithmetic_text(pipes['wino_split'], pipes['wgrad_split']), 'pipes': pipes,
                        'world_size': dist.get_world_size() if world > 1 else 1,
                        'backend': (dist.get_backend() if (world > 1 or forced) else 'none'),
                        'grad_exchange': ('bucketed all-reduce overlapped with backward' if world > 1 else
@@ -500,6 +615,8 @@ def main():
                                          if forced else 'none (1 rank)'),
                        'grad_exchange_last_step': exch},
             'losses_last_step': losses,
+            'peak_memory_bytes': {'allocated': int(torch.cuda.max_memory_allocated(dev)), 'reserved': int(torch.cuda.max_memory_reserved(dev)),
+                                  'note': 'torch caching allocator, this rank, whole run (all passes); of 288 GB HBM3E'},
             'launch': ('hipGraph replay: the whole step (forward, backward passes, optimizer kernels, BatchNorm statistics, filter re-packing) '
                        'captured once and replayed, %d replays / %d eager calls so far' % (gstep.replays, gstep.eager_calls)) if args.graph else
                       'launch by launch from Python (ctypes + autograd engine)',
@@ -516,51 +633,8 @@ def main():
             w2f, w2d = prof.get('conv_wino2_fwd', zero), prof.get('conv_wino2_dgrad', zero)
             wgemm, wxf = prof.get('wino_gemm', zero), prof.get('wino_transform', zero)
             wsplit = prof.get('wino_gemm_bf16x6', zero)
-            wgw_ = prof.get('conv_wgrad_wino', zero)
 
-            def mfma_entry(name, ms, flops, launches, what):
-                ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-                return {'bound': 'mfma', 'kernel': name, 'flops_counted': what, 'achieved': ach,
-                        'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS,
-                        'traffic': None, 'launches_per_step': launches / psteps,
-                        'avg_launch_ms': ms / max(launches, 1), 'gflop_per_launch': flops / max(launches, 1) / 1e9,
-                        'share_of_step_time': ms / (1e3 * dt_prof) if dt_prof else None}
-            # the MFMA-bound kernels of the step, each priced on the FLOPs its launches really issue:
-            #  * conv_igemm*: direct implicit-GEMM convolution -> algorithmic FLOPs 2 N K P Q C R S
-            #  * wino_gemm: the batched GEMM of the Winograd path -> 2 (m+2)^2 rows Kc T (= the algorithmic conv
-            #    FLOPs of those layers / 4 for F(4x4,3x3), plus tile padding)
-            #  * conv_wgrad: weight gradient (re-layout + reduce passes included in its time)
-            cands = [
-                mfma_entry('conv_igemm_kernel / conv_igemm_glds_kernel (direct fp32 MFMA implicit-GEMM convolution; forward + '
-                           'data-gradient launches)', fwd['ms'] + dg['ms'], fwd['flops'] + dg['flops'],
-                           fwd['launches'] + dg['launches'], 'algorithmic convolution FLOPs'),
-                mfma_entry('wino_gemm_kernel (batched fp32 MFMA GEMM of the Winograd F(4x4,3x3) path; forward, data-gradient '
-                           'and weight-gradient launches)', wgemm['ms'], wgemm['flops'], wgemm['launches'], 'executed GEMM FLOPs'),
-                mfma_entry('weight gradient, direct kernels: conv_wgrad_roll_kernel / conv_wgrad_kernel (+ re-layout, split-K reduce).  The '
-                           'wide 3x3 layers take the Winograd F(4x4,3x3) form instead: their GEMMs are priced under the wino_gemm* entry '
-                           'and their transforms under kernel_families.wino_transform, not here',
-                           wg['ms'] - wgw_['ms'], wg['flops'] - wgw_['flops'], wg['launches'] - wgw_['launches'],
-                           'executed = algorithmic weight-gradient FLOPs of the layers on the direct kernels'),
-            ]
-            if wsplit['launches'] > 0:
-                e = mfma_entry('wino_gemm_split256_kernel / wino_gemm_split_kernel (batched GEMM of the Winograd F(4x4,3x3) path, forward, '
-                               'data-gradient and weight-gradient launches, on the bf16 matrix pipe: every fp32 operand split exactly into three bf16 parts, six '
-                               'partial products per multiply accumulated in fp32 -- fp32-equivalent results, tests/test_gpu_ops.py)',
-                               wsplit['ms'], 6.0 * wsplit['flops'], wsplit['launches'],
-                               'executed bf16 MFMA FLOPs = 6 x the fp32-equivalent GEMM FLOPs')
-                e['peak'] = PEAK_BF16_MFMA_TFLOPS
-                e['frac'] = e['achieved'] / PEAK_BF16_MFMA_TFLOPS
-                e['fp32_equivalent_tflops'] = e['achieved'] / 6.0
-                e['fp32_equivalent_over_fp32_mfma_peak'] = e['achieved'] / 6.0 / PEAK_F32_MFMA_TFLOPS
-                e['gflop_per_launch_fp32_equivalent'] = e['gflop_per_launch'] / 6.0
-                cands.append(e)
-            if w2f['launches'] + w2d['launches'] > 0:
-                cands.append(mfma_entry('conv_wino2_kernel (fused Winograd F(2x2,3x3): input transform + sixteen 16x16x4 fp32 MFMA GEMMs + output '
-                                        'transform in one kernel; the 64-row 3x3 layers, forward + data gradient)', w2f['ms'] + w2d['ms'],
-                                        (w2f['flops'] + w2d['flops']) * 16.0 / 36.0, w2f['launches'] + w2d['launches'],
-                                        'executed MFMA FLOPs (= algorithmic conv FLOPs x 16/36)'))
-            cands = [e for e in cands if e['launches_per_step'] > 0]
-            cands.sort(key=lambda e: -(e['share_of_step_time'] or 0.0))
+            cands = roofline_entries(prof, psteps, dt_prof)
             res['roofline'] = cands[0]
             res['roofline']['other_mfma_kernels'] = cands[1:]
             # HBM bytes per launch of the direct-conv family from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate
@@ -594,8 +668,11 @@ def main():
                     key = ('wino_gemm_split' if e['kernel'].startswith('wino_gemm_split') else
                            'wino_gemm' if e['kernel'].startswith('wino_gemm') else
                            'conv_wino2' if e['kernel'].startswith('conv_wino2') else
+                           'conv_wgrad_split' if e['kernel'].startswith('conv_wgrad_roll_nchw') else
                            'conv_wgrad' if e['kernel'].startswith('weight gradient') else
                            'conv_igemm' if e['kernel'].startswith('conv_igemm') else None)
+                    if key not in FAMILIES:
+                        continue
                     if not key:
                         continue
                     alg_b = alg_bytes_per_call(key)
@@ -633,8 +710,9 @@ def main():
             for k in ('wino_gemm', 'wino_gemm_bf16x6', 'wino_transform'):
                 if k in res['kernel_families']:
                     res['kernel_families'][k]['nested_in'] = 'conv_wino_fwd + conv_wino_dgrad + conv_wgrad_wino'
-            if 'conv_wgrad_wino' in res['kernel_families']:
-                res['kernel_families']['conv_wgrad_wino']['nested_in'] = 'conv_wgrad'
+            for k in ('conv_wgrad_wino', 'conv_wgrad_bf16x6'):
+                if k in res['kernel_families']:
+                    res['kernel_families'][k]['nested_in'] = 'conv_wgrad'
             # the whole step on both FLOP counts: algorithmic = direct-convolution FLOPs of every conv launch;
             # executed = what the MFMA units are really asked to do (Winograd layers: the batched GEMM, 1/4 of the direct
             # count + tile padding); both over the HEADLINE step time (events off)
@@ -657,6 +735,9 @@ def main():
     if world > 1 or forced:
         dist.barrier()
     if rank == 0:
+        res['self_check'] = check_result_consistency(res)      # [] = every roofline entry priced against the pipe it runs on, text = switch state
+        if res['self_check']:
+            print('bench.py: inconsistent line: %s' % '; '.join(res['self_check']), file=sys.stderr)
         print(json.dumps(res), flush=True)
     if world > 1 or forced:
         dist.destroy_process_group()

@@ -18,6 +18,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import _lib
 from . import _ops as ops
 from .ssim import MS_SSIM
 
@@ -210,8 +211,8 @@ class PerceptionLoss(nn.Module):
 def masked_pair(target_image, generate_image, cmask):
     """``torch.cat([target_image * (1 - cmask), generate_image * (1 - cmask)], dim=0)`` -- the reference's
     ``mask_t = target * (1 - cmask).repeat(...)`` / ``mask_g`` (Loss.py:78-79,111-112) as one batch, from one HIP kernel
-    (``ops.masked_stack``; FCD_FUSED_GLUE=0: the ATen sequence)."""
-    if os.environ.get('FCD_FUSED_GLUE', '1') == '0' or not target_image.is_cuda:
+    (``ops.masked_stack``; switch FUSED_GLUE=0: the ATen sequence)."""
+    if not _lib.switch('FUSED_GLUE') or not target_image.is_cuda:
         keep = 1 - cmask
         return torch.cat([target_image * keep, generate_image * keep], dim=0)
     return ops.masked_stack([target_image, generate_image], cmask)
@@ -246,15 +247,15 @@ def mse_halves(f, nb):
     """mean((f[:nb] - f[nb:]) ** 2); ``f`` holds exactly ``2 * nb`` rows."""
     if f.shape[0] != 2 * nb:
         raise ValueError('mse_halves: %d rows for two halves of %d' % (f.shape[0], nb))
-    if os.environ.get('FCD_FUSED_GLUE', '1') == '0' or not f.is_cuda:
+    if not _lib.switch('FUSED_GLUE') or not f.is_cuda:
         return F.mse_loss(f[:nb], f[nb:])
     return _MseHalves.apply(f, nb)
 
 
 def _masked_ratio(a, b, m, kind, complement, scale, skip_zero):
-    """mean_i( num_i * scale / wsum_i ) of the masked sums -- one autograd node (``ops.masked_ratio_mean``); FCD_FUSED_GLUE=0: the
+    """mean_i( num_i * scale / wsum_i ) of the masked sums -- one autograd node (``ops.masked_ratio_mean``); switch FUSED_GLUE=0: the
     two halves through ATen (``ops.masked_sums`` + :func:`_per_sample_ratio`)."""
-    if os.environ.get('FCD_FUSED_GLUE', '1') == '0':
+    if not _lib.switch('FUSED_GLUE'):
         num, wsum = ops.masked_sums(a, b, m, kind, complement)
         return _per_sample_ratio(num, wsum, scale, skip_zero)
     return ops.masked_ratio_mean(a, b, m, kind, complement, scale, skip_zero)

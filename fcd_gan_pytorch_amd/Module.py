@@ -438,11 +438,11 @@ class Discriminator_SRGAN_simple(nn.Module):
     #  'diff'   -- the same order on ATen ops in fp32: (f_x - f_y).mean();
     #  'pooled' -- round 3: mean(f) of the whole batch first, then the difference of two ROUNDED means of nearly equal
     #              features (loses the bits the element-wise difference keeps).
-    POOL_MODE = os.environ.get('FCD_D_POOL', 'fused')
+    POOL_MODE = None          # None: follow the switch D_POOL (0 fused / 1 diff / 2 pooled); a string pins it for this class / instance
 
     def _classify_pairs(self, f, npairs):
         n = f.shape[0] // (2 * npairs)
-        mode = self.POOL_MODE
+        mode = self.POOL_MODE or ('fused', 'diff', 'pooled')[ops.switch('D_POOL')]
         if mode == 'fused':
             out = self.classify(ops.pair_gap_diff(f, npairs))
             return list(out.split(n, dim=0)) if npairs > 1 else [out]

@@ -17,6 +17,9 @@ from . import Module, Loss, ssim, optim, steps, dp, graph, tiles, metrics, datas
 
 __version__ = '0.1.0'
 
+from . import _ops as _ops_mod
+_ops_mod.install_foreign_optimizer_hook()      # stock torch.optim steps (incl. fused=True ones, which bump no version counter) invalidate the filter packs
+
 
 def install_as_reference_modules():
     """Register this package's modules under the reference's top-level names."""

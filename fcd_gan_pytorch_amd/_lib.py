@@ -62,6 +62,12 @@ _SIGS = {
     'fcd_version': (c_int, []),
     'fcd_build_hash': (c_char_p, []),
     'fcd_last_error_string': (c_char_p, []),
+    'fcd_switch_count': (c_int, []),
+    'fcd_switch_name': (c_char_p, [c_int]),
+    'fcd_switch_help': (c_char_p, [c_int]),
+    'fcd_switch_default': (c_int, [c_int]),
+    'fcd_switch_get': (c_int, [c_char_p]),
+    'fcd_switch_set': (c_int, [c_char_p, c_int]),
     'fcd_conv_packed_elems': (c_int64, [c_int, c_int, c_int, c_int, c_int]),
     'fcd_conv_pack_weights': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'fcd_conv2d_fwd': (c_int, [POINTER(ConvDesc), P, P, P, P, c_int, P]),
@@ -79,6 +85,7 @@ _SIGS = {
     'fcd_conv_wino_plan': (c_int, [POINTER(ConvDesc), c_int]),
     'fcd_conv_wino_set': (c_int, [c_int]),
     'fcd_conv_wino_split_set': (c_int, [c_int]),
+    'fcd_conv_wgrad_split_set': (c_int, [c_int]),
     'fcd_conv_wino_cat_ok': (c_int, [P]),
     'fcd_conv2d_fwd_wino_cat': (c_int, [P, P, P, c_int, P, P, P, c_int, P, c_size_t, P]),
     'fcd_conv2d_bwd_data_wino_cat': (c_int, [P, P, P, P, P, P, c_int, P, c_size_t, P]),
@@ -193,6 +200,45 @@ def _load():
 
 
 lib = _load()
+
+
+def switch(name):
+    """Current value of a run-time switch of csrc/switches.h (name with or without the FCD_ prefix)."""
+    v = lib.fcd_switch_get(name.encode())
+    if v < 0:
+        raise FcdError('unknown switch %r' % name)
+    return v
+
+
+def set_switch(name, value):
+    """Set a switch (``value`` < 0 or None: back to its default); returns the previous value."""
+    old = lib.fcd_switch_set(name.encode(), -1 if value is None else int(value))
+    if old < 0:
+        raise FcdError('unknown switch %r' % name)
+    return old
+
+
+class switched:
+    """``with switched(WGRAD_SPLIT=0, WINO_CHAIN=0): ...`` -- switches set for the block and restored after it (tests, A/B tools)."""
+
+    def __init__(self, **kv):
+        self.kv, self.old = kv, {}
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            self.old[k] = set_switch(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            set_switch(k, v)
+        return False
+
+
+def switch_table():
+    """[(name, value, default, help)] of every switch, in table order."""
+    return [(lib.fcd_switch_name(i).decode(), lib.fcd_switch_get(lib.fcd_switch_name(i)), lib.fcd_switch_default(i),
+             lib.fcd_switch_help(i).decode()) for i in range(lib.fcd_switch_count())]
 
 
 def build_hash():

@@ -12,7 +12,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import ConvDesc, check, lib
+from ._lib import ConvDesc, check, lib, switch
 
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_PRELU = 0, 1, 2, 3
 
@@ -225,7 +225,7 @@ def refresh_packs(params):
     """After an update of ``params`` (versions already bumped): every F(4x4) filter pack they held is re-packed IN PLACE by ONE launch
     (``fcd_conv_wino_pack_multi``: the Segmentor's 18 wide layers x {forward, data gradient} were 36 launches per step), every other
     pack is dropped as :func:`invalidate_packs` does.  With a second stream in play (``MULTI_STREAM``) nothing is re-used in place."""
-    if MULTI_STREAM or os.environ.get('FCD_PACK_MULTI') == '0':
+    if MULTI_STREAM or not switch('PACK_MULTI'):
         return invalidate_packs(params)
     split_now = lib.fcd_conv_wino_split_set(-1) != 0
     items = []
@@ -245,7 +245,7 @@ def refresh_packs(params):
             p.__dict__.pop('_fcd_pack', None)
     if not items:
         return
-    sig = tuple((p.data_ptr(), mode, buf.data_ptr()) for p, mode, buf in items) + (split_now,)
+    sig = tuple((p.data_ptr(), tuple(p.shape), mode, buf.data_ptr()) for p, mode, buf in items) + (split_now,)      # (K, C are baked into the table)
     hit = _PACK_TABLES.get(sig)
     if hit is None:
         rows, first, elems = [], 0, 0.0
@@ -263,6 +263,27 @@ def refresh_packs(params):
     table, n, total, elems = hit
     # (the parameters are contiguous slices of their optimizer's flat buffer: w is read where it lives)
     check(lib.fcd_conv_wino_pack_multi(_p(table), n, total, elems, _stream()), 'fcd_conv_wino_pack_multi')
+
+
+def _after_foreign_optimizer_step(optimizer, args, kwargs):
+    """Global ``torch.optim`` post-step hook (registered once by the package): every derived filter buffer of this package is keyed
+    on ``tensor._version``, and not every stock optimizer moves it -- the ``fused=True`` implementations (``torch._fused_adam_``,
+    ``_fused_sgd_`` ...) update the parameters in place WITHOUT touching the version counter (foreach / single-tensor ones do).
+    So after any ``torch.optim`` step the versions of the optimizer's device parameters are bumped here, and their F(4x4) filter
+    packs re-packed by one launch exactly as the fcd optimizers do (:func:`refresh_packs`).  tests/test_gpu_dropin.py."""
+    params = [p for g in optimizer.param_groups for p in g['params'] if isinstance(p, torch.Tensor) and p.is_cuda]
+    if params:
+        torch._C._increment_version(params)
+        refresh_packs(params)
+
+
+_HOOK = []
+
+
+def install_foreign_optimizer_hook():
+    if not _HOOK:
+        from torch.optim.optimizer import register_optimizer_step_post_hook
+        _HOOK.append(register_optimizer_step_post_hook(_after_foreign_optimizer_step))
 
 
 def _channel_sum(t, mask, N, C, HW):
@@ -289,7 +310,7 @@ class _Conv2d(torch.autograd.Function):
                                                    _p(bits), _stream()), 'fcd_conv2d_fwd_relu_bits')
             elif ctx.needs_input_grad[0] and not lib.fcd_conv_wino2_plan(ctypes.byref(d), 0):
                 nw = lib.fcd_conv_wino_relu_bits_bytes(ctypes.byref(d))
-                if nw and os.environ.get('FCD_WINO_RELU_BITS') != '0':
+                if nw and switch('WINO_RELU_BITS'):
                     # frozen F(4x4) layer (VGG16 of the perception term): 16 sign bits per output tile instead of y on the tape
                     wbits = torch.empty(nw // 2, dtype=torch.int16, device=x.device)
                     ws = _ws(lib.fcd_conv_wino_ws_bytes(ctypes.byref(d), 0), x.device)
@@ -415,7 +436,7 @@ class _ConvPairCat(torch.autograd.Function):
 
 def conv3x3_pair_cat_ok(f2n, up, weight):
     """True when :func:`conv3x3_pair_cat` can run this layer without the concatenated copy."""
-    if f2n.dim() != 4 or up.dim() != 4 or tuple(weight.shape[2:]) != (3, 3) or os.environ.get('FCD_PAIR_CAT') == '0':
+    if f2n.dim() != 4 or up.dim() != 4 or tuple(weight.shape[2:]) != (3, 3) or not switch('PAIR_CAT'):
         return False
     n, cu, H, W = up.shape
     c = f2n.shape[1]
@@ -498,7 +519,7 @@ class _ConvReluPool(torch.autograd.Function):
 
 def conv_relu_pool_supported(x, weight):
     K, C, R, S = weight.shape
-    if os.environ.get('FCD_NO_POOLFUSE'):          # A/B switch for benchmarking
+    if switch('NO_POOLFUSE'):          # A/B switch for benchmarking
         return False
     return (R == 3 and S == 3 and K > 32 and C > 32 and not weight.requires_grad
             and x.shape[2] >= 2 and x.shape[3] >= 2)
@@ -542,7 +563,7 @@ def frozen_chain_ok(x, weights):
     """True when :func:`frozen_conv_chain` can run ``weights`` (frozen 3x3 filters, >= 2 layers) as one run on ``x``: the
     forward run qualifies, and its data gradient is an F(4x4) run over all layers but at most the first (whose own kernel
     then receives an already gated gradient)."""
-    if os.environ.get('FCD_WINO_CHAIN') == '0' or len(weights) < 2 or len(weights) > 8 or not x.is_cuda or x.dim() != 4:
+    if not switch('WINO_CHAIN') or len(weights) < 2 or len(weights) > 8 or not x.is_cuda or x.dim() != 4:
         return False
     if any(w.requires_grad or tuple(w.shape[2:]) != (3, 3) for w in weights):
         return False
@@ -1109,7 +1130,7 @@ def bn_relu_pool_skip_ok(z, bn, groups=1):
     """True when ``a = bn_act(z, bn, ACT_RELU, groups); (a, maxpool2(a))`` can run as :func:`bn_relu_pool_skip`."""
     if not (torch.is_tensor(z) and z.is_cuda and z.dim() == 4 and z.dtype == torch.float32):
         return False
-    if os.environ.get('FCD_BN_FUSE') == '0' or _sync_world():
+    if not switch('BN_FUSE') or _sync_world():
         return False
     if not (bn.training or bn.running_mean is None) or bn.weight is None or bn.bias is None:
         return False
@@ -1135,7 +1156,7 @@ def bn_relu_head_ok(z, bn, weight, groups=1):
     """True when ``conv1x1_head(bn_act(z, bn, ACT_RELU, groups=groups), weight, bias)`` can run as :func:`bn_relu_head`."""
     if not (torch.is_tensor(z) and z.is_cuda and z.dim() == 4 and z.dtype == torch.float32):
         return False
-    if os.environ.get('FCD_BN_FUSE') == '0' or _sync_world():
+    if not switch('BN_FUSE') or _sync_world():
         return False
     if not (bn.training or bn.running_mean is None) or bn.weight is None or bn.bias is None or z.shape[0] % groups:
         return False

@@ -7,6 +7,7 @@
 #include <algorithm>
 
 #include "../../include/fcdgan_hip.h"
+#include "switches.h"
 
 #define FCD_WAVE 64
 
@@ -51,7 +52,9 @@ enum {
   FCD_K_WINO2_DGRAD = 15,
   FCD_K_WINO_GEMM_SPLIT = 16, // nested in 9/10: the batched GEMM on the bf16 matrix pipe (exact three-way operand split);
                               // FLOPs = fp32-equivalent GEMM FLOPs (the bf16 MFMAs execute 6x that)
-  FCD_K_COUNT = 17
+  FCD_K_WGRAD_SPLIT = 17,     // nested in 2: the NCHW-direct 3x3 weight-gradient kernel on the bf16 matrix pipe (exact three-way split of
+                              // x and dY); FLOPs = fp32-equivalent weight-gradient FLOPs (the bf16 MFMAs execute 6x that)
+  FCD_K_COUNT = 18
 };
 
 struct FcdProfScope {

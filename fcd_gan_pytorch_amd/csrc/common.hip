@@ -21,6 +21,77 @@ extern "C" int fcd_version(void) { return 100; }
 #include "build/build_hash.h"
 extern "C" const char* fcd_build_hash(void) { return FCD_BUILD_HASH; }
 
+// --------------------------------------------------------------------------- run-time switches (switches.h)
+#include <stdlib.h>
+
+int g_fcd_switch[FCD_SW_COUNT];
+namespace {
+struct SwitchRow { const char* name; int def; const char* help; };
+const SwitchRow kSwitches[FCD_SW_COUNT] = {
+#define FCD_SW_ROW(NAME, DEF, HELP) {#NAME, DEF, HELP},
+    FCD_SWITCH_TABLE(FCD_SW_ROW)
+#undef FCD_SW_ROW
+};
+// value of a switch after range rules that used to live next to each getenv
+int switch_clean(int id, int v) {
+  switch (id) {
+    case FCD_SW_WINO: return (v == 0 || v == 2 || v == 4) ? v : 4;
+    case FCD_SW_WINO_SPLIT: return v < 0 ? 1 : (v > 2 ? 1 : v);
+    case FCD_SW_THIN_MFMA: return v < 0 ? 0 : v;
+    case FCD_SW_WGRAD_WGS: return v < 1 ? 512 : v;
+    case FCD_SW_WINO_WG_WGS: return v < 0 ? 0 : v;
+    case FCD_SW_WINO2_WAVES: return (v == 1 || v == 4) ? v : 8;
+    case FCD_SW_WINO2_KS: return (v == 1 || v == 3) ? v : 2;
+    case FCD_SW_D_POOL: return (v == 1 || v == 2) ? v : 0;
+    default: return v;
+  }
+}
+int switch_parse(int id, const char* e) {
+  if (id == FCD_SW_D_POOL) {       // historical spellings
+    if (!strcmp(e, "fused")) return 0;
+    if (!strcmp(e, "diff")) return 1;
+    if (!strcmp(e, "pooled")) return 2;
+  }
+  return atoi(e);
+}
+// the environment is read HERE, once, when the library is mapped -- and nowhere else
+__attribute__((constructor)) void fcd_switches_from_environment() {
+  char var[64];
+  for (int i = 0; i < FCD_SW_COUNT; ++i) {
+    snprintf(var, sizeof(var), "FCD_%s", kSwitches[i].name);
+    const char* e = getenv(var);
+    g_fcd_switch[i] = switch_clean(i, (e && e[0]) ? switch_parse(i, e) : kSwitches[i].def);
+  }
+}
+int switch_index(const char* name) {
+  if (!name) return -1;
+  if (!strncmp(name, "FCD_", 4)) name += 4;
+  for (int i = 0; i < FCD_SW_COUNT; ++i)
+    if (!strcmp(name, kSwitches[i].name)) return i;
+  return -1;
+}
+}  // namespace
+
+extern "C" int fcd_switch_count(void) { return FCD_SW_COUNT; }
+extern "C" const char* fcd_switch_name(int i) { return (i >= 0 && i < FCD_SW_COUNT) ? kSwitches[i].name : nullptr; }
+extern "C" const char* fcd_switch_help(int i) { return (i >= 0 && i < FCD_SW_COUNT) ? kSwitches[i].help : nullptr; }
+extern "C" int fcd_switch_default(int i) { return (i >= 0 && i < FCD_SW_COUNT) ? kSwitches[i].def : 0; }
+// current value by name ("WGRAD_SPLIT" or "FCD_WGRAD_SPLIT"); FCD_ERR_INVALID for an unknown name (no switch is negative)
+extern "C" int fcd_switch_get(const char* name) {
+  const int i = switch_index(name);
+  FCD_CHECK_ARG(i >= 0, "fcd_switch_get: unknown switch '%s'", name ? name : "(null)");
+  return g_fcd_switch[i];
+}
+// set by name, returns the previous value (value < 0: restore the default).  Not synchronised with launches in flight on other
+// threads: switches are for A/B runs and tests.
+extern "C" int fcd_switch_set(const char* name, int value) {
+  const int i = switch_index(name);
+  FCD_CHECK_ARG(i >= 0, "fcd_switch_set: unknown switch '%s'", name ? name : "(null)");
+  const int old = g_fcd_switch[i];
+  g_fcd_switch[i] = switch_clean(i, value < 0 ? kSwitches[i].def : value);
+  return old;
+}
+
 // ---------------------------------------------------------------------------
 namespace {
 struct Pending {
@@ -43,7 +114,7 @@ double g_ms[FCD_K_COUNT], g_launches[FCD_K_COUNT], g_flops[FCD_K_COUNT], g_bytes
 const char* kNames[FCD_K_COUNT] = {"conv_igemm_fwd", "conv_igemm_dgrad", "conv_wgrad", "pack_weights",
                                    "norm_act",       "pool_resize",      "loss",       "optim",
                                    "misc", "conv_wino_fwd", "conv_wino_dgrad", "wino_gemm", "wino_transform",
-                                   "conv_wgrad_wino", "conv_wino2_fwd", "conv_wino2_dgrad", "wino_gemm_bf16x6"};
+                                   "conv_wgrad_wino", "conv_wino2_fwd", "conv_wino2_dgrad", "wino_gemm_bf16x6", "conv_wgrad_bf16x6"};
 
 hipEvent_t get_event() {
   if (!g_free_events.empty()) {

@@ -271,12 +271,7 @@ __global__ __launch_bounds__(256) void head_bn_apply_kernel(const float* __restr
 }  // namespace
 
 extern "C" int fcd_conv1x1_head_plan(int N, int C, int HW, int K) {
-  static int on = -1;
-  if (on < 0) {
-    const char* e = getenv("FCD_CONV_HEAD");
-    on = (e && e[0] == '0') ? 0 : 1;
-  }
-  return (on && K == 1 && N > 0 && N <= 65535 && C >= 8 && C <= 65534 && HW >= 1024 && (HW & 3) == 0) ? 1 : 0;
+  return (fcd_sw(FCD_SW_CONV_HEAD) && K == 1 && N > 0 && N <= 65535 && C >= 8 && C <= 65534 && HW >= 1024 && (HW & 3) == 0) ? 1 : 0;
 }
 
 extern "C" int fcd_conv1x1_head_fwd(const float* x, const float* w, const float* bias, float* y, int N, int C, int HW, int sigmoid,

@@ -1099,14 +1099,7 @@ extern "C" int fcd_conv_pack_weights(const float* w, float* wp, int K, int C, in
 
 // ---------------------------------------------------------------------------
 // dispatch
-static int xcd_remap_on() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("FCD_CONV_XCD");
-    v = (e && e[0] == '0') ? 0 : 1;
-  }
-  return v;
-}
+static int xcd_remap_on() { return fcd_sw(FCD_SW_CONV_XCD); }
 
 template <int R, int S, int RCH, int STRIDE, int DIL, int CB, int MI, int NI, int WM, int WN, int TH,
           int TW>
@@ -1153,23 +1146,9 @@ static int launch_cfg(const ConvArgs& a0, hipStream_t st) {
   }
 }
 
-static int thin_fwd_on() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("FCD_CONV_THINFWD");
-    v = (e && e[0] == '0') ? 0 : 1;
-  }
-  return v;
-}
+static int thin_fwd_on() { return fcd_sw(FCD_SW_CONV_THINFWD); }
 
-static int big_tiles_on() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("FCD_CONV_BIG");
-    v = (e && e[0] == '0') ? 0 : 1;
-  }
-  return v;
-}
+static int big_tiles_on() { return fcd_sw(FCD_SW_CONV_BIG); }
 
 template <int R, int S, int RCH, int STRIDE, int DIL, int CB>
 static int launch_family(const ConvArgs& a, hipStream_t st) {
@@ -1203,9 +1182,7 @@ static int conv_dispatch(const ConvArgs& a, int R, int S, int stride, int dil, h
   if (R == 3 && S == 3 && stride == 2 && dil == 1) return launch_family<3, 3, 3, 2, 1, 8>(a, st);
   if (R == 3 && S == 3 && stride == 1 && dil == 2) return launch_family<3, 3, 3, 1, 2, 8>(a, st);
   if (R == 9 && S == 9 && stride == 1 && dil == 1) {
-    static int rows16 = -1;
-    if (rows16 < 0) { const char* e = getenv("FCD_CONV_ROWS16"); rows16 = (e && e[0] == '0') ? 0 : 1; }
-    if (rows16 && a.K <= 16 && !a.mask && !a.pool_code_in && !a.shuf_C) {       // 16-row MFMA tiles
+    if (fcd_sw(FCD_SW_CONV_ROWS16) && a.K <= 16 && !a.mask && !a.pool_code_in && !a.shuf_C) {       // 16-row MFMA tiles
       ConvArgs b = a;
       const bool wide = a.Q > 16;
       b.tiles_p = cdiv(a.P, wide ? 8 : 16);
@@ -1485,12 +1462,7 @@ __global__ void pack_weights_s2t_kernel(const float* __restrict__ w, float* __re
 }
 
 extern "C" int fcd_conv_s2_dgrad_plan(const fcd_conv_desc* d) {
-  static int on = -1;
-  if (on < 0) {
-    const char* e = getenv("FCD_S2_SUBPIXEL");
-    on = (e && e[0] == '0') ? 0 : 1;
-  }
-  return (on && d && d->R == 3 && d->S == 3 && d->stride == 2 && d->pad == 1 && d->C >= 8) ? 1 : 0;
+  return (fcd_sw(FCD_SW_S2_SUBPIXEL) && d && d->R == 3 && d->S == 3 && d->stride == 2 && d->pad == 1 && d->C >= 8) ? 1 : 0;
 }
 
 static int64_t s2_rows_elems(int K, int C) { return (int64_t)round_up(K, 8) * 4 * round_up(4 * C, 128); }
@@ -1527,9 +1499,8 @@ extern "C" int fcd_conv2d_bwd_data_s2(const fcd_conv_desc* d, const float* dy, c
   const double flops = 2.0 * d->N * d->K * (double)d->P * d->Q * d->C * 9;
   const double bytes = 4.0 * ((double)d->N * d->C * d->H * d->W + (double)d->N * d->K * d->P * d->Q + (double)d->K * d->C * 9);
   FcdProfScope prof(FCD_K_CONV_DGRAD, (hipStream_t)stream, flops, bytes, fcd_prof_tag_desc("dgrad_s2sub", d));
-  static int glds = -1;      // FCD_S2_GLDS=0: the register-staged kernel for every layer
-  if (glds < 0) { const char* e = getenv("FCD_S2_GLDS"); glds = (e && e[0] == '0') ? 0 : 1; }
-  if (glds && !relu_out && a.K > 64) {
+  if (fcd_sw(FCD_SW_S2_GLDS) &&      // S2_GLDS=0: the register-staged kernel for every layer
+      !relu_out && a.K > 64) {
     a.wp = wp_s2 + s2_rows_elems(d->K, d->C);
     a.nchunks = cdiv(a.C, 8);
     const bool wide = a.Q > 16;

@@ -391,15 +391,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dgrad_c1_mfma_kernel(const flo
 // mask): VALU 1.14 ms; MFMA 8 rows 0.84, 16 rows 0.76, 32 rows 0.74 (4.7 TB/s of the gradient it reads).  The same idea for
 // the FORWARD of this layer (taps as the MFMA's k dimension, 48 MFMAs per 64-pixel row segment) lost: 1.03 vs 0.85 ms --
 // that kernel is bound by its 64 scattered output planes, not by the 576 FMAs per pixel
-static int thin_mfma_rows() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("FCD_THIN_MFMA");
-    v = e ? atoi(e) : 32;
-    if (v < 0) v = 0;
-  }
-  return v;
-}
+static int thin_mfma_rows() { return fcd_sw(FCD_SW_THIN_MFMA); }
 
 // returns 0 when handled, 1 when the shape is not a thin-channel case
 int fcd_try_dgrad_thin(const fcd_conv_desc* d, const float* dy, const float* relu_out, const float* wp_bwd, float* dx,

@@ -18,6 +18,8 @@
 // LDS double-buffered, one barrier per pixel tile.  Split-K over pixel tiles across
 // workgroups; partial slabs are summed by a second kernel (deterministic, no atomics).
 #include "common.h"
+
+#include <optional>
 #include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -825,15 +827,7 @@ struct WgradPlan {
 // Workgroups the split count aims at (FCD_WGRAD_WGS for A/B).  [r4] 512 = ONE round of the 512 resident slots (two 59-KB workgroups per CU):
 // every workgroup pays a prologue and a 147-KB partial store, and every split adds a pass to the reduction -- 1024 (rounds 1-3) measured
 // 0.30 / 0.25 / 0.23 ms on the Discriminator's stride-2 layers against 0.27 / 0.23 / 0.21 with 512, 2048: 0.36 / 0.33 / 0.29.
-static int wgrad_target_wgs() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("FCD_WGRAD_WGS");
-    v = e ? atoi(e) : 512;
-    if (v < 1) v = 512;
-  }
-  return v;
-}
+static int wgrad_target_wgs() { return fcd_sw(FCD_SW_WGRAD_WGS); }
 
 static bool wgrad_plan(const fcd_conv_desc* d, WgradPlan* pl) {
   const int R = d->R, S = d->S, st = d->stride;
@@ -896,30 +890,20 @@ extern "C" size_t fcd_conv2d_bwd_weight_ws_bytes(const fcd_conv_desc* d) {
                                     fcd_wino_wgrad_ws_bytes(d)), fcd_wgrad_thin_ws_bytes(d)), fcd_wgrad_thin9_ws_bytes(d));
 }
 
-static int wgrad_tkc() {       // FCD_WGRAD_TKC=0: split partials in dw's own layout (round-3 behaviour)
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("FCD_WGRAD_TKC");
-    v = (e && e[0] == '0') ? 0 : 1;
-  }
-  return v;
+static int wgrad_tkc() { return fcd_sw(FCD_SW_WGRAD_TKC); }      // 0: split partials in dw's own layout (round-3 behaviour)
+
+static int wgrad_roll() { return fcd_sw(FCD_SW_WGRAD_ROLL); }
+
+extern "C" int fcd_conv_wgrad_split_set(int on) {
+  const int old = fcd_sw(FCD_SW_WGRAD_SPLIT);
+  if (on >= 0) g_fcd_switch[FCD_SW_WGRAD_SPLIT] = on ? 1 : 0;
+  return old;
 }
 
-static int wgrad_roll() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("FCD_WGRAD_ROLL");
-    v = (e && e[0] == '0') ? 0 : 1;
-  }
-  return v;
-}
-
-// FCD_WGRAD_NCHW=0: channel-minor copies + conv_wgrad_roll_kernel for every 3x3 / stride-1 layer (rounds 1-4).  Read per call (tests switch it).
+// WGRAD_NCHW=0: channel-minor copies + conv_wgrad_roll_kernel for every 3x3 / stride-1 layer (rounds 1-4)
 static bool wgrad_nchw_ok(const fcd_conv_desc* d, const WgradPlan& pl, const float* x, const float* dy, const float* relu_out) {
-  const char* e = getenv("FCD_WGRAD_NCHW");
-  if (e && e[0] == '0') return false;
-  const char* sp = getenv("FCD_WGRAD_SPLIT");
-  const bool split = !(sp && sp[0] == '0');
+  if (!fcd_sw(FCD_SW_WGRAD_NCHW)) return false;
+  const bool split = fcd_sw(FCD_SW_WGRAD_SPLIT) != 0;
   const bool geom = d->stride == 1 ? (pl.TW == 32 && (d->W % 32) == 0)
                                    : (d->stride == 2 && split && pl.TW == 16 && (d->W % 8) == 0 && d->Q == d->W / 2);     // [r5] stride 2: bf16 pipe only
   return d->R == 3 && d->S == 3 && d->pad == 1 && geom && relu_out == nullptr &&
@@ -1027,10 +1011,15 @@ extern "C" int fcd_conv2d_bwd_weight_bias(const fcd_conv_desc* d, const float* x
   if (nchw) {
     a.x = x; a.dy = dy; a.db_part = db ? psum : nullptr;
     dim3 grid((unsigned)(pl.k_tiles * pl.c_tiles), (unsigned)pl.splits, 1);
-    const char* e = getenv("FCD_WGRAD_SPLIT");        // =0: the fp32 matrix pipe (A/B, tests)
-    if (d->stride == 2) hipLaunchKernelGGL((conv_wgrad_roll_nchw_kernel<true, 2>), grid, dim3(256), 0, st, a);
-    else if (e && e[0] == '0') hipLaunchKernelGGL((conv_wgrad_roll_nchw_kernel<false, 1>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((conv_wgrad_roll_nchw_kernel<true, 1>), grid, dim3(256), 0, st, a);
+    const bool bf16_pipe = d->stride == 2 || fcd_sw(FCD_SW_WGRAD_SPLIT);      // WGRAD_SPLIT=0: the fp32 matrix pipe (A/B, tests, bench.py fp32_mfma_only)
+    {
+      // nested in the call's FCD_K_CONV_WGRAD scope: the launch on the bf16 pipe, so that a report can price it against that peak
+      std::optional<FcdProfScope> ps;
+      if (bf16_pipe) ps.emplace(FCD_K_WGRAD_SPLIT, st, flops, bytes);
+      if (d->stride == 2) hipLaunchKernelGGL((conv_wgrad_roll_nchw_kernel<true, 2>), grid, dim3(256), 0, st, a);
+      else if (!bf16_pipe) hipLaunchKernelGGL((conv_wgrad_roll_nchw_kernel<false, 1>), grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((conv_wgrad_roll_nchw_kernel<true, 1>), grid, dim3(256), 0, st, a);
+    }
     if (db) hipLaunchKernelGGL(channel_psum_fin_kernel, dim3(d->K), dim3(256), 0, st, (const float*)psum, db, d->K, pl.Kp, pl.splits);
   } else if (R == 3 && S == 3 && sd == 1 && d->pad == 1 && wgrad_roll()) {
     // p-fastest tile order + rolling 4-row ring (see conv_wgrad_roll_kernel)

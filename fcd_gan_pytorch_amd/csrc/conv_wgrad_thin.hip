@@ -235,14 +235,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_finish_kernel(const float
   else if (db) db[k] = s;
 }
 
-int wt_env() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("FCD_WGRAD_THIN");
-    v = (e && e[0] == '0') ? 0 : 1;
-  }
-  return v;
-}
+int wt_env() { return fcd_sw(FCD_SW_WGRAD_THIN); }
 constexpr int WT_MAX_PARTS = 512;
 }  // namespace
 

@@ -241,14 +241,7 @@ __global__ void thin9_bias_fin_kernel(const double* __restrict__ part, float* __
   db[k] = (float)s;
 }
 
-int t9_env() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("FCD_WGRAD_THIN9");
-    v = (e && e[0] == '0') ? 0 : 1;
-  }
-  return v;
-}
+int t9_env() { return fcd_sw(FCD_SW_WGRAD_THIN9); }
 }  // namespace
 
 // 1: first-layer form (<= 4 input channels, <= 64 filters), 2: last-layer form (<= 64 input channels, <= 4 filters), 0: not this kernel

@@ -1280,25 +1280,14 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split256_kernel(WinoGemmArgs
 #undef Y_DMA
 }
 
-static int wino_gemm_cfg() {     // FCD_WINO_TILE: 0 = 128x128 (4 waves), 1 = 256x128 (8 waves), 2 = 256x256 (16 waves)
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("FCD_WINO_TILE");
-    v = e ? atoi(e) : 0;
-  }
-  return v;
-}
+static int wino_gemm_cfg() { return fcd_sw(FCD_SW_WINO_TILE); }     // 0 = 128x128 (4 waves), 1 = 256x128 (8 waves), 2 = 256x256 (16 waves)
 
 // Batches (transform positions) per workgroup.  The per-batch pipeline is only Kc / 32 stages long (2 ... 16 for the VGG
 // layers), so its fill and the C-tile store are a large share of a workgroup's life; chaining xb batches into one
 // pipeline pays them once.  Keep >= ~4 full rounds of the 512 resident workgroup slots (256 CUs x 2) so that the
 // tail stays small.  FCD_WINO_XB forces a value (1 = one batch per workgroup, the round-1 behaviour).
 static int wino_gemm_xb(long long tiles, int batches, int splits, int q_stages) {
-  static int forced = -1;
-  if (forced < 0) {
-    const char* e = getenv("FCD_WINO_XB");
-    forced = e ? atoi(e) : 0;
-  }
+  const int forced = fcd_sw(FCD_SW_WINO_XB);
   if (forced > 0) return std::min(forced, batches);
   if (q_stages & 1) return 1;          // the two LDS stages alternate: a batch must start on stage 0
   static const int cand[] = {36, 18, 12, 9, 6, 4, 3, 2};
@@ -1311,26 +1300,18 @@ static int wino_gemm_xb(long long tiles, int batches, int splits, int q_stages) 
 
 // FCD_WINO_SPLIT / fcd_conv_wino_split_set: 1 (default) = conv / data-gradient GEMMs on the bf16 matrix pipe with exact
 // three-way operand splitting (wino_gemm_split_kernel), 0 = v_mfma_f32_32x32x2_f32 (wino_gemm_kernel)
-static int g_wino_split = -1;
-static int wino_split() {
-  if (g_wino_split < 0) {
-    const char* e = getenv("FCD_WINO_SPLIT");
-    g_wino_split = e ? atoi(e) : 1;
-  }
-  return g_wino_split;
-}
+static int wino_split() { return fcd_sw(FCD_SW_WINO_SPLIT); }
 static int wino_split_state() { return wino_split(); }
 extern "C" int fcd_conv_wino_split_set(int on) {
   const int old = wino_split();
-  if (on >= 0) g_wino_split = on > 2 ? 1 : on;      // 2: as 1, and the 256 x 256 kernel for every GEMM with >= 256 rows (tests)
+  if (on >= 0) g_fcd_switch[FCD_SW_WINO_SPLIT] = on > 2 ? 1 : on;      // 2: as 1, and the 256 x 256 kernel for every GEMM with >= 256 rows (tests)
   return old;
 }
 
 static int wino_xcd();
 // few tiles per transform position: all tiles of a position group on one XCD (wino_gemm_block mode 2; FCD_WINO_XCD2=0: off)
 static int wino_xcd_mode(int tiles, int groups) {
-  static int max_tiles = -1;      // FCD_WINO_XCD2=<n>: largest tile count per group that takes mode 2 (0: never)
-  if (max_tiles < 0) { const char* e = getenv("FCD_WINO_XCD2"); max_tiles = e ? atoi(e) : 128; }
+  const int max_tiles = fcd_sw(FCD_SW_WINO_XCD2);      // largest tile count per group that takes mode 2 (0: never)
   if (!wino_xcd()) return 0;
   return (tiles <= max_tiles && groups >= 8) ? 2 : 1;
 }
@@ -1349,21 +1330,17 @@ static void wino_gemm_launch(WinoGemmArgs ga, int batches, int splits, hipStream
       return;
     }
     // [r3] one row tile, short reduction, M in blocks: the filter-resident kernel (FCD_WINO_RES=0: off)
-    static int res = -1;
-    if (res < 0) { const char* e = getenv("FCD_WINO_RES"); res = (e && e[0] == '0') ? 0 : 1; }
-    if (res && ga.c_blk && ga.M <= 128 && ga.Kc <= 128 && (long long)cdiv(ga.N, 256) * batches >= 512) {
+    if (fcd_sw(FCD_SW_WINO_RES) && ga.c_blk && ga.M <= 128 && ga.Kc <= 128 && (long long)cdiv(ga.N, 256) * batches >= 512) {
       ga.m_tiles = 1; ga.n_tiles = cdiv(ga.N, 256);
       ga.xb = 1;
-      static int wgs = -1;           // workgroups in flight: one per CU (FCD_WINO_RES_WGS for A/B)
-      if (wgs < 0) { const char* e = getenv("FCD_WINO_RES_WGS"); wgs = e ? atoi(e) : 256; }
+      const int wgs = fcd_sw(FCD_SW_WINO_RES_WGS);           // workgroups in flight: one per CU
       const int chunks = std::max(1, std::min(ga.n_tiles, wgs / batches));
       hipLaunchKernelGGL(wino_gemm_split_res_kernel, dim3((unsigned)chunks, (unsigned)batches), dim3(512), 0, st, ga);
       return;
     }
     // FCD_WINO_SPLIT_BIG: 0 = 128 x 128 tiles only; 1 (default) = 256 x 256 two-stage kernel for GEMMs with >= 256
     // rows and enough tiles to fill the chip; 2 = ... for every GEMM with >= 256 rows (tests)
-    static int big = -1;
-    if (big < 0) { const char* e = getenv("FCD_WINO_SPLIT_BIG"); big = e ? atoi(e) : 1; }
+    const int big = fcd_sw(FCD_SW_WINO_SPLIT_BIG);
     const bool force = big == 2 || wino_split() == 2;
     if (big && ga.M >= 256 && (force || (long long)cdiv(ga.M, 256) * cdiv(ga.N, 256) * batches >= 1024)) {
       ga.m_tiles = cdiv(ga.M, 256); ga.n_tiles = cdiv(ga.N, 256);
@@ -1593,16 +1570,7 @@ __global__ __launch_bounds__(256) void wino_output_blk_bn_kernel(WinoOutArgs a) 
 
 // --------------------------------------------------------------------------------------------
 // host side
-static int g_wino_mode = -1;   // -1: not initialised (FCD_WINO env, default 4)
-static int wino_env() {
-  if (g_wino_mode < 0) {
-    const char* e = getenv("FCD_WINO");
-    int v = e ? atoi(e) : 4;
-    if (v != 0 && v != 2 && v != 4) v = 4;
-    g_wino_mode = v;
-  }
-  return g_wino_mode;
-}
+static int wino_env() { return fcd_sw(FCD_SW_WINO); }
 
 int fcd_wino_mode_now() { return wino_env(); }   // conv_wino2.hip: the fused F(2x2) kernel follows the same switch
 
@@ -1610,7 +1578,7 @@ int fcd_wino_mode_now() { return wino_env(); }   // conv_wino2.hip: the fused F(
 // (Filters packed for another tile size stay valid: packs are keyed by m.)
 extern "C" int fcd_conv_wino_set(int m) {
   const int prev = wino_env();
-  if (m == 0 || m == 2 || m == 4) g_wino_mode = m;
+  if (m == 0 || m == 2 || m == 4) g_fcd_switch[FCD_SW_WINO] = m;
   return prev;
 }
 
@@ -1625,13 +1593,7 @@ extern "C" int fcd_conv_wino_plan(const fcd_conv_desc* d, int mode) {
   if (!(d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1)) return 0;
   const int red = mode == 0 ? d->C : d->K;       // reduction channels of the GEMM
   const int rows = mode == 0 ? d->K : d->C;      // GEMM rows
-  static int min_red = -1, min_rows = -1;
-  if (min_red < 0) {
-    const char* e = getenv("FCD_WINO_MINC");
-    min_red = e ? atoi(e) : 64;
-    const char* r = getenv("FCD_WINO_MINROWS");
-    min_rows = r ? atoi(r) : 128;
-  }
+  const int min_red = fcd_sw(FCD_SW_WINO_MINC), min_rows = fcd_sw(FCD_SW_WINO_MINROWS);
   if (red % 32 != 0 || red < min_red || rows < min_rows) return 0;
   if (d->P < 4 || d->Q < 4) return 0;
   return wino_env();
@@ -1707,14 +1669,7 @@ extern "C" int fcd_conv_wino_pack_multi(const long long* items_dev, int n, int t
   return FCD_OK;
 }
 
-static int wino_xcd() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("FCD_CONV_XCD");
-    v = (e && e[0] == '0') ? 0 : 1;
-  }
-  return v;
-}
+static int wino_xcd() { return fcd_sw(FCD_SW_CONV_XCD); }
 
 template <int MM, int TRB, int TWB>
 static void wino_launch_input_cfg(const WinoInArgs& ia, int src, hipStream_t st) {
@@ -1732,8 +1687,7 @@ static void wino_launch_input_cfg(const WinoInArgs& ia, int src, hipStream_t st)
 template <int MM>
 static void wino_launch_input(const WinoInArgs& ia, int src, hipStream_t st) {
   constexpr int NT = 64 / MM;             // tiles per block: 64 output pixels per patch row at 1 x NT
-  static int roll = -1;
-  if (roll < 0) { const char* e = getenv("FCD_WINO_IN_ROLL"); roll = e ? atoi(e) : 4; }
+  const int roll = fcd_sw(FCD_SW_WINO_IN_ROLL);
   // maps >= 2 strips high: the rolling kernel (next strip prefetched into registers)
   if ((ia.W & 3) == 0 && (src != 2 || (ia.Wp & 1) == 0) && roll > 1 && ia.TW > NT / 4) {
     const int trb = ia.TW > NT / 2 ? 1 : 2, strips = cdiv(ia.TH, trb);
@@ -1770,12 +1724,7 @@ static bool wino_cat_input_ok(const WinoPlan& pl, int W) {
 // (rows channels, H x W)
 // [r3] M in 32 x 32 MFMA-native blocks whenever the split kernels run the GEMM (FCD_WINO_CBLK=0: row-major M, A/B)
 static bool wino_blk_path(const WinoPlan& pl) {
-  static int cblk_on = -1;
-  if (cblk_on < 0) {
-    const char* e = getenv("FCD_WINO_CBLK");
-    cblk_on = (e && e[0] == '0') ? 0 : 1;
-  }
-  return cblk_on && pl.m == 4 && pl.rows > 64 && wino_split() && (pl.rows & 3) == 0;
+  return fcd_sw(FCD_SW_WINO_CBLK) && pl.m == 4 && pl.rows > 64 && wino_split() && (pl.rows & 3) == 0;
 }
 
 // The three stages of a layer call.  wino_run = input -> GEMM -> output; the chains further down put the fused output -> input
@@ -1795,8 +1744,7 @@ static void wino_stage_input(const WinoPlan& pl, int N, int in_ch, int H, int W,
   const int srcmode = in.aff_scale ? 3 : (in.code ? 2 : ((in.mask || in.mask_bits) ? 1 : 0));
   ia.aff_scale = in.aff_scale; ia.aff_shift = in.aff_shift; ia.aff_ng = in.aff_ng > 0 ? in.aff_ng : 1;
   {
-    static int exp = -1;
-    if (exp < 0) { const char* e = getenv("FCD_WINO_IN_EXP"); exp = e ? atoi(e) : 0; }
+    const int exp = fcd_sw(FCD_SW_WINO_IN_EXP);
     ia.exp = exp;
     ia.xcd = (wino_xcd() && !(exp & 8)) ? 1 : 0;
   }
@@ -1914,9 +1862,7 @@ extern "C" int fcd_conv2d_fwd_wino_keepv(const fcd_conv_desc* d, const float* x,
 // on the blocked F(4x4) path, or a workgroup's 256 tiles would straddle two groups)
 extern "C" int fcd_conv_wino_bn_split(const fcd_conv_desc* d, int groups) {
   WinoPlan pl;
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("FCD_WINO_BNSTATS"); on = (e && e[0] == '0') ? 0 : 1; }
-  if (!d || !on || groups < 1 || !wino_plan(d, 0, &pl) || !wino_blk_path(pl) || d->N % groups) return 0;
+  if (!d || !fcd_sw(FCD_SW_WINO_BNSTATS) || groups < 1 || !wino_plan(d, 0, &pl) || !wino_blk_path(pl) || d->N % groups) return 0;
   const long long per_group = pl.T / groups;
   if (per_group < 256 || per_group % 256) return 0;
   return (int)(per_group / 256);
@@ -1929,10 +1875,8 @@ extern "C" size_t fcd_conv_wino_bn_part_bytes(const fcd_conv_desc* d, int groups
 // (fcd_wino_fwd_extras.in_scale / in_shift): F(4x4) plan whose input goes through the rolling transform kernel
 extern "C" int fcd_conv_wino_in_affine_ok(const fcd_conv_desc* d) {
   WinoPlan pl;
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("FCD_BN_FUSE"); on = (e && e[0] == '0') ? 0 : 1; }
-  if (!d || !on || !wino_plan(d, 0, &pl)) return 0;
-  if (getenv("FCD_WINO_IN_ROLL") && atoi(getenv("FCD_WINO_IN_ROLL")) <= 1) return 0;
+  if (!d || !fcd_sw(FCD_SW_BN_FUSE) || !wino_plan(d, 0, &pl)) return 0;
+  if (fcd_sw(FCD_SW_WINO_IN_ROLL) <= 1) return 0;
   return wino_cat_input_ok(pl, d->W) ? 1 : 0;
 }
 
@@ -2446,13 +2390,7 @@ struct WinoWgPlan {
 int fcd_wino_wgrad_plan(const fcd_conv_desc* d, WinoWgPlan* pl) {
   if (wino_env() != 4) return 0;
   if (!(d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1)) return 0;
-  static int min_k = -1, min_c = -1;
-  if (min_k < 0) {
-    const char* e = getenv("FCD_WINO_WG_MINK");
-    min_k = e ? atoi(e) : 128;
-    const char* f = getenv("FCD_WINO_WG_MINC");
-    min_c = f ? atoi(f) : 128;
-  }
+  const int min_k = fcd_sw(FCD_SW_WINO_WG_MINK), min_c = fcd_sw(FCD_SW_WINO_WG_MINC);
   if (d->K < min_k || d->C < min_c || d->P < 4 || d->Q < 4) return 0;
   pl->TH = cdiv(d->H, 4);
   pl->TW = cdiv(d->W, 4);
@@ -2460,8 +2398,7 @@ int fcd_wino_wgrad_plan(const fcd_conv_desc* d, WinoWgPlan* pl) {
   pl->Tpad = (pl->T + 31) / 32 * 32;
   pl->stages = (int)(pl->Tpad / 32);
   const int blocks = cdiv(d->K, 128) * cdiv(d->C, 128) * 36;
-  static int wg_wgs = -1;             // FCD_WINO_WG_WGS=<n>: the round-4 rule (splits = ceil(n / blocks)); unset / 0: the round model below
-  if (wg_wgs < 0) { const char* e = getenv("FCD_WINO_WG_WGS"); wg_wgs = e ? atoi(e) : 0; if (wg_wgs < 0) wg_wgs = 0; }
+  const int wg_wgs = fcd_sw(FCD_SW_WINO_WG_WGS);             // <n>: the round-4 rule (splits = ceil(n / blocks)); 0: the round model below
   int splits;
   if (wg_wgs > 0) {
     splits = cdiv(wg_wgs, blocks);
@@ -2510,9 +2447,7 @@ int fcd_wino_wgrad_run(const fcd_conv_desc* d, const float* x, const float* dy, 
 extern "C" size_t fcd_conv_wino_keepv_bytes(const fcd_conv_desc* d) {
   WinoPlan pf;
   WinoWgPlan pw;
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("FCD_WINO_KEEPV"); on = (e && e[0] == '0') ? 0 : 1; }
-  if (!d || !on || !wino_split() || (d->C & 31) || !wino_plan(d, 0, &pf) || pf.m != 4 || !fcd_wino_wgrad_plan(d, &pw)) return 0;
+  if (!d || !fcd_sw(FCD_SW_WINO_KEEPV) || !wino_split() || (d->C & 31) || !wino_plan(d, 0, &pf) || pf.m != 4 || !fcd_wino_wgrad_plan(d, &pw)) return 0;
   if (pf.T != pw.T || pf.TW != pw.TW) return 0;
   // the forward dispatch (_ops._fwd_conv) tries the fused F(2x2) kernel first, which never writes V, and a <= 64-row GEMM takes the
   // non-split kernel, which ignores the transposed-B layout: only layers whose forward really runs the split F(4x4) GEMM keep V
@@ -2629,7 +2564,7 @@ extern "C" int fcd_conv_wino_cat_ok(const fcd_conv_desc* d) {
   WinoPlan pf, pd;
   WinoWgPlan pw;
   if (!d || !wino_plan(d, 0, &pf) || !wino_plan(d, 1, &pd) || !fcd_wino_wgrad_plan(d, &pw)) return 0;
-  if (getenv("FCD_WINO_IN_ROLL") && atoi(getenv("FCD_WINO_IN_ROLL")) <= 1) return 0;
+  if (fcd_sw(FCD_SW_WINO_IN_ROLL) <= 1) return 0;
   return wino_cat_input_ok(pf, d->W) ? 1 : 0;
 }
 

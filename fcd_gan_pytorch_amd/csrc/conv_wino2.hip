@@ -466,14 +466,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wino2_kernel(Wino2Args a) {
 unsigned long long* g_w2_tbuf = nullptr;
 #endif
 
-int w2_env() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("FCD_WINO2");
-    v = (e && e[0] == '0') ? 0 : 1;
-  }
-  return v;
-}
+int w2_env() { return fcd_sw(FCD_SW_WINO2); }
 }  // namespace
 
 // mode 0 forward / 1 data gradient: 1 when the layer runs on the fused F(2x2,3x3) kernel
@@ -481,11 +474,7 @@ extern "C" int fcd_conv_wino2_plan(const fcd_conv_desc* d, int mode) {
   if (!d || !w2_env() || fcd_wino_mode_now() == 0) return 0;
   if (!(d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1)) return 0;
   const int rows = mode == 0 ? d->K : d->C, red = mode == 0 ? d->C : d->K;
-  static int min_red = -1;
-  if (min_red < 0) {
-    const char* e = getenv("FCD_WINO2_MINC");
-    min_red = e ? atoi(e) : 32;
-  }
+  const int min_red = fcd_sw(FCD_SW_WINO2_MINC);
   if (rows <= 32 || rows > W2_ROWS || red < min_red) return 0;
   if (d->H < 4 || d->W < 4) return 0;
   return 1;
@@ -507,24 +496,9 @@ extern "C" int fcd_conv_wino2_pack(const float* w, float* U, int K, int C, int m
   return FCD_OK;
 }
 
-static int w2_xcd() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("FCD_CONV_XCD");
-    v = (e && e[0] == '0') ? 0 : 1;
-  }
-  return v;
-}
+static int w2_xcd() { return fcd_sw(FCD_SW_CONV_XCD); }
 
-static int w2_waves() {     // FCD_WINO2_WAVES = 8 (one 8 x 32 workgroup per CU) | 4 (two 4 x 32 workgroups per CU)
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("FCD_WINO2_WAVES");
-    v = e ? atoi(e) : 8;
-    if (v != 1 && v != 4) v = 8;
-  }
-  return v;
-}
+static int w2_waves() { return fcd_sw(FCD_SW_WINO2_WAVES); }     // 8 (one 8 x 32 workgroup per CU) | 4 (two 4 x 32 workgroups per CU) | 1
 
 #if W2_TIME
 extern "C" void fcd_wino2_time_buf(void* p) { g_w2_tbuf = (unsigned long long*)p; }
@@ -537,11 +511,7 @@ static void w2_launch(Wino2Args& a, int red, hipStream_t st) {
 #endif
   a.tiles_q = cdiv(a.W, W2_TW);
   a.xcd_remap = w2_xcd();
-  static int ks = -1;
-  if (ks < 0) {
-    const char* e = getenv("FCD_WINO2_KS");
-    ks = (e && atoi(e) == 1) ? 1 : ((e && atoi(e) == 3) ? 3 : 2);
-  }
+  const int ks = fcd_sw(FCD_SW_WINO2_KS);
   if (w2_waves() == 1) {          // one wave per SIMD: 4 waves x 4 tile rows, 512-register budget (accumulators in AGPRs)
     a.tiles_p = cdiv(a.H, 8);
     a.nchunks = cdiv(red, 8);

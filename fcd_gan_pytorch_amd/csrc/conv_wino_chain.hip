@@ -164,9 +164,7 @@ __global__ __launch_bounds__(NT, MINB) void wino_oi_kernel(WinoOiArgs a) {
 
 // 0: no kernel for this geometry (the caller runs output transform -> tensor -> input transform instead)
 int wino_oi_ok(int K, int H, int W) {
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("FCD_WINO_CHAIN"); on = (e && e[0] == '0') ? 0 : 1; }
-  if (!on || (K & 31) || (H & 3) || (W & 3)) return 0;
+  if (!fcd_sw(FCD_SW_WINO_CHAIN) || (K & 31) || (H & 3) || (W & 3)) return 0;
   const int TW = W / 4, TH = H / 4;
   if (TW >= 16) return (TW % 16) == 0;
   if (TW == 8) return (TH % 2) == 0;

@@ -880,9 +880,7 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const float* __r
 
 // 1: the shapes the three kernels take (even H and W, W % 4 == 0)
 extern "C" int fcd_bn_relu_pool_plan(int N, int C, int H, int W, int groups) {
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("FCD_BN_POOL"); on = (e && e[0] == '0') ? 0 : 1; }
-  return (on && N > 0 && C > 0 && groups > 0 && N % groups == 0 && H >= 2 && W >= 4 && (H & 1) == 0 && (W & 3) == 0 &&
+  return (fcd_sw(FCD_SW_BN_POOL) && N > 0 && C > 0 && groups > 0 && N % groups == 0 && H >= 2 && W >= 4 && (H & 1) == 0 && (W & 3) == 0 &&
           (long long)N * C < (1ll << 31)) ? 1 : 0;
 }
 

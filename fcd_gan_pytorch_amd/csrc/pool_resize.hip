@@ -465,9 +465,7 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_rows_kernel(const float* _
 
 // launch geometry of the row-walking kernel: tx column groups (<= 256), 256 / tx row lanes, rpb rows per lane
 static bool rows_geom(int groups, long long rows_total, dim3* grid, dim3* block, int* rpb) {
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("FCD_UPSAMPLE_ROWS"); on = (e && e[0] == '0') ? 0 : 1; }
-  if (!on || rows_total >= (1ll << 31) || groups < 1) return false;
+  if (!fcd_sw(FCD_SW_UPSAMPLE_ROWS) || rows_total >= (1ll << 31) || groups < 1) return false;
   int tx = 1;
   while (tx < groups && tx < 256) tx <<= 1;
   const int ty = 256 / tx;

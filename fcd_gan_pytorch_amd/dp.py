@@ -33,6 +33,8 @@ import os
 import torch
 import torch.distributed as dist
 
+from . import _lib
+
 
 def world_info(group=None):
     """(rank, world) of this process; (0, 1) when torch.distributed is not initialised."""
@@ -41,7 +43,7 @@ def world_info(group=None):
     return 0, 1
 
 
-_FORCE = {'on': os.environ.get('FCD_DP_FORCE_EXCHANGE') == '1'}
+_FORCE = {'on': bool(_lib.switch('DP_FORCE_EXCHANGE'))}
 
 
 def force_exchange(on=True):

@@ -25,6 +25,7 @@ import contextlib
 import torch
 import torch.nn as nn
 
+from . import _lib
 from .Loss import region_loss
 
 
@@ -58,9 +59,8 @@ def _masked_batch(tensors, cmask):
     """``torch.cat([t * (1 - cmask) for t in tensors], dim=0)``: every image the reference multiplies by
     ``(1 - cmask).repeat(1, C, 1, 1)`` before a Discriminator call (Demo_RSSS.py:290-300, Demo_WSSS.py:264-279), laid out as the
     batch ``Discriminator_SRGAN_simple.forward_stacked`` reads.  One HIP kernel forward, one backward (``ops.masked_stack``);
-    FCD_FUSED_GLUE=0 runs the ATen sequence (rsub, a broadcast multiply per tensor, cat) for A/B."""
-    import os
-    if os.environ.get('FCD_FUSED_GLUE', '1') == '0':
+    switch FUSED_GLUE=0 runs the ATen sequence (rsub, a broadcast multiply per tensor, cat) for A/B."""
+    if not _lib.switch('FUSED_GLUE'):
         keep = _bcast_keep(cmask, tensors[0].shape[1])
         return torch.cat([t * keep for t in tensors], dim=0)
     from . import _ops
@@ -71,7 +71,7 @@ _SIDE = {}
 
 
 def _side_stream(device):
-    """Second HIP stream of the adversarial steps -- EXPERIMENTAL, off unless FCD_STEP_OVERLAP=1.  The Discriminator
+    """Second HIP stream of the adversarial steps -- EXPERIMENTAL, off unless the switch STEP_OVERLAP is 1.  The Discriminator
     step -- its forward on the detached change map, backward, gradient exchange and update: many short launches on
     32x..16x16 maps that leave most of the 256 CUs idle -- is independent of the frozen-Generator forward and of the
     VGG feature passes of the Segmentor step, so it runs beside them; the Segmentor step's own Discriminator forward
@@ -80,14 +80,13 @@ def _side_stream(device):
     their cross-stream readers (_ops._shared; without that the optimizer's cache invalidation let the other stream's
     allocations overwrite filters a queued kernel was still reading).  Not the default: 0.4 % is not worth a second
     stream next to the RCCL stream on the multi-GPU path, which cannot be exercised here."""
-    import os
-    if device.type != 'cuda' or os.environ.get('FCD_STEP_OVERLAP') != '1':
+    if device.type != 'cuda' or not _lib.switch('STEP_OVERLAP'):
         return None
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         # the side stream would issue the Discriminator's collectives and read workspaces / gradient buffers the main stream
         # owns without record_stream: not supported (and not measured) under data parallelism
-        raise RuntimeError('FCD_STEP_OVERLAP=1 is a single-GPU experiment; unset it for multi-GPU runs')
+        raise RuntimeError('switch STEP_OVERLAP=1 is a single-GPU experiment; unset it for multi-GPU runs')
     s = _SIDE.get(device.index)
     if s is None:
         from . import _ops
@@ -123,8 +122,10 @@ def rsss_g_pretrain_step(netG, crit, optG, x, y, region, perception_weight=0.1, 
 
 def rsss_adversarial_step(netS, netD, netG, crit, optS, optD, x, y, region, perception_weight=0.1,
                           ssim_weight=0, l1_weight=0.02, g_weight=0.5, d_weight=1, r_weight=2,
-                          discriminator_continuous=True, literal=False, group=None, loss_scale=1.0):
-    """Demo_RSSS.py:285-332 (netG in eval mode, Demo_RSSS.py:240)."""
+                          discriminator_continuous=True, literal=False, group=None, loss_scale=1.0, d_share=None):
+    """Demo_RSSS.py:285-332 (netG in eval mode, Demo_RSSS.py:240).  ``d_share``: the Discriminator step sends the shared masked x
+    through D's net once (True) or twice as the reference does (False); None follows the switch D_SHARE (default 1).  A keyword of
+    the step -- and so part of a captured graph's signature -- not an environment read inside it."""
     cmap = netS(x, y)
     cmask = cmap if discriminator_continuous else (torch.sign(cmap - 0.5) + 1) / 2
     y_unc = y * (1 - region) + x * region
@@ -145,9 +146,8 @@ def rsss_adversarial_step(netS, netD, netG, crit, optS, optD, x, y, region, perc
             side.wait_stream(main)              # cmap, y_unc are ready
         with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
             # x_unc == x (Demo_RSSS.py:297): both calls take the same masked x, which goes through D's net once
-            # (FCD_D_SHARE=0: twice, as a batch of four groups -- the round-4 form, for A/B runs)
-            import os
-            if os.environ.get('FCD_D_SHARE', '1') == '0':
+            # (``d_share=False`` / switch D_SHARE=0: twice, as a batch of four groups -- the round-4 form, for A/B runs)
+            if not (_lib.switch('D_SHARE') if d_share is None else d_share):
                 c_out, nc_out = netD.forward_stacked(_masked_batch([x, y, x, y_unc], cmask.detach()), 2)
             else:
                 c_out, nc_out = netD.forward_shared_first(_masked_batch([x, y, y_unc], cmask.detach()), 2)

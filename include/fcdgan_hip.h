@@ -40,6 +40,20 @@ int fcd_version(void);
 const char* fcd_build_hash(void);
 const char* fcd_last_error_string(void);
 
+/* ---- run-time switches (csrc/switches.h) -----------------------------------
+ * ONE table of integer switches (which kernel / launch geometry serves a layer; A/B runs, tests, bench.py's
+ * `fp32_mfma_only` pass).  It is filled once, when the library is loaded, from the environment variables FCD_<NAME>;
+ * after that nothing on any call path reads the environment -- a run changes a switch through fcd_switch_set.  The
+ * reference has no such knobs (its kernels are ATen's); the host mirror reads its own A/B switches from the same table.
+ * Names are accepted with or without the FCD_ prefix.  fcd_switch_get: the value (never negative), FCD_ERR_INVALID
+ * for an unknown name.  fcd_switch_set: returns the previous value; value < 0 restores the default. */
+int fcd_switch_count(void);
+const char* fcd_switch_name(int i);
+const char* fcd_switch_help(int i);
+int fcd_switch_default(int i);
+int fcd_switch_get(const char* name);
+int fcd_switch_set(const char* name, int value);
+
 /* ---- convolution ---------------------------------------------------------
  * Replaces nn.Conv2d as used at Module.py:25,29 (3x3 p1), :146,158 (9x9 p4),
  * :85 (1x1), :196-205 (3x3 s2 p1), :212,214 (1x1 on 1x1 maps), the VGG16
@@ -115,14 +129,20 @@ int fcd_conv1x1_head_bn_bwd(const float* z, const float* w, const float* dy, con
  * fcd_conv_wino_filter_elems floats); every call needs fcd_conv_wino_ws_bytes of caller workspace.
  * Replaces the same nn.Conv2d call sites as fcd_conv2d_fwd / _bwd_data (Module.py:25-31, Loss.py:25). */
 int fcd_conv_wino_plan(const fcd_conv_desc* d, int mode);
-/* tile-size policy: 0 = direct kernels only, 2 or 4 (default, env FCD_WINO); returns the previous value */
+/* tile-size policy: 0 = direct kernels only, 2 or 4 (default, switch WINO); returns the previous value */
 int fcd_conv_wino_set(int m);
-/* matrix pipe of the batched GEMM of the three-kernel path: 1 (default, env FCD_WINO_SPLIT) = bf16 MFMA on exact
+/* matrix pipe of the batched GEMM of the three-kernel path: 1 (default, switch WINO_SPLIT) = bf16 MFMA on exact
  * three-way bf16 splits of the fp32 operands, six partial products accumulated in fp32 (fp32-equivalent result);
  * 0 = v_mfma_f32_32x32x2_f32 (fcd_conv_wino_pack writes the operand form of the CURRENT setting -- fp32 U or its three
  * bf16 planes -- so filters packed before a change of this switch must be packed again); 2 = as 1 with the 256 x 256-tile kernel for every GEMM of >= 256 rows (tests: the policy
  * otherwise keeps it for launches that fill the chip).  on < 0 only queries.  Returns the previous value. */
 int fcd_conv_wino_split_set(int on);
+/* matrix pipe of the NCHW-direct 3x3 weight-gradient kernel (fcd_conv2d_bwd_weight*, layers that do not take the F(4x4)
+ * form; replaces the weight gradient autograd derives for nn.Conv2d at Module.py:25-31,177-181,196-205): 1 (default, switch
+ * WGRAD_SPLIT) = bf16 MFMA on exact three-way splits of x and dY, six products per multiply accumulated in fp32; 0 = v_mfma_f32_*
+ * (stride-1 layers; the stride-2 form exists on the bf16 pipe only and then takes the channel-minor copies + fp32 kernel).
+ * on < 0 only queries.  Returns the previous value. */
+int fcd_conv_wgrad_split_set(int on);
 size_t fcd_conv_wino_ws_bytes(const fcd_conv_desc* d, int mode);
 int64_t fcd_conv_wino_filter_elems(int K, int C, int mode, int m);
 int fcd_conv_wino_pack(const float* w, float* U, int K, int C, int mode, int m, void* stream);

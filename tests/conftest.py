@@ -23,6 +23,21 @@ def pytest_collection_modifyitems(config, items):
             it.add_marker(skip)
 
 
+@pytest.fixture
+def switches():
+    """``switches(NAME, value)``: set a run-time switch of the library (csrc/switches.h) for the rest of the test; every switch
+    touched is restored afterwards.  (The environment is read once, when the library is loaded: a test cannot setenv.)"""
+    from fcd_gan_pytorch_amd import _lib
+    saved = {}
+
+    def set_(name, value):
+        old = _lib.set_switch(name, value)
+        saved.setdefault(name, old)
+    yield set_
+    for k, v in saved.items():
+        _lib.set_switch(k, v)
+
+
 @pytest.fixture(params=['direct', 'winograd'])
 def conv_path(request):
     """Run a gradient-level test once on the direct MFMA kernels only and once with the library's default

@@ -26,20 +26,17 @@ def _step(sync_bn, graphed=False, share=True, head_fused=True):
     import fcd_gan_pytorch_amd as p
     dev = torch.device('cuda', 0)
     p.set_sync_batchnorm(sync_bn)
-    # [r5] the Discriminator step sends the shared masked x through D's net once (steps.py, FCD_D_SHARE); under SyncBN it keeps the
+    # [r5] the Discriminator step sends the shared masked x through D's net once (steps.py, switch D_SHARE); under SyncBN it keeps the
     # reference's two passes.  share=False gives the per-replica run in that same form, so that the SyncBN comparison below
     # measures the SyncBN kernels and not the two ways of summing D's gradient (three RMSprop steps amplify those: D's loss
     # subtracts the two calls, the x-branch gradients nearly cancel)
-    os.environ['FCD_D_SHARE'] = '1' if share else '0' 
+    p._lib.set_switch('D_SHARE', 1 if share else 0)
     # [r5] likewise the change-density head behind the last BatchNorm and the encoder tails (ops.bn_relu_pool_skip: fp64 channel sums
     # in another order): per replica the head runs inside the head's kernels
     # (ops.bn_relu_head: w[c] * sum instead of sum of w[c] * term in its gradients, ~1e-7 relative), under SyncBN as BatchNorm
     # kernels + head kernels.  head_fused=False gives the per-replica run in the SyncBN run's form (ops.bn_relu_head_ok reads the
     # switch per call; the BatchNorm-in-the-loader fusion of the 3x3 layers is bit-identical either way)
-    if head_fused:
-        os.environ.pop('FCD_BN_FUSE', None)
-    else:
-        os.environ['FCD_BN_FUSE'] = '0'
+    p._lib.set_switch('BN_FUSE', 1 if head_fused else 0)
     netG, netS, netD = p.Module.Generator(C), p.Module.Segmentor(C, 1, True), p.Module.Discriminator_SRGAN_simple(C)
     netG.load_state_dict(seeded_state(onets.generator_spec(C), 101))
     netS.load_state_dict(seeded_state(onets.segmentor_spec(C, 1, True), 102))

@@ -260,10 +260,9 @@ def test_conv1x1_head(case):
     """One-output-channel 1x1 convolution + sigmoid (csrc/conv_head.hip; reference Module.py:82-90 OutConv) vs the ATen
     composition in fp64: forward, dx, dw, db; channel counts off the unroll of 8, with and without the sigmoid, and the
     frozen-filter case (dx only)."""
-    import os
-    if os.environ.get('FCD_CONV_HEAD') == '0':
-        pytest.skip('head kernels switched off')
     ops = _ops()
+    if not ops._lib.switch('CONV_HEAD'):
+        pytest.skip('head kernels switched off')
     N, C, H, W, sig = case
     x, w, b, g = rnd(N, C, H, W, seed=71), rnd(1, C, 1, 1, seed=72, scale=C ** -0.5), rnd(1, seed=73), rnd(N, 1, H, W, seed=74)
     xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
@@ -554,7 +553,7 @@ def test_wino_gemm_matrix_pipes(case):
 
 @pytest.mark.parametrize('case', [(2, 128, 32, 32, 256), (1, 256, 20, 36, 128), (3, 128, 13, 18, 128), (2, 512, 16, 16, 512)],
                          ids=lambda c: 'x'.join(map(str, c)))
-def test_wino_frozen_relu_bit_mask(case, monkeypatch):
+def test_wino_frozen_relu_bit_mask(case, switches):
     """Frozen F(4x4) layer with fused ReLU (the VGG16 stack of the perception term): the backward mask kept as 16 sign bits
     per output tile (fcd_conv2d_fwd_wino_relu_bits / fcd_conv2d_bwd_data_wino_bits) must give the SAME data gradient, bit
     for bit, as gating with the fp32 activation -- on all three gated input-transform kernels (strip / 2 x 8 / 4 x 4 blocks),
@@ -571,7 +570,7 @@ def test_wino_frozen_relu_bit_mask(case, monkeypatch):
         pytest.skip('layer is not planned F(4x4) in both directions')
     res = {}
     for tag, env in (('bits', '1'), ('y', '0')):
-        monkeypatch.setenv('FCD_WINO_RELU_BITS', env)
+        switches('WINO_RELU_BITS', int(env))
         xg = x.cuda().requires_grad_(True)
         wg = w.cuda()                                   # frozen
         y = ops.conv2d(xg, wg, b.cuda(), 1, 1, relu=True)
@@ -588,7 +587,7 @@ def test_wino_frozen_relu_bit_mask(case, monkeypatch):
 
 @pytest.mark.parametrize('case', [(4, 64, 64, 64, 128, 2), (2, 128, 128, 128, 128, 1), (4, 128, 32, 64, 256, 2)],
                          ids=lambda c: 'x'.join(map(str, c)))
-def test_bn_statistics_from_the_output_transform(case, monkeypatch):
+def test_bn_statistics_from_the_output_transform(case):
     """Conv2d -> BatchNorm2d(train) -> ReLU (reference Module.py:25-31): the BatchNorm's statistics summed by the F(4x4) output
     transform (conv2d(bn_groups=...) + fcd_bn_act_fwd_parts) against the separate statistics pass over y -- outputs, saved
     statistics through the backward pass (input / filter / affine gradients) and the running statistics, Siamese sample
@@ -1088,10 +1087,10 @@ def test_weight_gradient_from_the_forward_v_equals_the_one_from_x(case):
                                   # stride 2 (the Discriminator's layers; bf16 pipe only): square, odd height, ragged last tile + ragged filter count, one short tile
                                   (2, 64, 32, 32, 128, 2), (3, 64, 17, 48, 64, 2), (2, 128, 24, 40, 72, 2), (1, 256, 16, 16, 512, 2), (4, 64, 64, 128, 128, 2)],
                          ids=lambda c: 'x'.join(map(str, c)))
-def test_weight_gradient_on_nchw_operands(case, monkeypatch):
+def test_weight_gradient_on_nchw_operands(case, switches):
     """The rolling 3x3 weight-gradient kernel that reads x and dy as they are (``conv_wgrad_roll_nchw_kernel``, W % 32 == 0, no ReLU
     mask; reference: autograd of nn.Conv2d, Module.py:25-31,177-181) against the round-1..4 route (channel-minor copies of both operands +
-    ``conv_wgrad_roll_kernel``, FCD_WGRAD_NCHW=0) and against the fp64 gradient: several column strips, an odd row count, two filter
+    ``conv_wgrad_roll_kernel``, switch WGRAD_NCHW=0) and against the fp64 gradient: several column strips, an odd row count, two filter
     tiles, two channel tiles, ragged channel / filter counts (zero page), more samples than splits."""
     import ctypes
     ops = _ops()
@@ -1103,8 +1102,8 @@ def test_weight_gradient_on_nchw_operands(case, monkeypatch):
     x, dy = rnd(N, C, H, W, seed=171).cuda(), rnd(N, K, P, Q, seed=174).cuda()
     out = {}
     for tag in (('nchw', 'nchw_fp32_pipe', 'copies') if st == 1 else ('nchw', 'copies')):
-        monkeypatch.setenv('FCD_WGRAD_NCHW', '0' if tag == 'copies' else '1')
-        monkeypatch.setenv('FCD_WGRAD_SPLIT', '0' if tag == 'nchw_fp32_pipe' else '1')     # default: bf16 pipe, operands split exactly in three
+        switches('WGRAD_NCHW', 0 if tag == 'copies' else 1)
+        switches('WGRAD_SPLIT', 0 if tag == 'nchw_fp32_pipe' else 1)     # default: bf16 pipe, operands split exactly in three
         dw, db = torch.full((K, C, 3, 3), float('nan'), device='cuda'), torch.full((K,), float('nan'), device='cuda')
         ws = ops._ws(lib.fcd_conv2d_bwd_weight_ws_bytes(ctypes.byref(d)), x.device)
         ops.check(lib.fcd_conv2d_bwd_weight_bias(ctypes.byref(d), ops._p(x), ops._p(dy), None, ops._p(dw), ops._p(db), ops._p(ws),

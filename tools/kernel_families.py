@@ -14,11 +14,14 @@ FAMILIES = {
     'wino_gemm': (['wino_gemm_kernel'], ['wino_gemm'], []),
     'conv_wino2': (['conv_wino2_kernel'], ['conv_wino2_fwd', 'conv_wino2_dgrad'], []),
     # direct weight gradients incl. the 1x1 head: every kernel a fcd_conv2d_bwd_weight* / fcd_conv1x1_head_bwd call launches
-    'conv_wgrad': (['conv_wgrad_kernel', 'conv_wgrad_roll_kernel', 'conv_wgrad_roll_nchw_kernel', 'conv_wgrad_thin_kernel', 'conv_wgrad_thin_finish_kernel',
+    # [r6] the NCHW-direct 3x3 weight-gradient kernel on the bf16 matrix pipe (default; with the switch WGRAD_SPLIT=0 the same kernel
+    # name runs its fp32 instantiation and its calls open no conv_wgrad_bf16x6 scope -- an A/B configuration this map does not serve)
+    'conv_wgrad_split': (['conv_wgrad_roll_nchw_kernel'], ['conv_wgrad_bf16x6'], []),
+    'conv_wgrad': (['conv_wgrad_kernel', 'conv_wgrad_roll_kernel', 'conv_wgrad_thin_kernel', 'conv_wgrad_thin_finish_kernel',
                     'conv_wgrad_thin9_kernel', 'conv_wgrad_thin9_finish_kernel', 'thin9_bias_part_kernel', 'thin9_bias_fin_kernel',
                     'nchw_to_nhwc_kernel', 'nchw_to_nhwc_v4_kernel', 'wgrad_reduce_kernel', 'wgrad_reduce_wide_kernel',
                     'head_wgrad_kernel', 'head_wgrad_final_kernel', 'head_bn_reduce_kernel', 'head_bn_final_kernel'],
-                   ['conv_wgrad'], ['conv_wgrad_wino']),
+                   ['conv_wgrad'], ['conv_wgrad_wino', 'conv_wgrad_bf16x6']),
     # what stays on the direct forward / data-gradient entry points
     'conv_igemm': (['conv_igemm_kernel', 'conv_igemm_glds_kernel', 'conv_igemm_rows16_kernel', 'conv_s2sub_glds_kernel', 'small_fc_kernel', 'small_fc_narrow_kernel',
                     'conv3x3_fwd_thin_kernel', 'conv3x3_dgrad_thin_kernel', 'conv3x3_dgrad_thin_v4_kernel', 'conv3x3_dgrad_c1_mfma_kernel',
