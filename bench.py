@@ -189,12 +189,9 @@ def build_workload(args, dev, rank):
             for t in netG.buffers():
                 dist.broadcast(t, 0)
 
-        gs = fcd.graph.GraphedStep(fcd.steps.usss_g_pretrain_step, nets=(netG, crit), optimizers=(optG,), warmup=2)
-        gs.enabled = args.graph
-
         def step():
-            return gs(netG, crit, optG, x, y)
-        return step, {'G': optG}, gs
+            return fcd.steps.usss_g_pretrain_step(netG, crit, optG, x, y)
+        return step, {'G': optG}
 
     netS.train(); netD.train(); netG.eval()          # Demo_RSSS.py:146-148,240 / Demo_WSSS.py:206
     optS = fcd.optim.RMSprop(netS.parameters(), lr=5e-5)
@@ -212,19 +209,13 @@ def build_workload(args, dev, rank):
         g = torch.Generator(device=dev).manual_seed(99 + rank)
         y_nc = x_nc + 0.1 * torch.randn(x_nc.shape, device=dev, generator=g)
 
-        gs = fcd.graph.GraphedStep(fcd.steps.wsss_adversarial_step, nets=(netS, netD, netG, crit), optimizers=(optS, optD), warmup=2)
-        gs.enabled = args.graph
-
         def step():
-            return gs(netS, netD, netG, crit, optS, optD, x, y, x_nc, y_nc)
-        return step, {'S': optS, 'D': optD}, gs
-
-    gs = fcd.graph.GraphedStep(fcd.steps.rsss_adversarial_step, nets=(netS, netD, netG, crit), optimizers=(optS, optD), warmup=2)
-    gs.enabled = args.graph
+            return fcd.steps.wsss_adversarial_step(netS, netD, netG, crit, optS, optD, x, y, x_nc, y_nc)
+        return step, {'S': optS, 'D': optD}
 
     def step():
-        return gs(netS, netD, netG, crit, optS, optD, x, y, region)
-    return step, {'S': optS, 'D': optD}, gs
+        return fcd.steps.rsss_adversarial_step(netS, netD, netG, crit, optS, optD, x, y, region)
+    return step, {'S': optS, 'D': optD}
 
 
 def write_layer_tables(path, detail, psteps, args):
@@ -455,8 +446,6 @@ def main():
     ap.add_argument('--no-alt', action='store_true', help='skip the extra pass with the Winograd GEMMs on the fp32 matrix pipe')
     ap.add_argument('--prof-steps', type=int, default=3, help='steps of the profiled pass (HIP events around every launch)')
     ap.add_argument('--layers-md', default=None, help='write per-layer tables of the profiled pass to this markdown file')
-    ap.add_argument('--graph', action='store_true', help='replay the step from a hipGraph (graph.GraphedStep) instead of issuing it launch '
-                    'by launch; one rank only (collectives are never captured).  Measured: no faster on this box -- the step is kernel-bound')
     ap.add_argument('--force-exchange', action='store_true', help='with --gpus 1: create a ONE-rank process group and run every '
                     'data-parallel collective through it (dp.force_exchange) -- the RCCL rehearsal a 1-GPU box allows')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend: 'nccl' (= RCCL over xGMI); "
@@ -495,20 +484,7 @@ def main():
     from fcd_gan_pytorch_amd import _lib, dp as fdp
     if forced:
         fdp.force_exchange(True)
-    # hipGraph replay of the step: opt-in, one rank only (graph.py: same-box A/B shows no gain on a kernel-bound step, and a process
-    # group's watchdog thread aborts a capture that holds collectives)
-    args.graph = args.graph and world == 1 and not forced
-    step, opts, gstep = build_workload(args, dev, rank)
-    if args.graph:
-        try:
-            for _ in range(gstep.warmup + 1):        # settle + capture + first replay, before the counted warm-up steps
-                step()
-            torch.cuda.synchronize()
-        except Exception as e:                       # capture refused (e.g. an un-capturable call on this software stack):
-            if rank == 0:                            # the same kernels issued launch by launch -- still the HIP path
-                print('bench.py: hipGraph capture failed (%s: %s); stepping eagerly' % (type(e).__name__, e), file=sys.stderr)
-            gstep.enabled = False
-            args.graph = False
+    step, opts = build_workload(args, dev, rank)
 
     def barrier():
         if world > 1 or forced:
@@ -554,7 +530,6 @@ def main():
         _lib.lib.fcd_conv_wino_split_set(0)
         _lib.lib.fcd_conv_wgrad_split_set(0)
         ksteps = max(1, min(args.steps, 3))
-        was_graphed, gstep.enabled = gstep.enabled, False      # (the captured graph holds the split GEMM launches: this pass is eager)
         step()
         barrier()
         t1 = time.perf_counter()
@@ -564,7 +539,6 @@ def main():
         dta = time.perf_counter() - t1
         _lib.lib.fcd_conv_wino_split_set(pipes['wino_split'])
         _lib.lib.fcd_conv_wgrad_split_set(pipes['wgrad_split'])
-        gstep.enabled = was_graphed
         if world > 1:
             t = torch.tensor([dta], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -578,7 +552,6 @@ def main():
     prof, detail, dt_prof, psteps = {}, [], None, 0
     if not args.no_prof:
         psteps = max(1, min(args.steps, args.prof_steps))
-        was_graphed, gstep.enabled = gstep.enabled, False      # per-launch HIP events: launch by launch
         step()                                                 # (re-pack after the fp32-pipe pass, outside the profiled region)
         _lib.prof_read(reset=True)
         _lib.lib.fcd_prof_enable(2 if (args.layers_md and rank == 0) else 1)
@@ -589,7 +562,6 @@ def main():
         barrier()
         dt_prof = time.perf_counter() - t1
         _lib.lib.fcd_prof_enable(0)
-        gstep.enabled = was_graphed
         prof = _lib.prof_read(reset=True)
         detail = _lib.prof_detail(reset=True)
         if args.layers_md and rank == 0:
@@ -617,9 +589,7 @@ def main():
             'losses_last_step': losses,
             'peak_memory_bytes': {'allocated': int(torch.cuda.max_memory_allocated(dev)), 'reserved': int(torch.cuda.max_memory_reserved(dev)),
                                   'note': 'torch caching allocator, this rank, whole run (all passes); of 288 GB HBM3E'},
-            'launch': ('hipGraph replay: the whole step (forward, backward passes, optimizer kernels, BatchNorm statistics, filter re-packing) '
-                       'captured once and replayed, %d replays / %d eager calls so far' % (gstep.replays, gstep.eager_calls)) if args.graph else
-                      'launch by launch from Python (ctypes + autograd engine)',
+            'launch': 'launch by launch from Python (ctypes + autograd engine)',
             'host': dict(host, cores_usable=effective_cores(),
                          note='CPU seconds this rank spent issuing one step (all threads of the process) vs the step time: with N ranks '
                               'per node the sum over ranks has to fit the node\'s usable cores x ms_per_step'),

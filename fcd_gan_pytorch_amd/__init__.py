@@ -13,7 +13,7 @@ include/fcdgan_hip.h) and raises if it is missing: there is no CPU/eager fallbac
 import sys
 
 from . import _lib          # noqa: F401  (fails loudly when the HIP library is absent)
-from . import Module, Loss, ssim, optim, steps, dp, graph, tiles, metrics, datasets, demos  # noqa: F401
+from . import Module, Loss, ssim, optim, steps, dp, tiles, metrics, datasets, demos  # noqa: F401
 
 __version__ = '0.1.0'
 

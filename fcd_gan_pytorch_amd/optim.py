@@ -62,7 +62,7 @@ class _FlatOptimizer:
         self._buckets = None          # [(lo, hi, n_params)] over flat_g, bucket 0 = LAST parameters
         self._armed = False
         self.last_exchange = None     # diagnostics of the most recent exchange (tests, bench)
-        self._hyper = None            # device scalars of the update kernel once a hipGraph replays this optimizer (graph.GraphedStep)
+        self._hyper = None            # device scalars of the update kernel (use_device_hyper: for callers that capture the step into a hipGraph)
 
     def zero_grad(self, set_to_none=False):
         """One memset of the flat buffer; every ``.grad`` becomes None.  The backward kernels of the fcd ops then write
@@ -241,7 +241,7 @@ class _FlatOptimizer:
     def lr(self):
         return float(self.param_groups[0]['lr'])
 
-    # ---- hipGraph replays (graph.GraphedStep): the update kernel reads its per-step scalars from device memory
+    # ---- for callers that capture the step into a hipGraph: the update kernel reads its per-step scalars from device memory
     def hyper_values(self, step):
         """Floats the ``_h`` kernel reads for the ``step``-th (1-based) update."""
         return [self.lr]
@@ -255,7 +255,7 @@ class _FlatOptimizer:
 
     def _refresh_hyper(self):
         """Eager ``step()`` in device-hyper mode writes the current scalars itself; while a hipGraph is being captured the
-        host-to-device write is not capturable (and not wanted: ``GraphedStep`` writes before every replay)."""
+        host-to-device write is not capturable (and not wanted: the replaying caller writes before every replay)."""
         if not torch.cuda.is_current_stream_capturing():
             self.write_hyper()
 

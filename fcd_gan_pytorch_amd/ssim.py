@@ -36,7 +36,7 @@ _DEV_CONST = {}
 def _dev_const(values, device):
     """A small constant vector on the device, uploaded ONCE per (values, device): the window taps and the level weights are the
     same 11 + 5 numbers in every call, and a host-to-device copy per call is both two launches per step and the one thing in the
-    loss that a hipGraph capture of the train step cannot record (graph.GraphedStep)."""
+    loss that a hipGraph capture of the train step cannot record (a caller's own ``torch.cuda.graph``)."""
     key = (tuple(float(v) for v in values), str(device))
     t = _DEV_CONST.get(key)
     if t is None:

@@ -125,7 +125,7 @@ def rsss_adversarial_step(netS, netD, netG, crit, optS, optD, x, y, region, perc
                           discriminator_continuous=True, literal=False, group=None, loss_scale=1.0, d_share=None):
     """Demo_RSSS.py:285-332 (netG in eval mode, Demo_RSSS.py:240).  ``d_share``: the Discriminator step sends the shared masked x
     through D's net once (True) or twice as the reference does (False); None follows the switch D_SHARE (default 1).  A keyword of
-    the step -- and so part of a captured graph's signature -- not an environment read inside it."""
+    the step, not an environment read inside it."""
     cmap = netS(x, y)
     cmask = cmap if discriminator_continuous else (torch.sign(cmap - 0.5) + 1) / 2
     y_unc = y * (1 - region) + x * region

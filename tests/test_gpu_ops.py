@@ -1289,3 +1289,27 @@ def test_wino_packs_refreshed_in_one_launch_are_bit_identical():
     again = packs()
     for k in wino_keys:
         assert again[k][1] == before[k][1] and torch.equal(again[k][2], after[k][2])
+
+
+def test_device_hyper_kernels_equal_scalar_kernels():
+    """fcd_adam_step_h / fcd_rmsprop_step_h (update-rule scalars read from device memory -- what a caller who captures the step into a hipGraph
+    needs, include/fcdgan_hip.h) against the scalar-argument kernels over several steps."""
+    import fcd_gan_pytorch_amd as p
+    rng = np.random.default_rng(5)
+    w0 = torch.from_numpy(rng.standard_normal(10007).astype(np.float32))
+    res = {}
+    for mode in ('scalar', 'device'):
+        for kind in ('adam', 'rmsprop'):
+            prm = torch.nn.Parameter(w0.clone().to('cuda'))
+            opt = p.optim.Adam([prm], lr=3e-4, betas=(0.9, 0.99)) if kind == 'adam' else p.optim.RMSprop([prm], lr=5e-5)
+            if mode == 'device':
+                opt.use_device_hyper()
+            for it in range(7):
+                opt.zero_grad()
+                opt.param_groups[0]['lr'] = 3e-4 * (1 + it)
+                g = torch.from_numpy(np.random.default_rng(it).standard_normal(10007).astype(np.float32)).to('cuda')
+                opt.flat_g.copy_(g)
+                opt.step()
+            res[mode, kind] = opt.flat_p.cpu().numpy()
+    for kind in ('adam', 'rmsprop'):
+        np.testing.assert_array_equal(res['scalar', kind], res['device', kind], err_msg=kind)

@@ -17,9 +17,9 @@ import bench            # noqa: E402
 def main():
     import argparse
     _, bands, size, batch, _ = bench.WORKLOADS['rsss']
-    args = argparse.Namespace(workload='rsss', bands=bands, size=size, batch=batch, graph=False)
+    args = argparse.Namespace(workload='rsss', bands=bands, size=size, batch=batch)
     torch.cuda.set_device(0)
-    step, _, _ = bench.build_workload(args, torch.device('cuda', 0), 0)
+    step, _ = bench.build_workload(args, torch.device('cuda', 0), 0)
     for _ in range(3):
         step()
     torch.cuda.synchronize()

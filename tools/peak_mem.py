@@ -5,7 +5,7 @@ sys.path.insert(0, ROOT)
 import torch
 import bench
 ap = argparse.Namespace(workload='rsss', bands=13, size=256, batch=int(os.environ.get('BATCH', '8')))
-step = bench.build_workload(ap, torch.device('cuda', 0), 0)
+step, _ = bench.build_workload(ap, torch.device('cuda', 0), 0)
 for _ in range(3):
     step()
 torch.cuda.synchronize()
