@@ -14,7 +14,6 @@ How it differs from a layer-by-layer module tree:
    ``groups=2`` (see include/fcdgan_hip.h: fcd_bn_act_fwd).
 CUDA/ROCm tensors only: there is no CPU fallback in the product.
 """
-import os
 
 import numpy as np
 import torch
@@ -471,7 +470,9 @@ class Discriminator_SRGAN_simple(nn.Module):
         if z.shape[0] % (k + 1):
             raise ValueError('forward_shared_first: %d samples are not 1 + %d equal groups' % (z.shape[0], k))
         n = z.shape[0] // (k + 1)
-        if not self.training or ops.sync_bn_active():
+        # (the kernel's replay order is sixteen 4-bit entries -- include/fcdgan_hip.h, fcd_bn_act_fwd_replay: more than 8 second
+        #  arguments take the repeated batch as well)
+        if not self.training or ops.sync_bn_active() or k + 1 > 16 or 2 * k > 16:
             rep = torch.cat([t for i in range(k) for t in (z[:n], z[(i + 1) * n:(i + 2) * n])], dim=0)
             return self.forward_stacked(rep, k)
         order = [g for i in range(k) for g in (0, i + 1)]

@@ -7,7 +7,7 @@ Demo_RSSS.py:305,331, works unchanged).  All arithmetic of the ops below runs
 in the hand-written HIP kernels; CPU tensors are rejected (no fallback).
 """
 import ctypes
-import os
+import threading
 
 import torch
 
@@ -904,11 +904,6 @@ def bn_relu_conv3x3_ok(z, bn, weight, groups=1):
 def bn_relu_conv3x3(z, bn, weight, bias=None, groups=1, bn_groups=0):
     """``conv2d(bn_act(z, bn, ACT_RELU, groups=groups), weight, bias, 1, 1, bn_groups=bn_groups)`` without the activation tensor
     (:class:`_BnReluConv2d`; check :func:`bn_relu_conv3x3_ok` first)."""
-    if bn.track_running_stats and bn.num_batches_tracked is not None:
-        if _COUNTERS is not None:
-            _COUNTERS.append((bn.num_batches_tracked, groups))
-        else:
-            bn.num_batches_tracked += groups
     parts = getattr(z, '_fcd_bn', None)
     if parts is not None and (parts[3] != z.data_ptr() or parts[4] != z._version or parts[2] != groups or parts[1] <= 0):
         parts = None
@@ -917,10 +912,21 @@ def bn_relu_conv3x3(z, bn, weight, bias=None, groups=1, bn_groups=0):
     y = _BnReluConv2d.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                             bn.momentum if bn.momentum is not None else 0.1, bn.eps, int(groups), weight, bias,
                             (parts[0], parts[1]) if parts is not None else None, part, int(bn_groups) if part is not None else 0)
+    _count_batches(bn, groups)
     return _tag_bn(y, d, part, bn_groups)
 
 
-_COUNTERS = None
+_TLS = threading.local()      # .counters: the increments collected inside a batched_bn_counters context OF THIS THREAD (None outside)
+
+
+def _count_batches(bn, calls):
+    """``num_batches_tracked += calls`` for a train-mode BatchNorm call that has been LAUNCHED (a call that raised counts nothing)."""
+    if bn.track_running_stats and bn.num_batches_tracked is not None:
+        pending = getattr(_TLS, 'counters', None)
+        if pending is not None:
+            pending.append((bn.num_batches_tracked, calls))      # one multi-tensor add at the end of the net's forward
+        else:
+            bn.num_batches_tracked += calls
 
 
 class batched_bn_counters:
@@ -929,17 +935,15 @@ class batched_bn_counters:
     exits -- the nets' ``forward`` wrap themselves in it.  The buffers hold the same values as before once ``forward`` returns."""
 
     def __enter__(self):
-        global _COUNTERS
-        self.outer = _COUNTERS is not None
+        self.outer = getattr(_TLS, 'counters', None) is not None
         if not self.outer:
-            _COUNTERS = []
+            _TLS.counters = []
         return self
 
     def __exit__(self, *exc):
-        global _COUNTERS
         if self.outer:
             return False
-        todo, _COUNTERS = _COUNTERS, None
+        todo, _TLS.counters = _TLS.counters, None
         by_step = {}
         for t, g in todo:
             by_step.setdefault(int(g), []).append(t)
@@ -972,14 +976,12 @@ def bn_act(x, bn=None, act=ACT_NONE, slope=None, slope_imm=0.0, groups=1, order=
     if order is not None and not (training and bn.running_mean is not None):
         order = None
     calls = len(order) if order is not None else groups
-    if training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        if _COUNTERS is not None:
-            _COUNTERS.append((bn.num_batches_tracked, calls))      # one multi-tensor add at the end of the net's forward
-        else:
-            bn.num_batches_tracked += calls
-    return _BnAct.apply(x, bn.weight, bn.bias, slope, bn.running_mean, bn.running_var, training,
-                        bn.momentum if bn.momentum is not None else 0.1, bn.eps, groups, act, slope_imm,
-                        tuple(order) if order is not None else None)
+    y = _BnAct.apply(x, bn.weight, bn.bias, slope, bn.running_mean, bn.running_var, training,
+                     bn.momentum if bn.momentum is not None else 0.1, bn.eps, groups, act, slope_imm,
+                     tuple(order) if order is not None else None)
+    if training:
+        _count_batches(bn, calls)
+    return y
 
 
 # ------------------------------------------------ 1x1 head (one output channel + sigmoid)
@@ -1140,16 +1142,13 @@ def bn_relu_pool_skip_ok(z, bn, groups=1):
 
 def bn_relu_pool_skip(z, bn, groups=1):
     """``a = relu(bn(z))`` and ``maxpool2(a)`` from one node (:class:`_BnReluPoolSkip`; check :func:`bn_relu_pool_skip_ok` first)."""
-    if bn.track_running_stats and bn.num_batches_tracked is not None:
-        if _COUNTERS is not None:
-            _COUNTERS.append((bn.num_batches_tracked, groups))
-        else:
-            bn.num_batches_tracked += groups
     parts = getattr(z, '_fcd_bn', None)
     if parts is not None and (parts[3] != z.data_ptr() or parts[4] != z._version or parts[2] != groups or parts[1] <= 0):
         parts = None
-    return _BnReluPoolSkip.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum if bn.momentum is not None else 0.1,
-                                 bn.eps, int(groups), (parts[0], parts[1]) if parts is not None else None)
+    out = _BnReluPoolSkip.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum if bn.momentum is not None else 0.1,
+                                bn.eps, int(groups), (parts[0], parts[1]) if parts is not None else None)
+    _count_batches(bn, groups)
+    return out
 
 
 def bn_relu_head_ok(z, bn, weight, groups=1):
@@ -1166,16 +1165,13 @@ def bn_relu_head_ok(z, bn, weight, groups=1):
 def bn_relu_head(z, bn, weight, bias, sigmoid=True, groups=1):
     """``conv1x1_head(bn_act(z, bn, ACT_RELU, groups=groups), weight, bias, sigmoid)`` without the activation tensor
     (:class:`_BnReluHead`; check :func:`bn_relu_head_ok` first)."""
-    if bn.track_running_stats and bn.num_batches_tracked is not None:
-        if _COUNTERS is not None:
-            _COUNTERS.append((bn.num_batches_tracked, groups))
-        else:
-            bn.num_batches_tracked += groups
     parts = getattr(z, '_fcd_bn', None)
     if parts is not None and (parts[3] != z.data_ptr() or parts[4] != z._version or parts[2] != groups or parts[1] <= 0):
         parts = None
-    return _BnReluHead.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum if bn.momentum is not None else 0.1,
-                             bn.eps, int(groups), weight, bias, bool(sigmoid), (parts[0], parts[1]) if parts is not None else None)
+    out = _BnReluHead.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum if bn.momentum is not None else 0.1,
+                            bn.eps, int(groups), weight, bias, bool(sigmoid), (parts[0], parts[1]) if parts is not None else None)
+    _count_batches(bn, groups)
+    return out
 
 
 def conv1x1_head_supported(x, weight):

@@ -28,7 +28,6 @@ across ranks, no data-path collective except the gradient exchange of ``optim`` 
    confusion matrix: SURVEY.md 8e collective 4).
 """
 import math
-import os
 
 import torch
 import torch.distributed as dist
