@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""Training-equivalence evidence for the default conv plan.  NOT part of the timed suites.
+
+The F(4x4) forward flips ~30x more ReLU / max-pool decisions than stock fp32, and six iterations of parity say nothing about
+whether TRAINING cares.  This tool trains the Demo_RSSS adversarial loop (Demo_RSSS.py:285-332, RMSprop 5e-5, eval-mode frozen
+Generator, per-band perception) for >= 200 iterations on a synthetic multi-scene set from identical seeds in several LEGS:
+
+    oracle        CPU oracle (oracle/steps.py: the reference's loop on stock torch CPU ops), fp32
+    oracle_pert   the same with every initial Segmentor / Discriminator weight multiplied by (1 + 1e-6 u), u ~ U(-1, 1):
+                  the YARDSTICK -- how far two fp32 runs of the reference itself drift apart when nothing but rounding-level
+                  noise separates them (chaotic amplification through RMSprop's sign-like steps and the ReLU decisions)
+    hip_winograd  the product on its default plan (F(4x4) / fused F(2x2) / bf16-split GEMMs)
+    hip_direct    the product with fcd_conv_wino_set(0): direct fp32 MFMA kernels only
+
+and reports, against the `oracle` leg: the loss curves (every iteration), the drift of the training density map (every 10th
+iteration, same batch in every leg) and the final eval-mode F1 / IoU / mIoU over all scenes.  A HIP leg "trains like the
+reference" when its drift and its final scores sit inside what `oracle_pert` shows.
+
+    python tools/training_equivalence.py --leg oracle --out gpurun_out/te        # CPU legs run anywhere (no GPU)
+    python tools/training_equivalence.py --leg hip_winograd --out gpurun_out/te  # on the GPU box
+    python tools/training_equivalence.py --report gpurun_out/te --md profiles/r06_training_equivalence.md
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for q in (ROOT, os.path.join(ROOT, 'tests', 'golden')):
+    if q not in sys.path:
+        sys.path.insert(0, q)
+
+LEGS = ('oracle', 'oracle_pert', 'oracle_pert2', 'hip_winograd', 'hip_direct')
+C, HW, BATCH, SCENES = 4, 176, 4, 16
+
+
+def scenes(seed=2026):
+    """SCENES bi-temporal tile pairs with a true change rectangle each (seeded.seeded_tiles: T2 = T1 + 0.1 noise, rectangle replaced,
+    region = rectangle dilated by 10 px = the weak label Demo_RSSS trains on) + the rectangle itself as ground truth."""
+    from seeded import seeded_tiles
+    x, y, region = seeded_tiles(seed, SCENES, C, HW, HW)
+    truth = ((x - y).abs().amax(dim=1, keepdim=True) > 0.6).float() * region      # changed pixels: fresh noise vs 0.1 noise, inside the label
+    # a rectangle's interior is solid: fill it from its bounding box
+    for n in range(SCENES):
+        nz = truth[n, 0].nonzero()
+        if len(nz):
+            r0, c0 = nz.min(0).values.tolist()
+            r1, c1 = nz.max(0).values.tolist()
+            truth[n, 0, r0:r1 + 1, c0:c1 + 1] = 1.0
+    return x, y, region, truth
+
+
+def batch_order(iters, seed=77):
+    rng = np.random.default_rng(seed)
+    order = []
+    while len(order) < iters:
+        p = rng.permutation(SCENES)
+        order += [p[i:i + BATCH] for i in range(0, SCENES, BATCH)]
+    return [torch.from_numpy(np.sort(b)) for b in order[:iters]]
+
+
+def states():
+    from seeded import seeded_state
+    from oracle import nets as onets
+    return (seeded_state(onets.generator_spec(C), 9101), seeded_state(onets.segmentor_spec(C, 1, True), 9102),
+            seeded_state(onets.discriminator_spec(C), 9103), seeded_state(onets.vgg_spec(), 4242))
+
+
+def perturb(sd, seed, eps=1e-6):
+    rng = np.random.default_rng(seed)
+    out = {}
+    for k, v in sd.items():
+        if v.is_floating_point() and v.dim() >= 1 and not k.endswith(('running_mean', 'running_var')):
+            u = torch.from_numpy(rng.uniform(-1, 1, tuple(v.shape)).astype(np.float32))
+            out[k] = v * (1 + eps * u)
+        else:
+            out[k] = v.clone()
+    return out
+
+
+def scores(pred, truth):
+    """F1 / IoU of the changed class, mIoU, overall accuracy from {0,1} maps (metrics.py:11-82 of the reference: 2x2 confusion matrix)."""
+    p, t = pred.bool().flatten(), truth.bool().flatten()
+    tp = int((p & t).sum()); fp = int((p & ~t).sum()); fn = int((~p & t).sum()); tn = int((~p & ~t).sum())
+    iou1 = tp / max(tp + fp + fn, 1); iou0 = tn / max(tn + fp + fn, 1)
+    return dict(f1=2 * tp / max(2 * tp + fp + fn, 1), iou_changed=iou1, miou=0.5 * (iou0 + iou1), oa=(tp + tn) / max(tp + tn + fp + fn, 1),
+                tp=tp, fp=fp, fn=fn, tn=tn)
+
+
+KEYS = ('d_loss', 's_loss', 's_d_loss', 'g_loss', 'l1_loss', 'r_loss', 'perc')
+
+
+def run_oracle(leg, iters, threads):
+    from oracle import nets as onets, steps as osteps
+    torch.set_num_threads(threads)
+    sdG, sdS, sdD, sdV = states()
+    if leg.startswith('oracle_pert'):
+        s = 31 if leg == 'oracle_pert' else 32
+        sdS, sdD = perturb(sdS, s), perturb(sdD, s + 100)
+    n = osteps.Nets(sdG, sdS, sdD, sdV).make_optimizers('rsss')
+    x, y, region, truth = scenes()
+    curves, maps = [], {}
+    t0 = time.time()
+    for it, idx in enumerate(batch_order(iters)):
+        r = osteps.rsss_adversarial_step(n, x[idx], y[idx], region[idx])
+        curves.append([float(r[k if k != 'perc' else 'perc']) for k in KEYS])
+        if it % 10 == 0 or it == iters - 1:
+            maps[it] = r['cmap'].detach().numpy().astype(np.float32)
+        if it % 20 == 0:
+            print('[%s] it %d  s_loss %.5f d_loss %.5f  (%.0f s)' % (leg, it, curves[-1][1], curves[-1][0], time.time() - t0), flush=True)
+    with torch.no_grad():
+        cm = torch.cat([onets.segmentor(n.S, x[i:i + BATCH], y[i:i + BATCH], train=False, bilinear=True) for i in range(0, SCENES, BATCH)])
+    return curves, maps, cm.numpy(), truth.numpy(), region.numpy()
+
+
+def run_hip(leg, iters):
+    import fcd_gan_pytorch_amd as p
+    dev = torch.device('cuda', 0)
+    prev = p._lib.lib.fcd_conv_wino_set(0 if leg == 'hip_direct' else 4)
+    try:
+        sdG, sdS, sdD, sdV = states()
+        netG, netS, netD = p.Module.Generator(C), p.Module.Segmentor(C, 1, True), p.Module.Discriminator_SRGAN_simple(C)
+        netG.load_state_dict(sdG); netS.load_state_dict(sdS); netD.load_state_dict(sdD)
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            crit = p.Loss.CGeneratorLoss(channel=C, perception_layer=1, perception_perBand=True, allow_seeded=True)
+        crit.loss_perception.net.load_state_dict(sdV)
+        for m in (netG, netS, netD, crit):
+            m.to(dev)
+        netS.train(); netD.train(); netG.eval()
+        oS, oD = p.optim.RMSprop(netS.parameters(), lr=5e-5), p.optim.RMSprop(netD.parameters(), lr=5e-5)
+        x, y, region, truth = scenes()
+        xd, yd, rd = x.to(dev), y.to(dev), region.to(dev)
+        curves, maps = [], {}
+        name = {'perc': 'perception_loss'}
+        for it, idx in enumerate(batch_order(iters)):
+            idx = idx.to(dev)
+            r = p.steps.rsss_adversarial_step(netS, netD, netG, crit, oS, oD, xd[idx], yd[idx], rd[idx], literal=True)
+            curves.append([float(r[name.get(k, k)].detach()) for k in KEYS])
+            if it % 10 == 0 or it == iters - 1:
+                maps[it] = r['cmap'].detach().cpu().numpy().astype(np.float32)
+        netS.eval()
+        with torch.no_grad():
+            cm = torch.cat([netS(xd[i:i + BATCH], yd[i:i + BATCH]) for i in range(0, SCENES, BATCH)]).cpu()
+        return curves, maps, cm.numpy(), truth.numpy(), region.numpy()
+    finally:
+        p._lib.lib.fcd_conv_wino_set(prev)
+
+
+def run_leg(args):
+    os.makedirs(args.out, exist_ok=True)
+    t0 = time.time()
+    if args.leg.startswith('oracle'):
+        curves, maps, cm, truth, region = run_oracle(args.leg, args.iters, args.threads)
+    else:
+        curves, maps, cm, truth, region = run_hip(args.leg, args.iters)
+    meta = dict(leg=args.leg, iters=args.iters, seconds=time.time() - t0, torch=torch.__version__, threads=torch.get_num_threads(),
+                C=C, HW=HW, batch=BATCH, scenes=SCENES)
+    np.savez_compressed(os.path.join(args.out, 'te_%s.npz' % args.leg), curves=np.array(curves, np.float64), final_cmap=cm,
+                        truth=truth, region=region, meta=json.dumps(meta),
+                        **{'map%04d' % k: v for k, v in maps.items()})
+    print('[%s] done in %.0f s' % (args.leg, meta['seconds']))
+
+
+def report(args):
+    legs = {}
+    for leg in LEGS:
+        f = os.path.join(args.report, 'te_%s.npz' % leg)
+        if os.path.exists(f):
+            legs[leg] = np.load(f)
+    assert 'oracle' in legs, 'the oracle leg is the reference of every comparison'
+    ref = legs['oracle']
+    iters = ref['curves'].shape[0]
+    its = sorted(int(k[3:]) for k in ref.files if k.startswith('map'))
+    L = ['# Training equivalence of the conv plans: %d Demo_RSSS adversarial iterations, %d scenes of %dx%dx%d, batch %d' % (iters, SCENES, C, HW, HW, BATCH), '',
+         'Made by `tools/training_equivalence.py` (not part of the timed suites).  Every leg starts from the same seeded weights, sees the same batches',
+         'in the same order and runs the literal reference step order (`Demo_RSSS.py:285-332`; RMSprop 5e-5 for S and D, frozen eval-mode G,',
+         'per-band VGG16 perception on seeded filters).  `oracle` = CPU oracle, stock torch fp32.  `oracle_pert*` = the same with the initial',
+         'S / D weights multiplied by (1 + 1e-6 u): the yardstick -- two fp32 runs of the REFERENCE that differ by rounding-level noise only.',
+         '`hip_winograd` = the product\'s default plan, `hip_direct` = `fcd_conv_wino_set(0)`.', '']
+    for leg, z in legs.items():
+        m = json.loads(str(z['meta']))
+        L.append('* `%s`: %d iterations in %.0f s (%s threads, torch %s)' % (leg, m['iters'], m['seconds'], m['threads'], m['torch']))
+    L += ['', '## Loss curves: |leg - oracle| relative to |oracle|, by phase of the run (median / max over the iterations of the window)', '',
+          '| leg | loss | it 0 | it 1-9 | it 10-49 | it 50-99 | it 100-%d |' % (iters - 1), '|---|---|---|---|---|---|---|']
+    wins = [(0, 1), (1, 10), (10, 50), (50, 100), (100, iters)]
+    for leg, z in legs.items():
+        if leg == 'oracle':
+            continue
+        for j, k in enumerate(KEYS):
+            if k not in ('d_loss', 's_loss', 'g_loss', 'r_loss'):
+                continue
+            a, b = z['curves'][:, j], ref['curves'][:, j]
+            rel = np.abs(a - b) / np.maximum(np.abs(b), 1e-12)
+            cells = ['%.1e / %.1e' % (np.median(rel[lo:hi]), rel[lo:hi].max()) if hi > lo else '-' for lo, hi in wins if lo < iters]
+            L.append('| %s | %s | %s |' % (leg, k, ' | '.join(cells)))
+    L += ['', 'Loss values at selected iterations (oracle | each leg):', '', '| it | ' + ' | '.join('%s s_loss' % l for l in legs) + ' | ' + ' | '.join('%s d_loss' % l for l in legs) + ' |',
+          '|---|' + '---|' * (2 * len(legs))]
+    for it in [0, 1, 5, 10, 25, 50, 100, 150, iters - 1]:
+        if it < iters:
+            L.append('| %d | ' % it + ' | '.join('%.5f' % legs[l]['curves'][it, 1] for l in legs) + ' | ' + ' | '.join('%.5f' % legs[l]['curves'][it, 0] for l in legs) + ' |')
+    L += ['', '## Drift of the TRAINING density map from the oracle leg (same batch, same iteration): max | mean absolute difference', '',
+          '| it | ' + ' | '.join(l for l in legs if l != 'oracle') + ' |', '|---|' + '---|' * (len(legs) - 1)]
+    drift = {l: [] for l in legs if l != 'oracle'}
+    for it in its:
+        row = []
+        for l in drift:
+            d = np.abs(legs[l]['map%04d' % it] - ref['map%04d' % it])
+            drift[l].append((d.max(), d.mean()))
+            row.append('%.2e | %.2e' % (d.max(), d.mean()))
+        L.append('| %d | ' % it + ' | '.join(c.replace(' | ', ' / ') for c in row) + ' |')
+    yard = [l for l in drift if l.startswith('oracle_pert')]
+    if yard:
+        L += ['', 'Ratio of each HIP leg\'s mean drift to the yardstick\'s (largest `oracle_pert*` mean drift at the same iteration), over the recorded iterations >= 10:', '']
+        for l in drift:
+            if l.startswith('hip'):
+                r = [drift[l][i][1] / max(max(drift[yl][i][1] for yl in yard), 1e-12) for i, it in enumerate(its) if it >= 10]
+                L.append('* `%s`: median %.2f, max %.2f' % (l, float(np.median(r)), float(np.max(r))))
+    L += ['', '## Final eval-mode inference over all %d scenes (BatchNorm running statistics of the run), threshold 0.5' % SCENES, '',
+          '| leg | F1 (changed) vs rectangle | IoU changed | mIoU | OA | F1 vs weak label | mean density | max abs diff of the map vs oracle | pixels thresholded differently |', '|---|---|---|---|---|---|---|---|---|']
+    for leg, z in legs.items():
+        cm = torch.from_numpy(z['final_cmap'])
+        s = scores(cm > 0.5, torch.from_numpy(z['truth']) > 0.5)
+        sw = scores(cm > 0.5, torch.from_numpy(z['region']) > 0.5)
+        dm = np.abs(z['final_cmap'] - ref['final_cmap'])
+        flips = int(((z['final_cmap'] > 0.5) != (ref['final_cmap'] > 0.5)).sum())
+        L.append('| %s | %.4f | %.4f | %.4f | %.4f | %.4f | %.4f | %.2e | %d of %d |' % (leg, s['f1'], s['iou_changed'], s['miou'], s['oa'], sw['f1'], float(cm.mean()), dm.max(), flips, cm.numel()))
+    txt = '\n'.join(L) + '\n'
+    if args.md:
+        with open(args.md, 'w') as f:
+            f.write(txt)
+    print(txt)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--leg', choices=LEGS)
+    ap.add_argument('--iters', type=int, default=200)
+    ap.add_argument('--threads', type=int, default=os.cpu_count() or 8)
+    ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'te'))
+    ap.add_argument('--report', default=None, help='directory with the legs\' te_*.npz files')
+    ap.add_argument('--md', default=None)
+    args = ap.parse_args()
+    if args.report:
+        return report(args)
+    run_leg(args)
+
+
+if __name__ == '__main__':
+    main()
