@@ -54,8 +54,8 @@ def ms_ssim(X, Y, data_range=1.0, size_average=True, win_size=11, win_sigma=1.5,
         raise ValueError("Input images should have the same dimensions.")
     if min(X.shape[-2:]) <= (win_size - 1) * 16:
         raise AssertionError("Image size should be larger than %d" % ((win_size - 1) * 16))
-    w = torch.tensor(list(weights or MS_WEIGHTS), dtype=X.dtype)
-    g = gauss_window(win_size, win_sigma).to(X.dtype)
+    w = torch.tensor(list(weights or MS_WEIGHTS), dtype=X.dtype, device=X.device)
+    g = gauss_window(win_size, win_sigma).to(dtype=X.dtype, device=X.device)      # (device: the fp64 truth of the full-size tests may run on the GPU's stock fp64 ops)
     vals = []
     L = w.numel()
     for lvl in range(L):

@@ -75,7 +75,7 @@ def usss_g_pretrain_step(n, x, y, perception_weight=0.4, ssim_weight=0):
     """Demo_USSS.py:142-159."""
     n.opt['G'].zero_grad()
     y_fake = nets.generator(n.G, x, train=True)
-    cmap = torch.zeros((x.shape[0], 1, x.shape[2], x.shape[3]))
+    cmap = torch.zeros((x.shape[0], 1, x.shape[2], x.shape[3]), dtype=x.dtype, device=x.device)
     gen, l1, perc, ssim = losses.cnet_loss(n.VGG, y, y_fake, cmap)
     loss = gen + perception_weight * perc + ssim_weight * ssim
     loss.backward()

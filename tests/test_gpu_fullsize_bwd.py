@@ -99,8 +99,21 @@ D_LARGEST_JUMP = 1.05e-2
 HIP_D_LIMITS = dict(flat=1.5 * D_LARGEST_JUMP, tensor=2.5 * D_LARGEST_JUMP)
 
 
+# Where the fp64 TRUTH runs: the oracle's stock torch ops in double precision on the DEVICE (ATen / rocBLAS fp64 kernels -- as foreign
+# to the product's HIP kernels as oneDNN is).  Measured on the MI355X box (tools/debug, round 6): the fp64 Demo_RSSS oracle step at
+# 13 x 256 x 256, N = 2 takes 2.2 s there against 74 s on the 16 host cores, and the two sets of fp64 gradients agree to 3e-14 (S) /
+# 4e-14 (D) relative L2, the density map to 8e-14 -- the truth does not care where it is evaluated, the suite's wall clock does
+# (VERDICT r5 weak 11).  The fp32 ORACLE -- the yardstick "how far is stock fp32 PyTorch on the reference's CPU path from the truth" --
+# stays on the host.
+TRUTH_DEV = 'cuda'
+
+
+def _t64(t):
+    return t.double().to(TRUTH_DEV)
+
+
 def _dbl(sd):
-    return None if sd is None else {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    return None if sd is None else {k: (v.double() if v.is_floating_point() else v.clone()).to(TRUTH_DEV) for k, v in sd.items()}
 
 
 def _oracle_fp64(sds, kind, run):
@@ -118,8 +131,9 @@ def _oracle_fp64(sds, kind, run):
         for which in n.capture:
             for k, g in n.capture[which].items():
                 assert g is None or g.dtype == torch.float64, (which, k, g.dtype)
+            n.capture[which] = {k: (None if g is None else g.cpu()) for k, g in n.capture[which].items()}
         if isinstance(out, dict) and 'cmap' in out:
-            n.capture['cmap64'] = out['cmap'].detach()
+            n.capture['cmap64'] = out['cmap'].detach().cpu()
         return n.capture
     finally:
         torch.set_default_dtype(prev)
@@ -133,10 +147,10 @@ def _d_step_fp64(sdD, c_pair, nc_pair):
     torch.set_default_dtype(torch.float64)
     try:
         oD = onets.clone_state(_dbl(sdD))
-        c_out = onets.discriminator(oD, c_pair[0].double(), c_pair[1].double(), train=True)
-        nc_out = onets.discriminator(oD, nc_pair[0].double(), nc_pair[1].double(), train=True)
+        c_out = onets.discriminator(oD, _t64(c_pair[0]), _t64(c_pair[1]), train=True)
+        nc_out = onets.discriminator(oD, _t64(nc_pair[0]), _t64(nc_pair[1]), train=True)
         (1 + nc_out.mean() - c_out.mean()).backward()
-        return {k: oD[k].grad.detach() for k in onets.param_keys(oD)}
+        return {k: oD[k].grad.detach().cpu() for k in onets.param_keys(oD)}
     finally:
         torch.set_default_dtype(prev)
 
@@ -338,7 +352,7 @@ def test_rsss_iteration_gradients_full_size(conv_path, literal):
         n.capture = {}
         ro = osteps.rsss_adversarial_step(n, x, y, region)
         g64 = _oracle_fp64((sdG, sdS, sdD, sdV), 'rsss',
-                           lambda m: osteps.rsss_adversarial_step(m, x.double(), y.double(), region.double()))
+                           lambda m: osteps.rsss_adversarial_step(m, _t64(x), _t64(y), _t64(region)))
         _ORACLE['rsss'] = (n, ro, g64, _truth_limits(n.capture, g64, 'D', True), _truth_limits(n.capture, g64, 'S'), {})
     n, ro, g64, limD, limS, dcache = _ORACLE['rsss']
 
@@ -388,7 +402,7 @@ def test_usss_generator_step_gradients_full_size(conv_path):
 
         def run64(m):
             m.opt['G'] = torch.optim.Adam(m.params('G'), lr=2e-4, betas=(0.9, 0.99))
-            osteps.usss_g_pretrain_step(m, x.double(), y.double())
+            osteps.usss_g_pretrain_step(m, _t64(x), _t64(y))
         g64 = _oracle_fp64((sdG, None, None, sdV), None, run64)
         _ORACLE['usss'] = (n, ro, g64)
     n, ro, g64 = _ORACLE['usss']
@@ -427,7 +441,7 @@ def test_usss_generator_gradient_with_direct_vgg_decisions():
 
         def run64(m):
             m.opt['G'] = torch.optim.Adam(m.params('G'), lr=2e-4, betas=(0.9, 0.99))
-            osteps.usss_g_pretrain_step(m, x.double(), y.double())
+            osteps.usss_g_pretrain_step(m, _t64(x), _t64(y))
         _ORACLE['usss'] = (n, ro, _oracle_fp64((sdG, None, None, sdV), None, run64))
     n, ro, g64 = _ORACLE['usss']
     names = [k for k in g64['G'] if g64['G'][k] is not None and not is_pre_bn_bias(k)]
@@ -476,7 +490,7 @@ def test_wsss_iteration_gradients_full_size(conv_path):
         n.capture = {}
         ro = osteps.wsss_adversarial_step(n, x, y, xn, yn)
         g64 = _oracle_fp64((sdG, sdS, sdD, sdV), 'wsss',
-                           lambda m: osteps.wsss_adversarial_step(m, x.double(), y.double(), xn.double(), yn.double()))
+                           lambda m: osteps.wsss_adversarial_step(m, _t64(x), _t64(y), _t64(xn), _t64(yn)))
         _ORACLE['wsss'] = (n, ro, g64, _truth_limits(n.capture, g64, 'D', True), _truth_limits(n.capture, g64, 'S'), {})
     n, ro, g64, limD, limS, dcache = _ORACLE['wsss']
 

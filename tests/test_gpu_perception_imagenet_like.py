@@ -46,15 +46,16 @@ def _oracle(vgg, t, g, cmask, dtype):
     torch.set_default_dtype(dtype)
     olosses.BATCH_BANDS = dtype == torch.float64      # the fp64 truth: bands as one batch (same function, ~3x less wall time)
     try:
-        sd = {k: v.to(dtype) for k, v in vgg.items()}
-        gr, cr = g.to(dtype).clone().requires_grad_(True), cmask.to(dtype).clone().requires_grad_(True)
-        tt = t.to(dtype)
+        dev = 'cuda' if dtype == torch.float64 else 'cpu'      # the fp64 truth on the device's stock fp64 ops (see test_gpu_fullsize_bwd.py: TRUTH_DEV)
+        sd = {k: v.to(dtype).to(dev) for k, v in vgg.items()}
+        gr, cr = g.to(dtype).to(dev).clone().requires_grad_(True), cmask.to(dtype).to(dev).clone().requires_grad_(True)
+        tt = t.to(dtype).to(dev)
         loss = olosses.perception(sd, tt, gr, cr, feature_layer=1, per_band=True)
         loss.backward()
         with torch.no_grad():       # relu5_3 of the first target band and the first generated band (the tap the loss reads)
             keep = 1 - cr.detach()
             f = [onets.vgg_features(sd, (im[:, 0:1] * keep).repeat(1, 3, 1, 1), (29,))[29] for im in (tt, gr.detach())]
-        return dict(loss=loss.detach(), dg=gr.grad, dc=cr.grad, feat=torch.cat(f, 0))
+        return dict(loss=loss.detach().cpu(), dg=gr.grad.cpu(), dc=cr.grad.cpu(), feat=torch.cat(f, 0).cpu())
     finally:
         torch.set_default_dtype(prev)
         olosses.BATCH_BANDS = prev_bb
