@@ -25,12 +25,6 @@ int fcd_try_dgrad_thin(const fcd_conv_desc* d, const float* dy, const float* rel
 int fcd_try_fwd_thin(const fcd_conv_desc* d, const float* x, const float* wp, const float* bias, float* y, int relu,
                      hipStream_t st, unsigned char* bits);    // conv_thin.hip
 
-// FCD_EXP: diagnostic builds only (results are wrong when set): 1 = no patch loads/stores in the
-// loop, 2 = no filter DMA in the loop, 4 = no barrier in the loop, 8 = operands from registers,
-// 16 = patch loads from a tiny always-cached window, 32 = filter DMA from slabs 0/1 only
-#ifndef FCD_EXP
-#define FCD_EXP 0
-#endif
 struct ConvArgs {
   const float* x;
   const float* wp;
@@ -191,7 +185,7 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_kernel(ConvArgs a) {
   }
 #define FCD_LOAD_X(CCHUNK)                                                                            \
   {                                                                                                   \
-    const float* xsrc = (FCD_EXP & 16) ? a.x + ((CCHUNK) & 1) * 4096 : xin + (size_t)(CCHUNK) * chunk_elems; \
+    const float* xsrc = xin + (size_t)(CCHUNK) * chunk_elems;                                      \
     const float* msrc = min_ + (size_t)(CCHUNK) * chunk_elems;                                        \
     const int cleft = a.C - (CCHUNK) * CB;                                                            \
     _Pragma("unroll") for (int i = 0; i < X_PER_T; ++i) {                                             \
@@ -483,9 +477,7 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_rows16_kernel(ConvArgs a) {
 // one s_barrier per step instead of two, and the registers freed by the filter staging
 // buy a third resident workgroup per CU.
 // channels per K-step of the v2 kernel (A/B on MI355X: 2 -> -2 %, 6 -> -5 % vs 4)
-#ifndef FCD_CB2
-#define FCD_CB2 4
-#endif
+constexpr int FCD_CB2 = 4;
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 
@@ -502,10 +494,7 @@ typedef __attribute__((address_space(1))) const void gbl_void_t;
 // 2 pooled gradient routed by the argmax code byte.  Compile-time so the loop carries no mode branches.
 template <int R, int S, int RCH, int STRIDE, int DIL, int CB, int MI, int NI, int WM, int WN, int TH,
           int TW, int SRC>
-#ifndef FCD_WPE
-#define FCD_WPE 3
-#endif
-__global__ __launch_bounds__(256, (MI * NI > 4) ? 2 : FCD_WPE) void conv_igemm_glds_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, (MI * NI > 4) ? 2 : 3) void conv_igemm_glds_kernel(ConvArgs a) {
   constexpr int BM = 32 * MI * WM;
   constexpr int BN = 32 * NI * WN;
   static_assert(WM * WN == 4, "4 waves");
@@ -625,7 +614,7 @@ __global__ __launch_bounds__(256, (MI * NI > 4) ? 2 : FCD_WPE) void conv_igemm_g
 
 #define FCD_GLDS_W(CCHUNK, WDST)                                                                      \
   {                                                                                                   \
-    const float* wsrc = a.wp + (size_t)((FCD_EXP & 32) ? ((CCHUNK) & 1) : (CCHUNK)) * w_chunk_stride; \
+    const float* wsrc = a.wp + (size_t)(CCHUNK) * w_chunk_stride;                                  \
     _Pragma("unroll") for (int j = 0; j < W_PER_WAVE; ++j) {                                          \
       if (W_INSTR % 4 == 0 || wave + 4 * j < W_INSTR)                                                 \
         __builtin_amdgcn_global_load_lds((gbl_void_t*)(wsrc + w_goff[j]),                             \
@@ -645,7 +634,6 @@ __global__ __launch_bounds__(256, (MI * NI > 4) ? 2 : FCD_WPE) void conv_igemm_g
     _Pragma("unroll") for (int i = 0; i < X_PER_T; ++i) {                                             \
       unsigned off = x_boff[i];                                                                       \
       if (tail) off = (x_cc[i] < cleft) ? off : 0u;                                                   \
-      if (FCD_EXP & 16) off &= 16383u;                                                                \
       xr[i] = *(const float*)(xsrc + off);                                                            \
       if (SRC == 1) mr[i] = *(const float*)(msrc + off);                                              \
       if (SRC == 2) mcode[i] = csrc[off >> 2];                                                        \
@@ -677,8 +665,8 @@ __global__ __launch_bounds__(256, (MI * NI > 4) ? 2 : FCD_WPE) void conv_igemm_g
     const bool have_next = chunk + 1 < nsteps;                                                        \
     const int xb = chunk & 1;                                                                         \
     if (have_next) {                                                                                  \
-      if (!(FCD_EXP & 2)) FCD_GLDS_W(chunk + 1, WNXT)                                                 \
-      if (!(FCD_EXP & 1)) FCD_LOAD_X2(chunk + 1)                                                      \
+      FCD_GLDS_W(chunk + 1, WNXT)                                                                     \
+      FCD_LOAD_X2(chunk + 1)                                                                          \
     }                                                                                                 \
     const float* xl = smem_x + xb * XS_SZ;                                                            \
     float av[MI][FCD_KROW];                                                                           \
@@ -695,14 +683,13 @@ __global__ __launch_bounds__(256, (MI * NI > 4) ? 2 : FCD_WPE) void conv_igemm_g
     _Pragma("unroll") for (int j = 0; j < FCD_KH; ++j) {                                              \
       float bv[NI];                                                                                   \
       _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                               \
-        bv[ni] = (FCD_EXP & 8) ? (float)(lane + ni + j)                                               \
-                               : xl[xoff[ni] + (j / 9) * PLANE + ((j % 9) / 3) * PWP + (j % 3)];      \
+        bv[ni] = xl[xoff[ni] + (j / 9) * PLANE + ((j % 9) / 3) * PWP + (j % 3)];                      \
       _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                               \
         _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                             \
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][j], bv[ni], acc[mi][ni], 0, 0, 0); \
     }                                                                                                 \
-    if (!(FCD_EXP & 1)) if (have_next) FCD_STORE_X2(xb ^ 1, chunk + 1)                                \
-    if (!(FCD_EXP & 4)) __syncthreads();                                                              \
+    if (have_next) FCD_STORE_X2(xb ^ 1, chunk + 1)                                                    \
+    __syncthreads();                                                                                  \
   }
 
   for (int step = 0; step < nsteps; step += 2) {

@@ -22,9 +22,6 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#ifndef WT_XPRE
-#define WT_XPRE 0     // 1: also the input patch of the stride-1 layer through registers (14 per thread) -- spills, measured slower (0.38 vs 0.30 ms)
-#endif
 namespace {
 constexpr int WT_TH = 2, WT_TW = 64;            // output pixels per tile
 constexpr int WT_DYP = WT_TH * WT_TW + 4;       // dY row pitch (floats); 16-B aligned rows for the float4 stores (column reads: 4-way, off the critical path)
@@ -81,7 +78,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_thin_kernel(WgThinArgs a) {
   // committed to LDS behind it (the kernel used to load, wait, store and only then multiply: two workgroups per CU were all that
   // hid the loads).
   constexpr int DY_PER_T = (WT_ROWS * WT_TH * WT_TW / 4) / 256;        // 8 float4
-  constexpr bool XPRE = STRIDE == 1 && WT_XPRE;                                   // (the 5 x 129 patch of the stride-2 layer does not fit the registers: 36 per thread)
+  constexpr bool XPRE = false;      // (staging the input patch through registers too: stride 1 spills at 14 per thread, 0.38 vs 0.30 ms; stride 2 needs 36)
   constexpr int X_PER_T = XPRE ? (CMAX * XR * XC + 255) / 256 : 1;
   const bool vec = (a.Q & 3) == 0;
   const int xtotal = a.C * XR * XC;

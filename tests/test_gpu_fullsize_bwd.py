@@ -84,8 +84,8 @@ K_TRUTH = {'direct': dict(k_flat=2.0, k_tensor=3.0, floor_flat=2e-4, floor_tenso
            # backward with only the VGG masks / pool codes taken from the direct forward 1.12x.  A flipped unit contributes its whole dy to
            # the error, so the relative gradient error goes like sqrt(fraction of flipped units) ~ sqrt(forward rounding): F(4x4)'s ~30x
            # coarser forward rounding (1.4e-5 vs ~5e-7 of a layer output) gives ~5.4x.  The ARITHMETIC is held to 2x by the injected-
-           # decisions test; the end-to-end figure, which measures decision sensitivity, to 8 / 13 (5.42 / 9.03 measured on a dozen boxes
-           # over two rounds, unchanged by the better interpolation points and by the fused transforms).
+           # decisions test; the end-to-end figure, which measures decision sensitivity, to 8 / 13 (final builds of rounds 5 and 6 measure
+           # 5.49 flat / 9.33 worst tensor, profiles/r06_parity_fullsize.md; 5.42 / 9.03 before the round-5 chain kernels).
            ('winograd', 'G'): dict(k_flat=8.0, k_tensor=13.0, floor_flat=2e-4, floor_tensor=5e-4)}
 # (Winograd plan, measured: the generator's gradient through the 13 F(4x4) VGG layers of the perception term ends 4.4x
 #  (flat) / 8.1x (worst tensor) as far from the fp64 truth as stock fp32 -- 1.5e-3 / 2.5e-3 absolute; the Segmentor 1.9x /

@@ -12,7 +12,7 @@ extra = sys.argv[2] if len(sys.argv) > 2 else None
 r = json.load(open(os.path.join(src, 'parity_fullsize_bwd.json')))
 dist = r.pop('d_step_error_distribution_16_maps', None)
 decisions = r.pop('usss_g_4x256_decisions', None)      # [r5] test_usss_generator_gradient_with_direct_vgg_decisions
-L = ['# Full-size backward parity against an fp64 truth (round 4)', '',
+L = ['# Full-size backward parity against an fp64 truth', '',
      '`tests/test_gpu_fullsize_bwd.py` on MI355X: one whole train iteration of each demo on the HIP path; next to it the CPU oracle step',
      '(`oracle/steps.py`, stock fp32 PyTorch, literal reference order) and THE SAME oracle step in double precision.  Every gradient is compared',
      'exactly as its optimizer sees it (pre-step hook).  `HIP` / `oracle32` = relative L2 distance to the fp64 gradient.', '',
@@ -29,7 +29,20 @@ for tag in sorted(r):
             tag, w, v['flat_rel_l2_vs_fp64'], v['flat_rel_l2_oracle32_vs_fp64'], v['flat_rel_l2_vs_fp64'] / v['flat_rel_l2_oracle32_vs_fp64'],
             v['worst_tensor_over_rule'], v['worst_tensor'], v['worst_tensor_rel_l2_vs_fp64'], v['worst_tensor_oracle32_vs_fp64'],
             v['worst_error_ratio_above_floor'], v['worst_error_ratio_tensor'], v['worst_update_rel_l2'], v['bn_running_rel_err']))
-L += ['', 'K (flat / per tensor, `K_TRUTH`): direct plan 2 / 3; Winograd plan: Segmentor 3 / 5, Generator step 6 / 10; floors 2e-4 / 5e-4 of the gradient norm.',
+def _k_line():
+    """The bounds as the TEST holds them (imported from tests/test_gpu_fullsize_bwd.py: one source, no hand-copied numbers)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for q in (root, os.path.join(root, 'tests'), os.path.join(root, 'tests', 'golden')):
+        if q not in sys.path:
+            sys.path.insert(0, q)
+    from test_gpu_fullsize_bwd import K_TRUTH as kt
+    f = lambda d: '%g / %g' % (d['k_flat'], d['k_tensor'])
+    return ('K (flat / per tensor, `K_TRUTH` of tests/test_gpu_fullsize_bwd.py): direct plan %s; Winograd plan: %s, Segmentor %s, Generator step %s; '
+            'floors %g / %g of the gradient norm.' % (f(kt['direct']), f(kt['winograd']), f(kt[('winograd', 'S')]), f(kt[('winograd', 'G')]),
+                                                      kt['direct']['floor_flat'], kt['direct']['floor_tensor']))
+
+
+L += ['', _k_line(),
       'The Winograd plan is further from the truth than stock fp32 where a gradient runs through many F(4x4,3x3) layers (the Generator step: 13 VGG layers',
       'of the perception term) -- the transforms round ~10x coarser than a direct fp32 convolution (1.4e-5 vs 1e-6 of a layer output).', '',
       '## Discriminator: one draw, against the fp64 D-step evaluated on the map each path produced', '',
