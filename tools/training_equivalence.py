@@ -230,6 +230,20 @@ def report(args):
         dm = np.abs(z['final_cmap'] - ref['final_cmap'])
         flips = int(((z['final_cmap'] > 0.5) != (ref['final_cmap'] > 0.5)).sum())
         L.append('| %s | %.4f | %.4f | %.4f | %.4f | %.4f | %.4f | %.2e | %d of %d |' % (leg, s['f1'], s['iou_changed'], s['miou'], s['oa'], sw['f1'], float(cm.mean()), dm.max(), flips, cm.numel()))
+    f1 = {leg: scores(torch.from_numpy(z['final_cmap']) > 0.5, torch.from_numpy(z['truth']) > 0.5)['f1'] for leg, z in legs.items()}
+    last = {leg: float(z['curves'][-1, 1]) for leg, z in legs.items()}
+    ylegs = ['oracle'] + [l for l in legs if l.startswith('oracle_pert')]
+    L += ['', '## Reading', '',
+          'The loop is chaotic at the rounding level: a 1e-6 relative perturbation of the initial weights moves the REFERENCE\'s own training density map',
+          'by ~1e-2 (mean) / ~1 (max: single pixels flip between 0 and 1) from iteration 10 on, and its final s_loss lands anywhere in %.1f ... %.1f over the'
+          % (min(last[l] for l in ylegs), max(last[l] for l in ylegs)),
+          'three oracle legs (the run bifurcates around iteration 110 - 150).  Against that yardstick the HIP legs are indistinguishable from another oracle run:',
+          'mean drift / yardstick as listed above (1.0 = as far from `oracle` as the perturbed oracle is), final s_loss %s,'
+          % ', '.join('%s %.1f' % (l, last[l]) for l in legs if l.startswith('hip')),
+          'final F1 %s against %.4f ... %.4f for the oracle legs.  Nothing here separates the F(4x4) plan from the direct plan or either from stock fp32.'
+          % (', '.join('%s %.4f' % (l, f1[l]) for l in legs if l.startswith('hip')), min(f1[l] for l in ylegs), max(f1[l] for l in ylegs)),
+          '(The absolute scores are low and the mean density high: 200 iterations on noise tiles at lr 5e-5 do not train a useful segmentor; the question asked',
+          'here is whether the plans TRAIN DIFFERENTLY, not whether the toy problem is solved.)']
     txt = '\n'.join(L) + '\n'
     if args.md:
         with open(args.md, 'w') as f:
