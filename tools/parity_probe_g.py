@@ -48,7 +48,7 @@ def main():
 
     def run64(m):
         m.opt['G'] = torch.optim.Adam(m.params('G'), lr=2e-4, betas=(0.9, 0.99))
-        osteps.usss_g_pretrain_step(m, x.double(), y.double())
+        osteps.usss_g_pretrain_step(m, T._t64(x), T._t64(y))
     g64 = T._oracle_fp64((sdG, None, None, sdV), None, run64)['G']
     names = [k for k in g64 if g64[k] is not None and not T.is_pre_bn_bias(k)]
     flat64 = torch.cat([g64[k].reshape(-1) for k in names])

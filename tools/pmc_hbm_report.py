@@ -49,6 +49,7 @@ PATTERN = {
     'conv_wino2': (F_B32, W_B32, 'fused F(2x2) kernel: dword patch loads (8 x 32 pixel blocks + halo), filter slabs by LDS-DMA (L2-resident), '
                    'dword / 8-B output stores'),
     'conv_wgrad': (F_DMA, W_B32, 'direct weight-gradient calls: re-layout passes, GEMM kernel (operands by LDS-DMA), split-K reduce / finish kernels'),
+    'conv_wgrad_split': (F_DMA, W_B32, 'NCHW-direct 3x3 weight gradient on the bf16 pipe: x rows and dY slabs by LDS-DMA as they lie, partials by dword stores'),
     'conv_igemm': (F_B32, W_B32, 'direct forward / data-gradient calls: dword patch loads (+ small L2-resident filter slabs by LDS-DMA), dword stores'),
 }
 STEPS = int(os.environ.get('PMC_BENCH_STEPS', '3'))      # tools/pmc_hbm.sh: bench.py --steps 2 --warmup 1
