@@ -447,7 +447,7 @@ def main():
     ap.add_argument('--prof-steps', type=int, default=3, help='steps of the profiled pass (HIP events around every launch)')
     ap.add_argument('--layers-md', default=None, help='write per-layer tables of the profiled pass to this markdown file')
     ap.add_argument('--no-throttle', action='store_true', help='let the host run ahead until the hardware queue is full (it then spins in the '
-                    'launch call: one busy core per rank); default: dp.StepThrottle keeps it one step ahead, sleeping')
+                    'launch call: one busy core per rank); default: dp.StepThrottle keeps it one step ahead, sleeping between polls')
     ap.add_argument('--force-exchange', action='store_true', help='with --gpus 1: create a ONE-rank process group and run every '
                     'data-parallel collective through it (dp.force_exchange) -- the RCCL rehearsal a 1-GPU box allows')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend: 'nccl' (= RCCL over xGMI); "
@@ -595,7 +595,7 @@ def main():
             'peak_memory_bytes': {'allocated': int(torch.cuda.max_memory_allocated(dev)), 'reserved': int(torch.cuda.max_memory_reserved(dev)),
                                   'note': 'torch caching allocator, this rank, whole run (all passes); of 288 GB HBM3E'},
             'launch': 'launch by launch from Python (ctypes + autograd engine)',
-            'host': dict(host, cores_usable=effective_cores(), throttle=('off' if args.no_throttle else 'dp.StepThrottle(depth=1): blocking-sync event per step'),
+            'host': dict(host, cores_usable=effective_cores(), throttle=('off' if args.no_throttle else 'dp.StepThrottle(depth=1): event per step, polled with 1-ms sleeps'),
                          note='CPU seconds this rank spent issuing one step (all threads of the process) vs the step time: with N ranks '
                               'per node the sum over ranks has to fit the node\'s usable cores x ms_per_step'),
         }
