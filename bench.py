@@ -446,8 +446,8 @@ def main():
     ap.add_argument('--no-alt', action='store_true', help='skip the extra pass with the Winograd GEMMs on the fp32 matrix pipe')
     ap.add_argument('--prof-steps', type=int, default=3, help='steps of the profiled pass (HIP events around every launch)')
     ap.add_argument('--layers-md', default=None, help='write per-layer tables of the profiled pass to this markdown file')
-    ap.add_argument('--no-throttle', action='store_true', help='let the host run ahead until the hardware queue is full (it then spins in the '
-                    'launch call: one busy core per rank); default: dp.StepThrottle keeps it one step ahead, sleeping between polls')
+    ap.add_argument('--no-throttle', action='store_true', help='switch LAUNCH_WINDOW=0: let the host run ahead until the hardware queue is full (it then '
+                    'spins in the launch calls: one busy core per rank); default: at most 384 launches ahead, sleeping while it waits')
     ap.add_argument('--force-exchange', action='store_true', help='with --gpus 1: create a ONE-rank process group and run every '
                     'data-parallel collective through it (dp.force_exchange) -- the RCCL rehearsal a 1-GPU box allows')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend: 'nccl' (= RCCL over xGMI); "
@@ -486,6 +486,8 @@ def main():
     from fcd_gan_pytorch_amd import _lib, dp as fdp
     if forced:
         fdp.force_exchange(True)
+    if args.no_throttle:
+        _lib.set_switch('LAUNCH_WINDOW', 0)
     step, opts = build_workload(args, dev, rank)
 
     def barrier():
@@ -498,11 +500,8 @@ def main():
     barrier()
     # ---- headline: K steps, NO per-launch events (the profiler is a separate pass below)
     cpu0, thr0, t0 = time.process_time(), time.thread_time(), time.perf_counter()
-    throttle = None if args.no_throttle else fdp.StepThrottle(1, dev)
     for _ in range(args.steps):
         out = step()
-        if throttle:
-            throttle.tick()
     # host time the step's launches cost: CPU seconds of the whole process (Python thread + autograd engine thread + RCCL
     # proxy threads) up to the point where everything is queued, i.e. before the blocking synchronize
     cpu_queued, thr_queued, t_queued = time.process_time() - cpu0, time.thread_time() - thr0, time.perf_counter() - t0
@@ -595,7 +594,7 @@ def main():
             'peak_memory_bytes': {'allocated': int(torch.cuda.max_memory_allocated(dev)), 'reserved': int(torch.cuda.max_memory_reserved(dev)),
                                   'note': 'torch caching allocator, this rank, whole run (all passes); of 288 GB HBM3E'},
             'launch': 'launch by launch from Python (ctypes + autograd engine)',
-            'host': dict(host, cores_usable=effective_cores(), throttle=('off' if args.no_throttle else 'dp.StepThrottle(depth=1): event per step, polled with 1-ms sleeps'),
+            'host': dict(host, cores_usable=effective_cores(), launch_window=_lib.switch('LAUNCH_WINDOW'),
                          note='CPU seconds this rank spent issuing one step (all threads of the process) vs the step time: with N ranks '
                               'per node the sum over ranks has to fit the node\'s usable cores x ms_per_step'),
         }

@@ -65,6 +65,7 @@
   X(FUSED_GLUE, 1, "masked stacks / perception-tap MSE as fused kernels (0: ATen compositions)")                                    \
   X(D_SHARE, 1, "Demo_RSSS Discriminator step: the shared masked x through D's net once (0: twice, as the reference)")              \
   X(D_POOL, 0, "Discriminator pooled pair difference: 0 = fused kernel, 1 = ATen (f_x - f_y).mean(), 2 = mean first (round 3)")     \
+  X(LAUNCH_WINDOW, 384, "host: launches the issuing thread may be ahead of the device before it sleeps (0: run ahead until the hardware queue is full and spin there)") \
   X(STEP_OVERLAP, 0, "experimental: the Discriminator step of the adversarial loops on a second HIP stream")                        \
   X(DP_FORCE_EXCHANGE, 0, "one-rank process groups run every data-parallel collective")
 

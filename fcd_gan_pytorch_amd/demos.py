@@ -29,15 +29,12 @@ class _Epoch:
     def __iter__(self):
         loader = DataLoader(self.ds, batch_sampler=self.sampler)
         it = self.wrap(loader) if self.wrap else loader
-        throttle = dp.StepThrottle(1, self.device if torch.device(self.device).type == 'cuda' else None)
         for i, batch in enumerate(tiles.Prefetcher(it, self.device)):
             n = batch[0].shape[0]
             real = n - self.sampler.pads[i]
             w = _Weight(real / float(len(self.ds)))
             w.loss_scale = self.sampler.scales[i]         # != 1 only in the last batch under ragged='weighted' (pass to the step)
             yield batch, real, w
-            if torch.device(self.device).type == 'cuda':
-                throttle.tick()                           # the consumer's step for this batch is queued: stay one step ahead, sleeping
 
 
 class _Weight(float):

@@ -68,42 +68,6 @@ def exchanging(group=None):
     return 0
 
 
-class StepThrottle:
-    """Keeps the host at most ``depth`` steps ahead of the device, SLEEPING while it waits.
-
-    A train step is ~700 launches that the host queues in ~12 ms of real work; the device needs ~80 ms for them.  Left alone the
-    host runs ahead until the hardware queue is full and then SPINS inside the launch calls -- the Python thread during the forward
-    passes, the autograd engine's thread during backward: 82 ms of process CPU per 79-ms step (measured, `host` in the bench line),
-    i.e. one busy core per rank for nothing, which is what eight ranks + their RCCL proxy threads would fight over on a node whose
-    cgroup gives them 16 cores.  ``tick()`` after every step records an event and waits for the event of the
-    step ``depth`` ticks ago by POLLING ``event.query()`` with 1-ms sleeps: the queue never fills, the device always has between
-    ``depth`` and ``depth + 1`` steps of work queued (no bubble), and the wait costs no CPU.  (A ``hipEventBlockingSync`` event is
-    not enough on this stack: ``torch.cuda.Event(blocking=True).synchronize()`` measured 72 ms of CPU per step in the waiting
-    thread -- it spins too.)"""
-
-    def __init__(self, depth=1, device=None, poll_s=1e-3):
-        self.depth, self.device, self.poll_s, self.events = max(1, int(depth)), device, poll_s, []
-
-    def _wait(self, ev):
-        import time
-        while not ev.query():
-            time.sleep(self.poll_s)
-
-    def tick(self):
-        if not torch.cuda.is_available():
-            return
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.device))
-        self.events.append(ev)
-        if len(self.events) > self.depth:
-            self._wait(self.events.pop(0))
-
-    def drain(self):
-        for ev in self.events:
-            self._wait(ev)
-        self.events = []
-
-
 class RankStridedBatches:
     """Batch sampler (pass as ``DataLoader(batch_sampler=...)``).  ``pads[i]`` = number of trailing padded
     (duplicate) samples in this rank's i-th batch of the current epoch."""

@@ -1313,3 +1313,20 @@ def test_device_hyper_kernels_equal_scalar_kernels():
             res[mode, kind] = opt.flat_p.cpu().numpy()
     for kind in ('adam', 'rmsprop'):
         np.testing.assert_array_equal(res['scalar', kind], res['device', kind], err_msg=kind)
+
+
+def test_launch_window_bounds_how_far_the_host_runs_ahead(switches):
+    """``_ops._LaunchWindow`` (switch LAUNCH_WINDOW): every 128th C-ABI launch leaves an event, and the issuing thread waits (sleeping) on
+    the oldest while more than the window is outstanding -- so at most window / 128 events are ever pending; 0 switches it off."""
+    ops = _ops()
+    x = rnd(2, 8, 16, 16, seed=5).cuda()
+    win = ops._WINDOW
+    switches('LAUNCH_WINDOW', 256)
+    for _ in range(128 * 6):
+        y = ops.bn_act(x, None, ops.ACT_RELU)
+        assert len(win.events) <= 2
+    assert len(win.events) == 2 and torch.equal(y, torch.relu(x))
+    switches('LAUNCH_WINDOW', 0)
+    for _ in range(128 * 2):
+        ops.bn_act(x, None, ops.ACT_RELU)
+    assert len(win.events) == 0
