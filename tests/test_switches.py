@@ -64,3 +64,37 @@ def test_no_environment_read_on_any_call_path():
     for f in sorted(glob.glob(os.path.join(PKG, '*.py'))):
         for m in re.finditer(r"environ(?:\.get)?[\[(]\s*'([A-Z0-9_]+)'", open(f).read()):
             assert m.group(1) in allowed or not m.group(1).startswith('FCD'), (os.path.basename(f), m.group(1))
+
+
+def test_launch_window_logic_on_fake_events(monkeypatch):
+    """_ops._LaunchWindow without a device: every 128th launch records an event, the issuing thread polls the OLDEST one (sleeping) while
+    more than LAUNCH_WINDOW launches are outstanding, LAUNCH_WINDOW=0 drops everything."""
+    import torch
+    from fcd_gan_pytorch_amd import _lib, _ops
+    log = []
+
+    class FakeEvent:
+        def __init__(self):
+            self.polls = 0
+
+        def record(self, stream):
+            log.append(('record', stream))
+
+        def query(self):
+            self.polls += 1
+            return self.polls >= 3          # "done" at the third poll
+
+    monkeypatch.setattr(torch.cuda, 'Event', FakeEvent)
+    monkeypatch.setattr(torch.cuda, 'is_current_stream_capturing', lambda: False)
+    sleeps = []
+    monkeypatch.setattr(_ops.time, 'sleep', lambda s: sleeps.append(s))
+    win = _ops._LaunchWindow()
+    with _lib.switched(LAUNCH_WINDOW=256):
+        for i in range(128 * 5):
+            win.note('s0')
+            assert len(win.events) <= 2
+        assert len(log) == 5 and len(win.events) == 2 and len(sleeps) == 3 * 2       # three waits, two sleeping polls each
+    with _lib.switched(LAUNCH_WINDOW=0):
+        for i in range(128):
+            win.note('s0')
+        assert len(win.events) == 0 and len(log) == 5
