@@ -1322,6 +1322,7 @@ def test_launch_window_bounds_how_far_the_host_runs_ahead(switches):
     x = rnd(2, 8, 16, 16, seed=5).cuda()
     win = ops._WINDOW
     switches('LAUNCH_WINDOW', 256)
+    win.events.clear()                  # (what earlier tests left pending under the default window)
     for _ in range(128 * 6):
         y = ops.bn_act(x, None, ops.ACT_RELU)
         assert len(win.events) <= 2
